@@ -1,0 +1,454 @@
+"""CPU restatement of the DMVAE ELBO training step -- TEST INFRASTRUCTURE ONLY.
+
+This module is the parity oracle for the HIP hot path.  It is imported only by
+tests/, by __graft_entry__.smoke() and by bench.py's cpu_baseline leg; the
+product path (deep-mixture-vae_amd/) never imports it and fails loudly when the
+HIP library is missing.
+
+Pinning status (see DESIGN.md "Oracle"):
+  * prior / latent-variable math (rows A2, A6, A6b, A9, A10 of SURVEY.md 8a) is
+    pinned by golden vectors produced by executing the reference's own
+    code/priors.py (oracle/make_golden.py, fixtures in tests/golden/).
+  * dense layers, sigmoid cross-entropy, autodiff backward and Adam live in
+    TensorFlow 1.x (third party, not vendored, not installed): for those rows
+    this file restates the documented TF semantics; PARITY UNPINNED by any
+    reference run -- checked instead against closed forms and torch-autograd
+    float64 (tests/test_oracle_*.py).
+
+All functions are plain NumPy and dtype-generic (float64 for checking,
+float32 for the timed CPU baseline).  Reference citations are file:line under
+/root/reference/code/.
+"""
+import math
+
+import numpy as np
+
+# --------------------------------------------------------------------------
+# Model description
+# --------------------------------------------------------------------------
+
+
+class Config:
+    """Shapes of the MLP DMVAE (base_models.py:218-293, literals 500/500/2000,
+    decoder 2000/500/500).  enc/head/dec widths are parameters so that the
+    4x4096 configuration of BASELINE.json can be expressed."""
+
+    def __init__(self, input_dim=784, latent_dim=10, n_classes=10,
+                 enc_layers=(500, 500), head_dim=2000,
+                 dec_layers=(2000, 500, 500), input_type="binary"):
+        self.input_dim = int(input_dim)
+        self.latent_dim = int(latent_dim)
+        self.n_classes = int(n_classes)
+        self.enc_layers = tuple(int(v) for v in enc_layers)
+        self.head_dim = int(head_dim)
+        self.dec_layers = tuple(int(v) for v in dec_layers)
+        self.input_type = input_type
+
+    def layer_table(self):
+        """[(name, fan_in, fan_out, bias_kind)] in forward order.
+
+        bias_kind "zero": tf.layers.dense default bias (base_models.py:221-248,
+        291-293); "xavier": FullyConnected bias of shape (1,out) created with
+        the same xavier initializer (includes/layers.py:24-28)."""
+        t = []
+        prev = self.input_dim
+        for i, h in enumerate(self.enc_layers):
+            t.append(("enc%d" % i, prev, h, "zero"))
+            prev = h
+        trunk = prev
+        t.append(("zh", trunk, self.head_dim, "zero"))
+        t.append(("mean", self.head_dim, self.latent_dim, "zero"))
+        t.append(("logvar", self.head_dim, self.latent_dim, "zero"))
+        t.append(("ch", trunk, self.head_dim, "zero"))
+        t.append(("logits", self.head_dim, self.n_classes, "zero"))
+        prev = self.latent_dim
+        for i, h in enumerate(self.dec_layers):
+            t.append(("dec%d" % i, prev, h, "xavier"))
+            prev = h
+        t.append(("out", prev, self.input_dim, "zero"))
+        return t
+
+    def n_params(self):
+        n = 0
+        for _, fi, fo, _ in self.layer_table():
+            n += fi * fo + fo
+        return n + 2 * self.n_classes * self.latent_dim
+
+
+def xavier_uniform(rng, fan_in, fan_out, shape, dtype=np.float64):
+    """tf.contrib.layers.xavier_initializer(uniform=True): U(+-sqrt(6/(in+out)))
+    (train.py:197 passes it to every layer)."""
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(dtype)
+
+
+def init_params(cfg, seed=0, dtype=np.float64):
+    """Parameter creation, SURVEY 8a row A0.
+
+    dense kernels xavier-uniform, dense biases zero (base_models.py:221-248,
+    291-293); FullyConnected weight (in,out) AND bias (1,out) xavier-uniform
+    (includes/layers.py:24-28: for the bias fan_in=1, fan_out=out); prior
+    means ~ N(0,1), prior log_vars = 0 (priors.py:57-65)."""
+    rng = np.random.RandomState(seed)
+    p = {}
+    for name, fi, fo, bk in cfg.layer_table():
+        p["W_" + name] = xavier_uniform(rng, fi, fo, (fi, fo), dtype)
+        if bk == "zero":
+            p["b_" + name] = np.zeros((fo,), dtype)
+        else:
+            p["b_" + name] = xavier_uniform(rng, 1, fo, (fo,), dtype)
+    p["prior_means"] = rng.randn(cfg.n_classes, cfg.latent_dim).astype(dtype)
+    p["prior_log_vars"] = np.zeros((cfg.n_classes, cfg.latent_dim), dtype)
+    return p
+
+
+def param_names(cfg):
+    names = []
+    for name, _, _, _ in cfg.layer_table():
+        names += ["W_" + name, "b_" + name]
+    return names + ["prior_means", "prior_log_vars"]
+
+
+# --------------------------------------------------------------------------
+# Latent-variable math (priors.py)
+# --------------------------------------------------------------------------
+
+
+def sample_gumbel(shape, rng=None, eps=1e-20):
+    """includes/utils.py:17-19: U~U(0,1); -log(eps - log(U + eps))."""
+    rng = np.random if rng is None else rng
+    U = rng.uniform(0, 1, shape)
+    return -np.log(eps - np.log(U + eps))
+
+
+def softmax(a):
+    a = a - np.max(a, axis=-1, keepdims=True)
+    e = np.exp(a)
+    return e / np.sum(e, axis=-1, keepdims=True)
+
+
+def gaussian_reparam(mean, log_var, epsilon):
+    """priors.py:86-89: Z = mean + exp(log_var/2) * epsilon."""
+    return mean + np.exp(log_var / 2) * epsilon
+
+
+def gumbel_softmax(logits, gumbel, temperature):
+    """priors.py:170-181: softmax((logits + g) / temperature), logits (B,K),
+    g (B,K) (reference shape (B,1,K) flattened)."""
+    return softmax((logits + gumbel) / temperature)
+
+
+def kl_mixture_exact(mean, log_var, weights, prior_means, prior_log_vars):
+    """priors.py:131-145 (cluster_sample=False, the live branch)."""
+    pm = prior_means[None, :, :]
+    plv = prior_log_vars[None, :, :]
+    mu = mean[:, None, :]
+    lv = log_var[:, None, :]
+    res = plv - lv - 1 + (np.exp(lv) + np.square(mu - pm)) / np.exp(plv)
+    res = np.sum(res, axis=-1)
+    res = np.sum(res * weights, axis=-1)
+    return np.mean(0.5 * res)
+
+
+def kl_mixture_relaxed(mean, log_var, weights, prior_means, prior_log_vars):
+    """priors.py:119-128 (cluster_sample=True)."""
+    pm = weights @ prior_means
+    plv = weights @ prior_log_vars
+    res = plv - log_var - 1 + (np.exp(log_var) + np.square(mean - pm)) / np.exp(plv)
+    return np.mean(0.5 * np.sum(res, axis=1))
+
+
+def kl_categorical(logits, n_classes, eps=1e-20):
+    """priors.py:183-201 with dim=1."""
+    q = softmax(logits)
+    res = q * (np.log(q + eps) - np.log(1.0 / n_classes))
+    return np.mean(np.sum(res, axis=1))
+
+
+def kl_normal(mean, log_var):
+    """NormalFactorial.kl_from_prior, priors.py:38-47 (K=1 known answer)."""
+    res = np.exp(log_var) + np.square(mean) - 1.0 - log_var
+    return np.mean(0.5 * np.sum(res, axis=1))
+
+
+def cluster_probs(Z, prior_means, prior_log_vars):
+    """priors.py:91-102."""
+    z = Z[:, None, :]
+    pm = prior_means[None]
+    plv = prior_log_vars[None]
+    p = -(np.sum(np.square(z - pm) / np.exp(plv), axis=-1) + np.sum(plv, axis=-1)) / 2
+    return softmax(p)
+
+
+# --------------------------------------------------------------------------
+# Forward / loss / backward of the whole step
+# --------------------------------------------------------------------------
+
+
+def _dense(x, W, b, relu):
+    y = x @ W + b
+    return np.maximum(y, 0) if relu else y
+
+
+def encode(p, cfg, X):
+    """Encoder trunk + z head + c head, base_models.py:220-249."""
+    acts = {"x": X}
+    h = X
+    for i in range(len(cfg.enc_layers)):
+        h = _dense(h, p["W_enc%d" % i], p["b_enc%d" % i], True)
+        acts["enc%d" % i] = h
+    acts["zh"] = _dense(h, p["W_zh"], p["b_zh"], True)
+    acts["mean"] = _dense(acts["zh"], p["W_mean"], p["b_mean"], False)
+    acts["logvar"] = _dense(acts["zh"], p["W_logvar"], p["b_logvar"], False)
+    acts["ch"] = _dense(h, p["W_ch"], p["b_ch"], True)
+    acts["logits"] = _dense(acts["ch"], p["W_logits"], p["b_logits"], False)
+    return acts
+
+
+def decode(p, cfg, Z, acts=None):
+    """Decoder FullyConnected x3 + linear dense, base_models.py:279-293."""
+    acts = {} if acts is None else acts
+    h = Z
+    for i in range(len(cfg.dec_layers)):
+        h = _dense(h, p["W_dec%d" % i], p["b_dec%d" % i], True)
+        acts["dec%d" % i] = h
+    acts["xlogits"] = _dense(h, p["W_out"], p["b_out"], False)
+    return acts
+
+
+def recon_loss(cfg, X, xlogits):
+    """base_models.py:72-85; binary branch = tf.nn.sigmoid_cross_entropy_with_
+    logits = max(l,0) - l*x + log(1+exp(-|l|))."""
+    if cfg.input_type == "binary":
+        l = xlogits
+        per = np.maximum(l, 0) - l * X + np.log1p(np.exp(-np.abs(l)))
+        return np.mean(np.sum(per, axis=1))
+    elif cfg.input_type == "real":
+        return 0.5 * np.mean(np.sum(np.square(X - xlogits), axis=1))
+    raise NotImplementedError
+
+
+def forward(p, cfg, X, epsilon, kl_ratio=1.0, mode="exact", gumbel=None,
+            temperature=1.0):
+    """One forward pass of the loss, base_models.py:66-93,158-302.
+
+    mode "exact": the checked-in graph (cluster_sample False, weights =
+    softmax(logits)).  mode "relaxed": weights = Gumbel-Softmax sample feeding
+    the cluster_sample=True KL branch (report/report.tex:330-333)."""
+    a = encode(p, cfg, X)
+    a["eps"] = epsilon
+    a["Z"] = gaussian_reparam(a["mean"], a["logvar"], epsilon)
+    decode(p, cfg, a["Z"], a)
+    a["q"] = softmax(a["logits"])
+    if mode == "exact":
+        a["w"] = a["q"]
+        a["kl_z"] = kl_mixture_exact(a["mean"], a["logvar"], a["w"],
+                                     p["prior_means"], p["prior_log_vars"])
+    elif mode == "relaxed":
+        a["w"] = gumbel_softmax(a["logits"], gumbel, temperature)
+        a["kl_z"] = kl_mixture_relaxed(a["mean"], a["logvar"], a["w"],
+                                       p["prior_means"], p["prior_log_vars"])
+    else:
+        raise ValueError(mode)
+    a["kl_c"] = kl_categorical(a["logits"], cfg.n_classes)
+    a["recon"] = recon_loss(cfg, X, a["xlogits"])
+    a["latent"] = a["kl_c"] + a["kl_z"]
+    a["loss"] = a["recon"] + kl_ratio * a["latent"]
+    a["mode"] = mode
+    a["kl_ratio"] = kl_ratio
+    a["temperature"] = temperature
+    return a
+
+
+def latent_backward(cfg, a, p, dZ):
+    """Hand-derived gradients of kl_ratio*(KL_C+KL_Z) and of the reparam,
+    SURVEY 8a row A13.  Returns dmean, dlogvar, dlogits, dprior_means,
+    dprior_log_vars.  dZ is dLoss/dZ from the decoder."""
+    mu, lv, eps = a["mean"], a["logvar"], a["eps"]
+    pm, plv = p["prior_means"], p["prior_log_vars"]
+    B = mu.shape[0]
+    K = cfg.n_classes
+    r = a["kl_ratio"]
+    e = np.exp(lv)
+    q = a["q"]
+    e0 = 1e-20
+    # KL_C = mean_b sum_k q (log(q+e0) + log K)
+    dq = (r / B) * (np.log(q + e0) + q / (q + e0) + math.log(K))
+    dlogits = q * (dq - np.sum(q * dq, axis=1, keepdims=True))
+    if a["mode"] == "exact":
+        w = a["w"]
+        ip = np.exp(-plv)                                   # (K,D)
+        diff = mu[:, None, :] - pm[None]                    # (B,K,D)
+        t = plv[None] - lv[:, None, :] - 1 + (e[:, None, :] + diff ** 2) * ip[None]
+        dw = (r / (2 * B)) * np.sum(t, axis=2)              # (B,K)
+        dlogits = dlogits + w * (dw - np.sum(w * dw, axis=1, keepdims=True))
+        gmu = (r / B) * np.sum(w[:, :, None] * diff * ip[None], axis=1)
+        glv = (r / (2 * B)) * (e * (w @ ip) - 1)
+        dpm = -(r / B) * np.sum(w[:, :, None] * diff * ip[None], axis=0)
+        dplv = (r / (2 * B)) * np.sum(
+            w[:, :, None] * (1 - (e[:, None, :] + diff ** 2) * ip[None]), axis=0)
+    else:
+        w = a["w"]
+        tau = a["temperature"]
+        bpm = w @ pm
+        bplv = w @ plv
+        ibp = np.exp(-bplv)
+        diff = mu - bpm
+        gmu = (r / B) * diff * ibp
+        glv = (r / (2 * B)) * (e * ibp - 1)
+        dbpm = -(r / B) * diff * ibp
+        dbplv = (r / (2 * B)) * (1 - (e + diff ** 2) * ibp)
+        dw = dbpm @ pm.T + dbplv @ plv.T                    # (B,K)
+        dpm = w.T @ dbpm
+        dplv = w.T @ dbplv
+        dlogits = dlogits + (1.0 / tau) * w * (dw - np.sum(w * dw, axis=1, keepdims=True))
+    dmean = dZ + gmu
+    dlogvar = dZ * eps * 0.5 * np.exp(lv / 2) + glv
+    return dmean, dlogvar, dlogits, dpm, dplv
+
+
+def backward(p, cfg, a):
+    """Gradient of a["loss"] w.r.t. every trainable (what optimizer.minimize
+    derives through tf.gradients, base_models.py:110)."""
+    g = {}
+    X = a["x"]
+    B = X.shape[0]
+    if cfg.input_type == "binary":
+        l = a["xlogits"]
+        dl = (1.0 / (1.0 + np.exp(-l)) - X) / B
+    else:
+        dl = (a["xlogits"] - X) / B
+    nd = len(cfg.dec_layers)
+    h = a["dec%d" % (nd - 1)]
+    g["W_out"] = h.T @ dl
+    g["b_out"] = dl.sum(0)
+    dh = dl @ p["W_out"].T
+    for i in reversed(range(nd)):
+        y = a["dec%d" % i]
+        dy = dh * (y > 0)
+        xin = a["dec%d" % (i - 1)] if i > 0 else a["Z"]
+        g["W_dec%d" % i] = xin.T @ dy
+        g["b_dec%d" % i] = dy.sum(0)
+        dh = dy @ p["W_dec%d" % i].T
+    dZ = dh
+    dmean, dlogvar, dlogits, dpm, dplv = latent_backward(cfg, a, p, dZ)
+    g["prior_means"] = dpm
+    g["prior_log_vars"] = dplv
+    g["W_mean"] = a["zh"].T @ dmean
+    g["b_mean"] = dmean.sum(0)
+    g["W_logvar"] = a["zh"].T @ dlogvar
+    g["b_logvar"] = dlogvar.sum(0)
+    dzh = (dmean @ p["W_mean"].T + dlogvar @ p["W_logvar"].T) * (a["zh"] > 0)
+    g["W_logits"] = a["ch"].T @ dlogits
+    g["b_logits"] = dlogits.sum(0)
+    dch = (dlogits @ p["W_logits"].T) * (a["ch"] > 0)
+    ne = len(cfg.enc_layers)
+    trunk = a["enc%d" % (ne - 1)]
+    g["W_zh"] = trunk.T @ dzh
+    g["b_zh"] = dzh.sum(0)
+    g["W_ch"] = trunk.T @ dch
+    g["b_ch"] = dch.sum(0)
+    dh = dzh @ p["W_zh"].T + dch @ p["W_ch"].T
+    for i in reversed(range(ne)):
+        y = a["enc%d" % i]
+        dy = dh * (y > 0)
+        xin = a["enc%d" % (i - 1)] if i > 0 else X
+        g["W_enc%d" % i] = xin.T @ dy
+        g["b_enc%d" % i] = dy.sum(0)
+        if i > 0:
+            dh = dy @ p["W_enc%d" % i].T
+    return g
+
+
+# --------------------------------------------------------------------------
+# Optimizer and epoch semantics
+# --------------------------------------------------------------------------
+
+
+def adam_tf_init(p):
+    return ({k: np.zeros_like(v) for k, v in p.items()},
+            {k: np.zeros_like(v) for k, v in p.items()})
+
+
+def adam_tf(p, g, m, v, t, lr=0.002, beta1=0.9, beta2=0.999, epsilon=1e-8):
+    """tf.train.AdamOptimizer (TF 1.x) update, base_models.py:95-110:
+    lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; theta -= lr_t*m/(sqrt(v)+eps)
+    (eps outside the bias correction).  lr is constant.  t starts
+    at 1.  Updates p, m, v in place for the keys present in g."""
+    lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    for k in g:
+        m[k] = beta1 * m[k] + (1 - beta1) * g[k]
+        v[k] = beta2 * v[k] + (1 - beta2) * g[k] * g[k]
+        p[k] = p[k] - (lr_t * m[k] / (np.sqrt(v[k]) + epsilon)).astype(p[k].dtype)
+    return p, m, v
+
+
+def train_step(p, m, v, t, cfg, X, epsilon, kl_ratio=1.0, lr=0.002,
+               mode="exact", gumbel=None, temperature=1.0):
+    """One session.run([loss, train_step]) of base_models.py:126-129."""
+    a = forward(p, cfg, X, epsilon, kl_ratio, mode, gumbel, temperature)
+    g = backward(p, cfg, a)
+    adam_tf(p, g, m, v, t, lr)
+    return a, g
+
+
+class Dataset:
+    """includes/utils.py:428-466: shuffle on construction and at every
+    get_batches(); emit consecutive batches, last one may be short."""
+
+    def __init__(self, data, batch_size=100, shuffle=True, rng=None):
+        data, classes = data
+        self.rng = np.random if rng is None else rng
+        self.data = np.copy(data)
+        self.classes = np.copy(classes)
+        self.batch_size = batch_size
+        self.shuffle = shuffle
+        self.data_dim = self.data.shape[1]
+        self.epoch_len = int(math.ceil(len(self.data) / batch_size))
+        if shuffle:
+            idx = self.rng.permutation(len(self.data))
+            self.data = self.data[idx]
+            self.classes = self.classes[idx]
+
+    def get_batches(self):
+        if self.shuffle:
+            idx = self.rng.permutation(len(self.data))
+            self.data = self.data[idx]
+            self.classes = self.classes[idx]
+        for s in range(0, len(self.data), self.batch_size):
+            yield self.data[s:s + self.batch_size]
+
+    def __len__(self):
+        return self.epoch_len
+
+
+def train_epoch(p, m, v, t0, cfg, data, noise_fn, kl_ratio=1.0, lr=0.002):
+    """VAE.train_op, base_models.py:112-132: loss += batch_loss/epoch_len."""
+    loss = 0.0
+    t = t0
+    for batch in data.get_batches():
+        t += 1
+        a, _ = train_step(p, m, v, t, cfg, batch, noise_fn(len(batch)), kl_ratio, lr)
+        loss += a["loss"] / data.epoch_len
+    return loss, t
+
+
+def clustering_accuracy(weights, classes):
+    """includes/utils.py:22-34 with scipy's Hungarian solver in place of the
+    removed sklearn.utils.linear_assignment_."""
+    from scipy.optimize import linear_sum_assignment
+    clusters = np.argmax(weights, axis=-1)
+    n = weights.shape[1]
+    d = np.zeros((n, n), dtype=np.int64)
+    for c, y in zip(clusters, classes):
+        d[c, y] += 1
+    r, c = linear_sum_assignment(d.max() - d)
+    return d[r, c].sum() / float(len(clusters))
+
+
+def synthetic_images(n, dim=784, seed=0, density=0.19, dtype=np.float32):
+    """Deterministic MNIST-like stand-in: x = u * 1[v < density]."""
+    rng = np.random.default_rng(seed)
+    u = rng.random((n, dim), dtype=np.float32)
+    v = rng.random((n, dim), dtype=np.float32)
+    return (u * (v < density)).astype(dtype)
