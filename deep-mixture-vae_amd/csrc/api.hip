@@ -1,0 +1,600 @@
+// extern "C" surface of libdmvae_hip.so (include/dmvae_hip.h): argument
+// checking, the step plan (arena layout + the launch sequence of one
+// session.run([loss, train_step])), and HIP-event profiling of every launch.
+#include <stdarg.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace dmvae {
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ profiling
+struct ProfRec { const char* name; double flops, bytes; hipEvent_t e0, e1; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_event_pool;
+static std::mutex g_prof_mu;
+
+static hipEvent_t get_event() {
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+ProfScope::ProfScope(hipStream_t s_, const char* name, double flops, double bytes) : s(s_), slot(-1) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r{name, flops, bytes, get_event(), get_event()};
+    (void)hipEventRecord(r.e0, s);
+    slot = (int)g_prof.size();
+    g_prof.push_back(r);
+}
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    (void)hipEventRecord(g_prof[slot].e1, s);
+}
+
+static const char* gemm_name(int dtype, int layout) {
+    static const char* n[2][3] = {{"gemm_f32_fwd", "gemm_f32_dx", "gemm_f32_dw"}, {"gemm_bf16_fwd", "gemm_bf16_dx", "gemm_bf16_dw"}};
+    return n[dtype][layout];
+}
+
+static int gemm_checked(hipStream_t s, int dtype, int layout, int M, int N, int K, const void* A, int64_t lda,
+                        const void* B, int64_t ldb, const dmvae_epilogue* epi, int split) {
+    DMVAE_REQUIRE(dtype == DMVAE_F32 || dtype == DMVAE_BF16, "dmvae_gemm: bad dtype %d", dtype);
+    DMVAE_REQUIRE(layout >= 0 && layout <= 2, "dmvae_gemm: bad layout %d", layout);
+    DMVAE_REQUIRE(A && B && epi && epi->out, "dmvae_gemm: null pointer");
+    DMVAE_REQUIRE(M > 0 && N > 0 && K > 0 && M % 64 == 0 && N % 64 == 0 && K % 64 == 0,
+                  "dmvae_gemm: M=%d N=%d K=%d must be positive multiples of 64 (pad the operands)", M, N, K);
+    DMVAE_REQUIRE(split >= 1 && K % (split * 64) == 0, "dmvae_gemm: split_k=%d does not divide K=%d into multiples of 64", split, K);
+    DMVAE_REQUIRE(split == 1 || epi->kind == DMVAE_EPI_ATOMIC_F32, "dmvae_gemm: split_k > 1 needs DMVAE_EPI_ATOMIC_F32");
+    const int esz = dtype == DMVAE_BF16 ? 2 : 4;
+    DMVAE_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && (lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0,
+                  "dmvae_gemm: operands must be 16-byte aligned with 16-byte multiple row strides");
+    GemmArgs a;
+    a.A = A; a.lda = lda; a.B = B; a.ldb = ldb;
+    a.M = M; a.N = N; a.K = K; a.k_split = K / split;
+    a.epi = *epi;
+    if (a.epi.m_valid <= 0) a.epi.m_valid = M;
+    if (a.epi.n_valid <= 0) a.epi.n_valid = N;
+    const double bytes = (double)esz * ((double)M * K + (double)K * N) + (double)M * N * (epi->kind == DMVAE_EPI_STORE_F32 || epi->kind == DMVAE_EPI_ATOMIC_F32 || epi->kind == DMVAE_EPI_BIAS_F32 ? 4 : esz);
+    ProfScope ps(s, gemm_name(dtype, layout), 2.0 * M * N * (double)K, bytes);
+    return dtype == DMVAE_BF16 ? gemm_bf16_dispatch(s, layout, a, split) : gemm_f32_dispatch(s, layout, a, split);
+}
+
+static int gemm_partials(int dtype, int M, int N) {
+    if (dtype == DMVAE_F32) return (M / 64) * (N / 64);
+    const int t = gemm_bf16_tile_m(M, N, 1);
+    return (M / (t / 1000)) * (N / (t % 1000));
+}
+
+}  // namespace dmvae
+
+using namespace dmvae;
+
+// ====================================================================== plan
+static inline int pad64(int x) { return (x + 63) / 64 * 64; }
+static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+struct PLayer {
+    std::string name;
+    int in, out, in_pad, out_pad;
+    int64_t w_off, b_off, ldw;    // arena element offsets; ldw = row stride of W
+};
+
+struct dmvae_plan {
+    dmvae_config cfg;
+    int Bp, Ip, Dp, Kp, Hp, Tp;   // padded batch / input / latent / classes / head / trunk
+    int es;                        // bytes per activation element
+    std::vector<PLayer> enc, dec;
+    PLayer zc, mv, lg, out;        // fused z|c hidden, fused mean|log_var, logits, output layer
+    int64_t prior_off;             // prior_means [K][D] then prior_log_vars [K][D], contiguous
+    int64_t param_elems;
+    std::vector<dmvae_tensor_info> tensors;
+    // workspace byte offsets
+    int64_t o_x, o_xf, o_hzc, o_mv, o_lg, o_Z, o_Zf, o_gmu, o_glv, o_clv, o_w, o_dlg, o_recon, o_dl, o_dmv, o_dhzc;
+    std::vector<int64_t> o_enc, o_dec, o_denc, o_ddec;
+    int64_t o_rpart, o_lpart, o_dprior, o_cs;
+    int n_rpart, n_lblk;
+    int64_t cs_elems;
+    int64_t work_bytes;
+    dmvae_buffers buf;
+    bool bound;
+};
+
+static void add_tensor(dmvae_plan* p, const std::string& name, int64_t off, int rows, int cols, int64_t ld) {
+    dmvae_tensor_info t;
+    memset(&t, 0, sizeof(t));
+    snprintf(t.name, sizeof(t.name), "%s", name.c_str());
+    t.offset = off; t.rows = rows; t.cols = cols; t.ld = ld;
+    p->tensors.push_back(t);
+}
+
+extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
+    DMVAE_REQUIRE(c && out, "dmvae_plan_create: null argument");
+    DMVAE_REQUIRE(c->input_dim > 0 && c->latent_dim > 0 && c->n_classes > 0 && c->head_dim > 0, "dmvae_plan_create: bad dims");
+    DMVAE_REQUIRE(c->n_enc >= 1 && c->n_enc <= DMVAE_MAX_LAYERS && c->n_dec >= 1 && c->n_dec <= DMVAE_MAX_LAYERS, "dmvae_plan_create: 1..%d layers", DMVAE_MAX_LAYERS);
+    DMVAE_REQUIRE(c->dtype == DMVAE_F32 || c->dtype == DMVAE_BF16, "dmvae_plan_create: bad dtype");
+    DMVAE_REQUIRE(c->max_batch > 0, "dmvae_plan_create: max_batch must be > 0");
+    dmvae_plan* p = new dmvae_plan();
+    p->cfg = *c;
+    p->bound = false;
+    p->es = c->dtype == DMVAE_BF16 ? 2 : 4;
+    p->Bp = (c->max_batch + 127) / 128 * 128;
+    p->Ip = pad64(c->input_dim);
+    p->Dp = pad64(c->latent_dim);
+    p->Kp = pad64(c->n_classes);
+    p->Hp = pad64(c->head_dim);
+    int64_t off = 0;
+    auto place = [&](PLayer& L, const std::string& name, int in, int out_, int in_pad, int out_pad) {
+        L.name = name; L.in = in; L.out = out_; L.in_pad = in_pad; L.out_pad = out_pad; L.ldw = out_pad;
+        L.w_off = off; off += (int64_t)in_pad * out_pad;
+        L.b_off = off; off += out_pad;
+    };
+    int prev = c->input_dim, prev_pad = p->Ip;
+    for (int i = 0; i < c->n_enc; ++i) {
+        PLayer L;
+        place(L, "enc" + std::to_string(i), prev, c->enc[i], prev_pad, pad64(c->enc[i]));
+        add_tensor(p, "W_" + L.name, L.w_off, L.in, L.out, L.ldw);
+        add_tensor(p, "b_" + L.name, L.b_off, 1, L.out, L.out_pad);
+        p->enc.push_back(L);
+        prev = c->enc[i]; prev_pad = L.out_pad;
+    }
+    p->Tp = prev_pad;
+    place(p->zc, "zc", prev, 2 * p->Hp, p->Tp, 2 * p->Hp);
+    add_tensor(p, "W_zh", p->zc.w_off, prev, c->head_dim, p->zc.ldw);
+    add_tensor(p, "b_zh", p->zc.b_off, 1, c->head_dim, 2 * p->Hp);
+    add_tensor(p, "W_ch", p->zc.w_off + p->Hp, prev, c->head_dim, p->zc.ldw);
+    add_tensor(p, "b_ch", p->zc.b_off + p->Hp, 1, c->head_dim, 2 * p->Hp);
+    place(p->mv, "mv", c->head_dim, 2 * p->Dp, p->Hp, 2 * p->Dp);
+    add_tensor(p, "W_mean", p->mv.w_off, c->head_dim, c->latent_dim, p->mv.ldw);
+    add_tensor(p, "b_mean", p->mv.b_off, 1, c->latent_dim, 2 * p->Dp);
+    add_tensor(p, "W_logvar", p->mv.w_off + p->Dp, c->head_dim, c->latent_dim, p->mv.ldw);
+    add_tensor(p, "b_logvar", p->mv.b_off + p->Dp, 1, c->latent_dim, 2 * p->Dp);
+    place(p->lg, "logits", c->head_dim, c->n_classes, p->Hp, p->Kp);
+    add_tensor(p, "W_logits", p->lg.w_off, c->head_dim, c->n_classes, p->lg.ldw);
+    add_tensor(p, "b_logits", p->lg.b_off, 1, c->n_classes, p->Kp);
+    prev = c->latent_dim; prev_pad = p->Dp;
+    for (int i = 0; i < c->n_dec; ++i) {
+        PLayer L;
+        place(L, "dec" + std::to_string(i), prev, c->dec[i], prev_pad, pad64(c->dec[i]));
+        add_tensor(p, "W_" + L.name, L.w_off, L.in, L.out, L.ldw);
+        add_tensor(p, "b_" + L.name, L.b_off, 1, L.out, L.out_pad);
+        p->dec.push_back(L);
+        prev = c->dec[i]; prev_pad = L.out_pad;
+    }
+    place(p->out, "out", prev, c->input_dim, prev_pad, p->Ip);
+    add_tensor(p, "W_out", p->out.w_off, prev, c->input_dim, p->out.ldw);
+    add_tensor(p, "b_out", p->out.b_off, 1, c->input_dim, p->Ip);
+    p->prior_off = off;
+    const int KD = c->n_classes * c->latent_dim;
+    add_tensor(p, "prior_means", off, c->n_classes, c->latent_dim, c->latent_dim);
+    add_tensor(p, "prior_log_vars", off + KD, c->n_classes, c->latent_dim, c->latent_dim);
+    off += align_up(2 * (int64_t)KD, 64);
+    p->param_elems = off;
+
+    // ---- workspace
+    int64_t w = 0;
+    auto take = [&](int64_t bytes) { int64_t o = w; w += align_up(bytes, 256); return o; };
+    const int64_t Bp = p->Bp, es = p->es;
+    p->o_xf = take(Bp * p->Ip * 4);
+    p->o_x = (c->dtype == DMVAE_F32) ? p->o_xf : take(Bp * p->Ip * es);
+    for (auto& L : p->enc) p->o_enc.push_back(take(Bp * L.out_pad * es));
+    p->o_hzc = take(Bp * 2 * p->Hp * es);
+    p->o_mv = take(Bp * 2 * p->Dp * 4);
+    p->o_lg = take(Bp * p->Kp * 4);
+    p->o_Z = take(Bp * p->Dp * es);
+    p->o_Zf = take(Bp * p->Dp * 4);
+    p->o_gmu = take(Bp * p->Dp * 4);
+    p->o_glv = take(Bp * p->Dp * 4);
+    p->o_clv = take(Bp * p->Dp * 4);
+    p->o_w = take(Bp * p->Kp * 4);
+    p->o_dlg = take(Bp * p->Kp * es);
+    for (auto& L : p->dec) p->o_dec.push_back(take(Bp * L.out_pad * es));
+    p->o_recon = take(Bp * p->Ip * 4);
+    p->o_dl = take(Bp * p->Ip * es);
+    for (auto& L : p->dec) p->o_ddec.push_back(take(Bp * L.out_pad * es));
+    p->o_dmv = take(Bp * 2 * p->Dp * es);
+    p->o_dhzc = take(Bp * 2 * p->Hp * es);
+    for (auto& L : p->enc) p->o_denc.push_back(take(Bp * L.out_pad * es));
+    p->n_rpart = gemm_partials(c->dtype, p->Bp, p->Ip);
+    p->o_rpart = take((int64_t)p->n_rpart * 4);
+    p->n_lblk = latent_nblocks(p->Bp, c->latent_dim, c->n_classes);
+    p->o_lpart = take((int64_t)p->n_lblk * 2 * 4);
+    p->o_dprior = take((int64_t)p->n_lblk * 2 * KD * 4);
+    int maxN = std::max(2 * p->Hp, p->Ip);
+    for (auto& L : p->enc) maxN = std::max(maxN, L.out_pad);
+    for (auto& L : p->dec) maxN = std::max(maxN, L.out_pad);
+    maxN = std::max(maxN, 2 * KD);
+    p->cs_elems = (int64_t)64 * maxN;
+    p->o_cs = take(p->cs_elems * 4);
+    p->work_bytes = w;
+    *out = p;
+    return 0;
+}
+
+extern "C" void dmvae_plan_destroy(dmvae_plan* p) { delete p; }
+
+extern "C" int dmvae_plan_sizes(const dmvae_plan* p, dmvae_sizes* o) {
+    DMVAE_REQUIRE(p && o, "dmvae_plan_sizes: null argument");
+    o->param_elems = p->param_elems;
+    o->work_bytes = p->work_bytes;
+    o->batch_pad = p->Bp;
+    o->input_pad = p->Ip;
+    o->n_tensors = (int)p->tensors.size();
+    o->reserved = 0;
+    return 0;
+}
+extern "C" int dmvae_plan_tensor(const dmvae_plan* p, int i, dmvae_tensor_info* o) {
+    DMVAE_REQUIRE(p && o && i >= 0 && i < (int)p->tensors.size(), "dmvae_plan_tensor: bad index %d", i);
+    *o = p->tensors[i];
+    return 0;
+}
+extern "C" int dmvae_plan_bind(dmvae_plan* p, const dmvae_buffers* b) {
+    DMVAE_REQUIRE(p && b && b->param && b->grad && b->m && b->v && b->work && b->state, "dmvae_plan_bind: null buffer");
+    DMVAE_REQUIRE(p->cfg.dtype == DMVAE_F32 || b->param_bf16, "dmvae_plan_bind: bf16 plan needs the bf16 parameter shadow");
+    DMVAE_REQUIRE((uintptr_t)b->work % 256 == 0 && (uintptr_t)b->param % 256 == 0 && (uintptr_t)b->grad % 256 == 0, "dmvae_plan_bind: buffers must be 256-byte aligned");
+    p->buf = *b;
+    p->bound = true;
+    return 0;
+}
+
+#define WS(p, off) (reinterpret_cast<char*>((p)->buf.work) + (off))
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+// weights as seen by the GEMMs: bf16 shadow or the f32 master
+static inline const void* Wp(const dmvae_plan* p, int64_t off) {
+    return p->cfg.dtype == DMVAE_BF16 ? (const void*)(reinterpret_cast<const bf16_t*>(p->buf.param_bf16) + off)
+                                      : (const void*)(p->buf.param + off);
+}
+static inline const void* act_off(const dmvae_plan* p, int64_t base, int64_t elems) { return WS(p, base) + elems * p->es; }
+
+extern "C" int dmvae_plan_load_batch(dmvae_plan* p, void* stream, const float* data, int64_t n_rows, const int32_t* perm,
+                                     int64_t first, int n_valid, int use_state_cursor) {
+    DMVAE_REQUIRE(p && p->bound && data, "dmvae_plan_load_batch: plan not bound / null data");
+    DMVAE_REQUIRE(n_valid >= 0 && n_valid <= p->cfg.max_batch, "dmvae_plan_load_batch: n_valid=%d exceeds max_batch=%d", n_valid, p->cfg.max_batch);
+    hipStream_t s = (hipStream_t)stream;
+    void* xa = p->cfg.dtype == DMVAE_BF16 ? (void*)WS(p, p->o_x) : nullptr;
+    return gather_launch(s, p->cfg.dtype, data, n_rows, p->cfg.input_dim, perm, first, p->cfg.max_batch, n_valid, p->Bp, xa, p->Ip,
+                         reinterpret_cast<float*>(WS(p, p->o_xf)), p->Ip, p->Ip, use_state_cursor ? p->buf.state : nullptr);
+}
+
+static int fwd_dense(dmvae_plan* p, hipStream_t s, const void* A, int64_t lda, int Kdim, const PLayer& L, int N, int64_t w_col,
+                     int kind, void* out, int64_t ldo) {
+    dmvae_epilogue e;
+    memset(&e, 0, sizeof(e));
+    e.kind = kind; e.out = out; e.ldo = ldo; e.bias = p->buf.param + L.b_off + w_col;
+    return gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_FWD, p->Bp, N, Kdim, A, lda,
+                        reinterpret_cast<const char*>(Wp(p, L.w_off + w_col)), L.ldw, &e, 1);
+}
+
+static int encode_impl(dmvae_plan* p, hipStream_t s) {
+    const void* in = WS(p, p->o_x);
+    int64_t ld = p->Ip;
+    int kd = p->Ip;
+    for (size_t i = 0; i < p->enc.size(); ++i) {
+        const PLayer& L = p->enc[i];
+        TRY(fwd_dense(p, s, in, ld, kd, L, L.out_pad, 0, DMVAE_EPI_BIAS_RELU, WS(p, p->o_enc[i]), L.out_pad));
+        in = WS(p, p->o_enc[i]); ld = L.out_pad; kd = L.out_pad;
+    }
+    TRY(fwd_dense(p, s, in, ld, kd, p->zc, 2 * p->Hp, 0, DMVAE_EPI_BIAS_RELU, WS(p, p->o_hzc), 2 * p->Hp));
+    TRY(fwd_dense(p, s, WS(p, p->o_hzc), 2 * p->Hp, p->Hp, p->mv, 2 * p->Dp, 0, DMVAE_EPI_BIAS_F32, WS(p, p->o_mv), 2 * p->Dp));
+    TRY(fwd_dense(p, s, act_off(p, p->o_hzc, p->Hp), 2 * p->Hp, p->Hp, p->lg, p->Kp, 0, DMVAE_EPI_BIAS_F32, WS(p, p->o_lg), p->Kp));
+    return 0;
+}
+
+static int decode_hidden(dmvae_plan* p, hipStream_t s) {
+    const void* in = WS(p, p->o_Z);
+    int64_t ld = p->Dp;
+    int kd = p->Dp;
+    for (size_t i = 0; i < p->dec.size(); ++i) {
+        const PLayer& L = p->dec[i];
+        TRY(fwd_dense(p, s, in, ld, kd, L, L.out_pad, 0, DMVAE_EPI_BIAS_RELU, WS(p, p->o_dec[i]), L.out_pad));
+        in = WS(p, p->o_dec[i]); ld = L.out_pad; kd = L.out_pad;
+    }
+    return 0;
+}
+
+extern "C" int dmvae_plan_encode(dmvae_plan* p, void* stream, int n_valid) {
+    DMVAE_REQUIRE(p && p->bound, "dmvae_plan_encode: plan not bound");
+    (void)n_valid;
+    return encode_impl(p, (hipStream_t)stream);
+}
+
+extern "C" int dmvae_plan_decode(dmvae_plan* p, void* stream, const float* Z, int64_t ldz, int n_valid) {
+    DMVAE_REQUIRE(p && p->bound && Z, "dmvae_plan_decode: plan not bound / null Z");
+    DMVAE_REQUIRE(n_valid >= 0 && n_valid <= p->cfg.max_batch, "dmvae_plan_decode: n_valid=%d exceeds max_batch", n_valid);
+    hipStream_t s = (hipStream_t)stream;
+    // Z (f32, caller) -> padded act buffer: a row gather with identity order
+    void* za = p->cfg.dtype == DMVAE_BF16 ? (void*)WS(p, p->o_Z) : nullptr;
+    float* zf = p->cfg.dtype == DMVAE_BF16 ? reinterpret_cast<float*>(WS(p, p->o_Zf)) : reinterpret_cast<float*>(WS(p, p->o_Z));
+    DMVAE_REQUIRE(ldz == p->cfg.latent_dim, "dmvae_plan_decode: Z must be contiguous [n][latent_dim]");
+    TRY(gather_launch(s, p->cfg.dtype, Z, n_valid, p->cfg.latent_dim, nullptr, 0, p->cfg.max_batch, n_valid, p->Bp, za, p->Dp, zf, p->Dp, p->Dp, nullptr));
+    TRY(decode_hidden(p, s));
+    const PLayer& L = p->out;
+    const int last = (int)p->dec.size() - 1;
+    const int kind = p->cfg.input_type == 0 ? DMVAE_EPI_BIAS_SIGMOID : DMVAE_EPI_BIAS_F32;
+    return fwd_dense(p, s, WS(p, p->o_dec[last]), p->dec[last].out_pad, p->dec[last].out_pad, L, p->Ip, 0, kind, WS(p, p->o_recon), p->Ip);
+}
+
+static int dw_split(const dmvae_plan* p, int M, int N) {
+    if (p->cfg.deterministic) return 1;
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    int split = 1;
+    while (split < 8 && tiles * split < 256 && p->Bp % (split * 2 * 64) == 0 && p->Bp / (split * 2) >= 256) split *= 2;
+    return split;
+}
+
+// dW = X^T dY into the grad arena, db = colsum(dY)
+static int grad_dense(dmvae_plan* p, hipStream_t s, const void* X, int64_t ldx, int Mdim, const void* dY, int64_t ldy, int N,
+                      int64_t w_off, int64_t ldw, int64_t b_off) {
+    dmvae_epilogue e;
+    memset(&e, 0, sizeof(e));
+    const int split = dw_split(p, Mdim, N);   // 1 in deterministic mode
+    e.kind = split > 1 ? DMVAE_EPI_ATOMIC_F32 : DMVAE_EPI_STORE_F32;
+    e.out = p->buf.grad + w_off; e.ldo = ldw;
+    TRY(gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_DW, Mdim, N, p->Bp, X, ldx, dY, ldy, &e, split));
+    return colsum_launch(s, p->cfg.dtype, dY, ldy, p->Bp, N, p->buf.grad + b_off, reinterpret_cast<float*>(WS(p, p->o_cs)), p->cs_elems);
+}
+
+static int dx_dense(dmvae_plan* p, hipStream_t s, const void* dY, int64_t ldy, int Kdim, int64_t w_off, int64_t ldw, int N,
+                    const void* Yfwd, int64_t ldyf, void* out, int64_t ldo) {
+    dmvae_epilogue e;
+    memset(&e, 0, sizeof(e));
+    e.kind = DMVAE_EPI_RELU_MASK; e.out = out; e.ldo = ldo; e.aux0 = Yfwd; e.ld0 = ldyf;
+    return gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_DX, p->Bp, N, Kdim, dY, ldy, Wp(p, w_off), ldw, &e, 1);
+}
+
+extern "C" int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_valid, const float* eps, int64_t ld_eps,
+                                           const float* gumbel, int64_t ld_gumbel, float inv_B) {
+    DMVAE_REQUIRE(p && p->bound, "dmvae_plan_forward_backward: plan not bound");
+    DMVAE_REQUIRE(n_valid > 0 && n_valid <= p->cfg.max_batch, "dmvae_plan_forward_backward: n_valid=%d out of range", n_valid);
+    hipStream_t s = (hipStream_t)stream;
+    const dmvae_config& c = p->cfg;
+    const int dt = c.dtype;
+    TRY(encode_impl(p, s));
+
+    dmvae_latent_args la;
+    memset(&la, 0, sizeof(la));
+    la.B = n_valid; la.B_pad = p->Bp; la.D = c.latent_dim; la.K = c.n_classes; la.mode = c.mode; la.act_dtype = dt;
+    la.kl_ratio = 1.f; la.temperature = c.temperature; la.inv_B = inv_B; la.seed = c.seed; la.noise_step = 0;
+    la.mean = reinterpret_cast<float*>(WS(p, p->o_mv)); la.ld_mean = 2 * p->Dp;
+    la.log_var = la.mean + p->Dp; la.ld_log_var = 2 * p->Dp;
+    la.logits = reinterpret_cast<float*>(WS(p, p->o_lg)); la.ld_logits = p->Kp;
+    la.eps = eps; la.ld_eps = ld_eps; la.gumbel = gumbel; la.ld_gumbel = ld_gumbel;
+    la.prior_means = p->buf.param + p->prior_off;
+    la.prior_log_vars = la.prior_means + (int64_t)c.n_classes * c.latent_dim;
+    la.Z_act = WS(p, p->o_Z); la.ld_Z = p->Dp;
+    la.Z_f32 = dt == DMVAE_BF16 ? reinterpret_cast<float*>(WS(p, p->o_Zf)) : nullptr; la.ld_Zf = p->Dp;
+    la.weights = reinterpret_cast<float*>(WS(p, p->o_w)); la.ld_w = p->Kp;
+    la.gmu = reinterpret_cast<float*>(WS(p, p->o_gmu)); la.glv = reinterpret_cast<float*>(WS(p, p->o_glv));
+    la.clv = reinterpret_cast<float*>(WS(p, p->o_clv)); la.ld_g = p->Dp;
+    la.dlogits_act = WS(p, p->o_dlg); la.ld_dl = p->Kp;
+    la.dprior_partials = reinterpret_cast<float*>(WS(p, p->o_dprior));
+    la.loss_partials = reinterpret_cast<float*>(WS(p, p->o_lpart));
+    la.state = p->buf.state;
+    TRY(latent_launch(s, &la));
+
+    TRY(decode_hidden(p, s));
+    const int nd = (int)p->dec.size(), ne = (int)p->enc.size();
+    {   // output layer + reconstruction loss + dLoss/dlogits in one epilogue
+        const PLayer& L = p->out;
+        dmvae_epilogue e;
+        memset(&e, 0, sizeof(e));
+        e.kind = DMVAE_EPI_BIAS_RECON; e.m_valid = n_valid; e.n_valid = c.input_dim; e.recon_kind = c.input_type; e.scale = inv_B;
+        e.out = WS(p, p->o_dl); e.ldo = p->Ip; e.bias = p->buf.param + L.b_off;
+        e.aux0 = WS(p, p->o_xf); e.ld0 = p->Ip; e.partials = reinterpret_cast<float*>(WS(p, p->o_rpart));
+        TRY(gemm_checked(s, dt, DMVAE_GEMM_FWD, p->Bp, p->Ip, p->dec[nd - 1].out_pad, WS(p, p->o_dec[nd - 1]), p->dec[nd - 1].out_pad,
+                         Wp(p, L.w_off), L.ldw, &e, 1));
+    }
+    // ---- backward: decoder
+    TRY(grad_dense(p, s, WS(p, p->o_dec[nd - 1]), p->dec[nd - 1].out_pad, p->dec[nd - 1].out_pad, WS(p, p->o_dl), p->Ip, p->Ip,
+                   p->out.w_off, p->out.ldw, p->out.b_off));
+    TRY(dx_dense(p, s, WS(p, p->o_dl), p->Ip, p->Ip, p->out.w_off, p->out.ldw, p->dec[nd - 1].out_pad,
+                 WS(p, p->o_dec[nd - 1]), p->dec[nd - 1].out_pad, WS(p, p->o_ddec[nd - 1]), p->dec[nd - 1].out_pad));
+    for (int i = nd - 1; i >= 0; --i) {
+        const PLayer& L = p->dec[i];
+        const void* xin = i > 0 ? WS(p, p->o_dec[i - 1]) : WS(p, p->o_Z);
+        const int64_t ldx = i > 0 ? p->dec[i - 1].out_pad : p->Dp;
+        TRY(grad_dense(p, s, xin, ldx, L.in_pad, WS(p, p->o_ddec[i]), L.out_pad, L.out_pad, L.w_off, L.ldw, L.b_off));
+        if (i > 0) {
+            TRY(dx_dense(p, s, WS(p, p->o_ddec[i]), L.out_pad, L.out_pad, L.w_off, L.ldw, L.in_pad,
+                         WS(p, p->o_dec[i - 1]), p->dec[i - 1].out_pad, WS(p, p->o_ddec[i - 1]), p->dec[i - 1].out_pad));
+        } else {   // dZ -> [dmean | dlog_var] through the reparameterisation + KL gradients
+            dmvae_epilogue e;
+            memset(&e, 0, sizeof(e));
+            e.kind = DMVAE_EPI_LATENT; e.out = WS(p, p->o_dmv); e.ldo = 2 * p->Dp; e.d_off = p->Dp;
+            e.aux0 = la.gmu; e.ld0 = p->Dp; e.aux1 = la.glv; e.ld1 = p->Dp; e.aux2 = la.clv; e.ld2 = p->Dp;
+            TRY(gemm_checked(s, dt, DMVAE_GEMM_DX, p->Bp, p->Dp, L.out_pad, WS(p, p->o_ddec[0]), L.out_pad, Wp(p, L.w_off), L.ldw, &e, 1));
+        }
+    }
+    // ---- backward: heads
+    TRY(grad_dense(p, s, WS(p, p->o_hzc), 2 * p->Hp, p->Hp, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->mv.b_off));
+    TRY(grad_dense(p, s, act_off(p, p->o_hzc, p->Hp), 2 * p->Hp, p->Hp, WS(p, p->o_dlg), p->Kp, p->Kp, p->lg.w_off, p->lg.ldw, p->lg.b_off));
+    TRY(dx_dense(p, s, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->Hp, WS(p, p->o_hzc), 2 * p->Hp, WS(p, p->o_dhzc), 2 * p->Hp));
+    TRY(dx_dense(p, s, WS(p, p->o_dlg), p->Kp, p->Kp, p->lg.w_off, p->lg.ldw, p->Hp, act_off(p, p->o_hzc, p->Hp), 2 * p->Hp,
+                 const_cast<void*>(act_off(p, p->o_dhzc, p->Hp)), 2 * p->Hp));
+    // ---- backward: trunk
+    TRY(grad_dense(p, s, WS(p, p->o_enc[ne - 1]), p->Tp, p->Tp, WS(p, p->o_dhzc), 2 * p->Hp, 2 * p->Hp, p->zc.w_off, p->zc.ldw, p->zc.b_off));
+    TRY(dx_dense(p, s, WS(p, p->o_dhzc), 2 * p->Hp, 2 * p->Hp, p->zc.w_off, p->zc.ldw, p->Tp, WS(p, p->o_enc[ne - 1]), p->Tp,
+                 WS(p, p->o_denc[ne - 1]), p->Tp));
+    for (int i = ne - 1; i >= 0; --i) {
+        const PLayer& L = p->enc[i];
+        const void* xin = i > 0 ? WS(p, p->o_enc[i - 1]) : WS(p, p->o_x);
+        const int64_t ldx = i > 0 ? p->enc[i - 1].out_pad : p->Ip;
+        TRY(grad_dense(p, s, xin, ldx, L.in_pad, WS(p, p->o_denc[i]), L.out_pad, L.out_pad, L.w_off, L.ldw, L.b_off));
+        if (i > 0)
+            TRY(dx_dense(p, s, WS(p, p->o_denc[i]), L.out_pad, L.out_pad, L.w_off, L.ldw, L.in_pad,
+                         WS(p, p->o_enc[i - 1]), p->enc[i - 1].out_pad, WS(p, p->o_denc[i - 1]), p->enc[i - 1].out_pad));
+    }
+    // ---- prior-table gradients: fixed-order sum of the per-block partials
+    const int KD2 = 2 * c.n_classes * c.latent_dim;
+    TRY(colsum_launch(s, DMVAE_F32, WS(p, p->o_dprior), KD2, p->n_lblk, KD2, p->buf.grad + p->prior_off,
+                      reinterpret_cast<float*>(WS(p, p->o_cs)), p->cs_elems));
+    // ---- loss scalars
+    return loss_finalize_launch(s, reinterpret_cast<float*>(WS(p, p->o_rpart)), p->n_rpart, reinterpret_cast<float*>(WS(p, p->o_lpart)),
+                                p->n_lblk, inv_B, p->buf.state);
+}
+
+extern "C" int dmvae_plan_update(dmvae_plan* p, void* stream, float grad_scale) {
+    DMVAE_REQUIRE(p && p->bound, "dmvae_plan_update: plan not bound");
+    hipStream_t s = (hipStream_t)stream;
+    AdamArgs a;
+    a.n = p->param_elems; a.p = p->buf.param; a.g = p->buf.grad; a.m = p->buf.m; a.v = p->buf.v;
+    a.pb = reinterpret_cast<bf16_t*>(p->cfg.dtype == DMVAE_BF16 ? p->buf.param_bf16 : nullptr);
+    a.lr = 0.f; a.b1 = p->cfg.beta1; a.b2 = p->cfg.beta2; a.eps = p->cfg.adam_eps; a.gscale = grad_scale;
+    a.zero_grad = p->cfg.deterministic ? 0 : 1;
+    a.t_host = 0; a.st = reinterpret_cast<const dmvae_state*>(p->buf.state);
+    TRY(adam_launch(s, a));
+    return adam_finish_launch(s, p->buf.state);
+}
+
+extern "C" int dmvae_plan_view(const dmvae_plan* p, const char* name, void** ptr, int64_t* ld, int32_t* dtype) {
+    DMVAE_REQUIRE(p && p->bound && name && ptr && ld && dtype, "dmvae_plan_view: null argument / plan not bound");
+    const std::string n(name);
+    char* base = reinterpret_cast<char*>(p->buf.work);
+    *dtype = DMVAE_F32;
+    if (n == "mean") { *ptr = base + p->o_mv; *ld = 2 * p->Dp; }
+    else if (n == "log_var") { *ptr = base + p->o_mv + (int64_t)p->Dp * 4; *ld = 2 * p->Dp; }
+    else if (n == "logits") { *ptr = base + p->o_lg; *ld = p->Kp; }
+    else if (n == "weights") { *ptr = base + p->o_w; *ld = p->Kp; }
+    else if (n == "recon") { *ptr = base + p->o_recon; *ld = p->Ip; }
+    else if (n == "x") { *ptr = base + p->o_xf; *ld = p->Ip; }
+    else if (n == "Z") { *ptr = base + (p->cfg.dtype == DMVAE_BF16 ? p->o_Zf : p->o_Z); *ld = p->Dp; }
+    else if (n == "dxlogits") { *ptr = base + p->o_dl; *ld = p->Ip; *dtype = p->cfg.dtype; }
+    else { set_error("dmvae_plan_view: unknown view '%s'", name); return DMVAE_EINVAL; }
+    return 0;
+}
+
+// ====================================================================== thin C wrappers
+extern "C" int dmvae_gemm(void* stream, int dtype, int layout, int M, int N, int K, const void* A, int64_t lda,
+                          const void* B, int64_t ldb, const dmvae_epilogue* epi, int split_k) {
+    return gemm_checked((hipStream_t)stream, dtype, layout, M, N, K, A, lda, B, ldb, epi, split_k);
+}
+extern "C" int dmvae_gemm_partials(int dtype, int M, int N) { return gemm_partials(dtype, M, N); }
+
+extern "C" int dmvae_latent_nblocks(int B_pad, int D, int K) { return latent_nblocks(B_pad, D, K); }
+extern "C" int dmvae_latent_fwd(void* stream, const dmvae_latent_args* a) {
+    DMVAE_REQUIRE(a && a->mean && a->log_var && a->logits && a->prior_means && a->prior_log_vars && a->Z_act && a->gmu && a->glv &&
+                  a->clv && a->dlogits_act && a->dprior_partials && a->loss_partials, "dmvae_latent_fwd: null pointer");
+    DMVAE_REQUIRE(a->mode == 0 || a->mode == 1, "dmvae_latent_fwd: bad mode %d", a->mode);
+    DMVAE_REQUIRE(a->ld_Z >= a->D && a->ld_dl >= a->K && a->ld_g >= a->D, "dmvae_latent_fwd: leading dimension too small");
+    return latent_launch((hipStream_t)stream, a);
+}
+extern "C" int dmvae_recon_nblocks(int B_pad, int I_pad) { return recon_nblocks(B_pad, I_pad); }
+extern "C" int dmvae_recon_fwd_bwd(void* stream, int act_dtype, int recon_kind, int B, int B_pad, int I, int I_pad, const float* logits,
+                                   int64_t ldl, const float* x, int64_t ldx, float inv_B, void* dl, int64_t ldd, float* partials) {
+    DMVAE_REQUIRE(logits && x && dl && partials, "dmvae_recon_fwd_bwd: null pointer");
+    DMVAE_REQUIRE(I_pad % 4 == 0 && ldl % 4 == 0 && ldx % 4 == 0 && ldd % 4 == 0 && B <= B_pad && I <= I_pad, "dmvae_recon_fwd_bwd: dims must be multiples of 4");
+    return recon_launch((hipStream_t)stream, act_dtype, recon_kind, B, B_pad, I, I_pad, logits, ldl, x, ldx, inv_B, dl, ldd, partials);
+}
+extern "C" int dmvae_colsum(void* stream, int in_dtype, const void* in, int64_t ld, int M, int N, float* out) {
+    DMVAE_REQUIRE(in && out && M > 0 && N > 0, "dmvae_colsum: bad argument");
+    if (M > 512) TRY(colsum_prepare(N));
+    return colsum_launch((hipStream_t)stream, in_dtype, in, ld, M, N, out, nullptr, 0);
+}
+extern "C" int dmvae_loss_finalize(void* stream, const float* rp, int nr, const float* lp, int nl, float inv_B, void* state) {
+    DMVAE_REQUIRE(rp && lp && state, "dmvae_loss_finalize: null pointer");
+    return loss_finalize_launch((hipStream_t)stream, rp, nr, lp, nl, inv_B, state);
+}
+extern "C" int dmvae_adam_tf(void* stream, int64_t n, float* param, float* grad, float* m, float* v, void* param_bf16, float lr,
+                             float beta1, float beta2, float epsilon, float grad_scale, int zero_grad, uint64_t t_host, const void* state) {
+    DMVAE_REQUIRE(param && grad && m && v && n > 0 && n % 4 == 0, "dmvae_adam_tf: n must be a positive multiple of 4");
+    DMVAE_REQUIRE(state || t_host >= 1, "dmvae_adam_tf: t starts at 1");
+    AdamArgs a;
+    a.n = n; a.p = param; a.g = grad; a.m = m; a.v = v; a.pb = reinterpret_cast<bf16_t*>(param_bf16);
+    a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = epsilon; a.gscale = grad_scale; a.zero_grad = zero_grad;
+    a.t_host = t_host; a.st = reinterpret_cast<const dmvae_state*>(state);
+    return adam_launch((hipStream_t)stream, a);
+}
+extern "C" int dmvae_adam_finish(void* stream, void* state) {
+    DMVAE_REQUIRE(state, "dmvae_adam_finish: null state");
+    return adam_finish_launch((hipStream_t)stream, state);
+}
+extern "C" int dmvae_gather_rows(void* stream, int act_dtype, const float* data, int64_t n_rows, int dim, const int32_t* perm,
+                                 int64_t first, int batch, int n_valid, int B_pad, void* out_act, int64_t ld_act, float* out_f32,
+                                 int64_t ld_f32, const void* state) {
+    DMVAE_REQUIRE(data && (out_act || out_f32), "dmvae_gather_rows: null pointer");
+    const int64_t ld = out_act ? ld_act : ld_f32;
+    DMVAE_REQUIRE(ld % 4 == 0 && ld >= dim && (!out_act || !out_f32 || ld_act == ld_f32), "dmvae_gather_rows: ld must be a multiple of 4, >= dim, equal for both outputs");
+    return gather_launch((hipStream_t)stream, act_dtype, data, n_rows, dim, perm, first, batch, n_valid, B_pad, out_act, ld_act, out_f32, ld_f32, (int)ld, state);
+}
+extern "C" int dmvae_philox_normal(void* stream, float* out, int64_t n, uint64_t seed, uint64_t step, uint32_t sid) {
+    DMVAE_REQUIRE(out && n > 0, "dmvae_philox_normal: bad argument");
+    return philox_launch((hipStream_t)stream, out, n, seed, step, sid, 0);
+}
+extern "C" int dmvae_philox_gumbel(void* stream, float* out, int64_t n, uint64_t seed, uint64_t step, uint32_t sid) {
+    DMVAE_REQUIRE(out && n > 0, "dmvae_philox_gumbel: bad argument");
+    return philox_launch((hipStream_t)stream, out, n, seed, step, sid, 1);
+}
+extern "C" int dmvae_cast_f32_to_bf16(void* stream, const float* in, void* out, int64_t n) {
+    DMVAE_REQUIRE(in && out && n > 0, "dmvae_cast: bad argument");
+    return cast_launch((hipStream_t)stream, in, out, n, 1);
+}
+extern "C" int dmvae_cast_bf16_to_f32(void* stream, const void* in, float* out, int64_t n) {
+    DMVAE_REQUIRE(in && out && n > 0, "dmvae_cast: bad argument");
+    return cast_launch((hipStream_t)stream, in, out, n, 0);
+}
+
+extern "C" int dmvae_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return 0;
+}
+extern "C" int dmvae_prof_collect(dmvae_prof_row* rows, int max_rows) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    std::map<std::string, dmvae_prof_row> agg;
+    std::vector<std::string> order;
+    for (auto& r : g_prof) {
+        (void)hipEventSynchronize(r.e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        auto it = agg.find(r.name);
+        if (it == agg.end()) {
+            dmvae_prof_row row;
+            memset(&row, 0, sizeof(row));
+            snprintf(row.name, sizeof(row.name), "%s", r.name);
+            it = agg.emplace(r.name, row).first;
+            order.push_back(r.name);
+        }
+        it->second.launches += 1;
+        it->second.total_ms += ms;
+        it->second.flops += r.flops;
+        it->second.bytes += r.bytes;
+        g_event_pool.push_back(r.e0);
+        g_event_pool.push_back(r.e1);
+    }
+    g_prof.clear();
+    int n = 0;
+    for (auto& k : order) {
+        if (n >= max_rows) break;
+        rows[n++] = agg[k];
+    }
+    return n;
+}
+
+extern "C" int dmvae_abi_version(void) { return DMVAE_ABI_VERSION; }
+extern "C" const char* dmvae_last_error(void) { return g_err; }

@@ -1,0 +1,108 @@
+// Shared device/host helpers for the gfx950 DMVAE kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/dmvae_hip.h"
+
+typedef unsigned short bf16_t;   // raw bf16 bits in memory
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WAVE 64
+
+// round-to-nearest-even f32 -> bf16 through the hardware convert (keeps NaN a NaN)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) {
+    return __uint_as_float(((unsigned int)h) << 16);
+}
+__device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
+    return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Fixed-order block sum for 256-thread blocks; result valid in thread 0.
+__device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats LDS */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+}
+
+// ---- Philox4x32-10 (counter-based; same stream on every replay of a graph) ----
+__host__ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+// uniform in (0,1]: never 0 so log() is finite
+__host__ __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f); }
+
+// element `idx` of noise stream (seed, step, stream_id): one Philox block gives 4 values;
+// value j = idx & 3 of block idx >> 2.
+__device__ __forceinline__ void philox_block(uint64_t seed, uint64_t step, uint32_t stream_id, uint64_t blk, uint32_t out[4]) {
+    out[0] = (uint32_t)blk; out[1] = (uint32_t)(blk >> 32) ^ (stream_id << 24);
+    out[2] = (uint32_t)step; out[3] = (uint32_t)(step >> 32);
+    philox4x32_10(out, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+__device__ __forceinline__ float philox_normal_at(uint64_t seed, uint64_t step, uint32_t stream_id, uint64_t idx) {
+    uint32_t r[4];
+    philox_block(seed, step, stream_id, idx >> 1, r);
+    // Box-Muller: block idx>>1 yields two normals from (r0,r1)
+    const float rad = sqrtf(-2.0f * __logf(u01(r[0])));
+    const float ang = 6.283185307179586f * u01(r[1]);
+    return (idx & 1) ? rad * __sinf(ang) : rad * __cosf(ang);
+}
+__device__ __forceinline__ float philox_gumbel_at(uint64_t seed, uint64_t step, uint32_t stream_id, uint64_t idx) {
+    uint32_t r[4];
+    philox_block(seed, step, stream_id, idx >> 2, r);
+    const float U = u01(r[idx & 3]);
+    // includes/utils.py:17-19: -log(eps - log(U + eps)), eps = 1e-20 (vanishes in f32 for U in (0,1])
+    return -__logf(1e-20f - __logf(U));
+}
+
+// ---- host side: errors + launch profiling ----
+namespace dmvae {
+void set_error(const char* fmt, ...);
+struct ProfScope {   // brackets a launch with a hipEvent pair when profiling is on
+    ProfScope(hipStream_t s, const char* name, double flops, double bytes);
+    ~ProfScope();
+    hipStream_t s; int slot;
+};
+int check_launch(const char* what);
+}  // namespace dmvae
+
+#define DMVAE_REQUIRE(cond, ...)                      \
+    do {                                              \
+        if (!(cond)) {                                \
+            dmvae::set_error(__VA_ARGS__);            \
+            return DMVAE_EINVAL;                      \
+        }                                             \
+    } while (0)

@@ -1,0 +1,287 @@
+// HBM-bound kernels of the DMVAE step: TF-style Adam, column sums (bias
+// gradients / reduction of per-block partials), stand-alone reconstruction
+// loss, batch assembly, Philox noise, casts, loss finalize.
+// All loads/stores are 16 B per lane where the layout allows.
+#include "kernels.h"
+
+namespace dmvae {
+
+// ---------------------------------------------------------------- Adam (TF 1.x)
+// tf.train.AdamOptimizer, base_models.py:95-110 -- epsilon OUTSIDE the bias
+// correction: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t*m/(sqrt(v)+eps).
+// 4 elements per lane: 16-B loads of p, g, m, v; 16-B stores of p, m, v (+8 B bf16).
+__global__ __launch_bounds__(256) void adam_tf_kernel(AdamArgs a) {
+    const uint64_t t = a.st ? a.st->adam_t + 1 : a.t_host;
+    const float lr = a.st ? a.st->lr : a.lr;
+    // powf on the exact integer t; double keeps 1-b2^t accurate for small t
+    const double b1t = pow((double)a.b1, (double)t), b2t = pow((double)a.b2, (double)t);
+    const float lr_t = (float)((double)lr * sqrt(1.0 - b2t) / (1.0 - b1t));
+    const int64_t n4 = a.n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 p = reinterpret_cast<float4*>(a.p)[i];
+        float4 g = reinterpret_cast<float4*>(a.g)[i];
+        float4 m = reinterpret_cast<float4*>(a.m)[i];
+        float4 v = reinterpret_cast<float4*>(a.v)[i];
+        float* pp = &p.x; float* gp = &g.x; float* mp = &m.x; float* vp = &v.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gj = gp[j] * a.gscale;
+            mp[j] = a.b1 * mp[j] + (1.f - a.b1) * gj;
+            vp[j] = a.b2 * vp[j] + (1.f - a.b2) * gj * gj;
+            pp[j] = pp[j] - lr_t * mp[j] / (sqrtf(vp[j]) + a.eps);
+        }
+        reinterpret_cast<float4*>(a.p)[i] = p;
+        reinterpret_cast<float4*>(a.m)[i] = m;
+        reinterpret_cast<float4*>(a.v)[i] = v;
+        if (a.pb) {
+            uint2 q;
+            q.x = pack2bf(p.x, p.y);
+            q.y = pack2bf(p.z, p.w);
+            reinterpret_cast<uint2*>(a.pb)[i] = q;
+        }
+        if (a.zero_grad) reinterpret_cast<float4*>(a.g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__global__ void adam_finish_kernel(dmvae_state* st) { st->adam_t += 1; }
+
+int adam_launch(hipStream_t s, const AdamArgs& a) {
+    const int64_t n4 = a.n >> 2;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    ProfScope ps(s, "adam_tf", 12.0 * a.n, (28.0 + (a.pb ? 2.0 : 0.0) + (a.zero_grad ? 4.0 : 0.0)) * a.n);
+    hipLaunchKernelGGL(adam_tf_kernel, dim3(blocks), dim3(256), 0, s, a);
+    return check_launch("adam_tf");
+}
+int adam_finish_launch(hipStream_t s, void* st) {
+    hipLaunchKernelGGL(adam_finish_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<dmvae_state*>(st));
+    return check_launch("adam_finish");
+}
+
+// ---------------------------------------------------------------- column sums
+// out[n] = sum_m in[m][n].  Two passes in a fixed order (no atomics):
+//   pass 1: grid (N/256-col strips) x (row slabs of 256 rows): each thread sums
+//           its column over the slab (coalesced across the 256 lanes) -> ws[slab][n]
+//   pass 2: each thread sums its column over the slabs.
+// When M <= 256 a single pass writes out directly.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* in, int64_t ld, int M, int N, int rows_per_slab, float* out, int64_t ldo) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = blockIdx.y * rows_per_slab;
+    const int r1 = min(M, r0 + rows_per_slab);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+        float v0, v1, v2, v3;
+        if constexpr (sizeof(T) == 2) {
+            v0 = bf2f(in[(int64_t)(r + 0) * ld + n]); v1 = bf2f(in[(int64_t)(r + 1) * ld + n]);
+            v2 = bf2f(in[(int64_t)(r + 2) * ld + n]); v3 = bf2f(in[(int64_t)(r + 3) * ld + n]);
+        } else {
+            v0 = in[(int64_t)(r + 0) * ld + n]; v1 = in[(int64_t)(r + 1) * ld + n];
+            v2 = in[(int64_t)(r + 2) * ld + n]; v3 = in[(int64_t)(r + 3) * ld + n];
+        }
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; r < r1; ++r) {
+        if constexpr (sizeof(T) == 2) s0 += bf2f(in[(int64_t)r * ld + n]);
+        else s0 += in[(int64_t)r * ld + n];
+    }
+    out[(int64_t)blockIdx.y * ldo + n] = (s0 + s1) + (s2 + s3);
+}
+
+static float* g_colsum_ws = nullptr;     // [COLSUM_MAX_SLABS][COLSUM_MAX_N] scratch, allocated once (outside capture)
+static int64_t g_colsum_ws_elems = 0;
+constexpr int COLSUM_SLABS = 64;
+
+int colsum_prepare(int64_t max_n) {      // called from plan bind / first use, never under capture
+    const int64_t need = (int64_t)COLSUM_SLABS * max_n;
+    if (need <= g_colsum_ws_elems) return 0;
+    if (g_colsum_ws) (void)hipFree(g_colsum_ws);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&g_colsum_ws), need * sizeof(float));
+    if (e != hipSuccess) { set_error("colsum scratch hipMalloc failed: %s", hipGetErrorString(e)); g_colsum_ws_elems = 0; return (int)e; }
+    g_colsum_ws_elems = need;
+    return 0;
+}
+
+int colsum_launch(hipStream_t s, int in_dtype, const void* in, int64_t ld, int M, int N, float* out, float* ws, int64_t ws_elems) {
+    const int strips = (N + 255) / 256;
+    const double bytes = (double)M * N * (in_dtype == DMVAE_BF16 ? 2 : 4);
+    ProfScope ps(s, "colsum", (double)M * N, bytes);
+    if (M <= 512) {
+        if (in_dtype == DMVAE_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(strips, 1), dim3(256), 0, s, (const bf16_t*)in, ld, M, N, M, out, (int64_t)0);
+        else hipLaunchKernelGGL(colsum_kernel<float>, dim3(strips, 1), dim3(256), 0, s, (const float*)in, ld, M, N, M, out, (int64_t)0);
+        return check_launch("colsum");
+    }
+    if (!ws) { ws = g_colsum_ws; ws_elems = g_colsum_ws_elems; }
+    int slabs = COLSUM_SLABS;
+    int rps = (M + slabs - 1) / slabs;
+    slabs = (M + rps - 1) / rps;
+    if ((int64_t)slabs * N > ws_elems) {
+        set_error("dmvae_colsum: scratch too small (%lld < %lld); call through a bound plan or with N <= prepared", (long long)ws_elems, (long long)slabs * N);
+        return DMVAE_ESTATE;
+    }
+    if (in_dtype == DMVAE_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(strips, slabs), dim3(256), 0, s, (const bf16_t*)in, ld, M, N, rps, ws, (int64_t)N);
+    else hipLaunchKernelGGL(colsum_kernel<float>, dim3(strips, slabs), dim3(256), 0, s, (const float*)in, ld, M, N, rps, ws, (int64_t)N);
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3(strips, 1), dim3(256), 0, s, (const float*)ws, (int64_t)N, slabs, N, slabs, out, (int64_t)0);
+    return check_launch("colsum");
+}
+
+// ---------------------------------------------------------------- stand-alone recon loss
+// base_models.py:72-85.  Each thread handles 4 consecutive columns (16-B loads).
+template <typename ACT>
+__global__ __launch_bounds__(256) void recon_kernel(int recon_kind, int B, int B_pad, int I, int I_pad,
+                                                    const float* logits, int64_t ldl, const float* x, int64_t ldx,
+                                                    float inv_B, void* dl, int64_t ldd, float* partials) {
+    __shared__ float red[4];
+    const int quads = I_pad >> 2;
+    const int64_t total = (int64_t)B_pad * quads;
+    float loss = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / quads), n = (int)(i % quads) * 4;
+        float l[4], xv[4], d[4];
+        loadf4(logits, (int64_t)m * ldl + n, l);
+        loadf4(x, (int64_t)m * ldx + n, xv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = m < B && (n + j) < I;
+            if (recon_kind == 0) {
+                loss += ok ? xent_logits(l[j], xv[j]) : 0.f;
+                d[j] = ok ? (sigmoidf_(l[j]) - xv[j]) * inv_B : 0.f;
+            } else {
+                const float r = l[j] - xv[j];
+                loss += ok ? 0.5f * r * r : 0.f;
+                d[j] = ok ? r * inv_B : 0.f;
+            }
+        }
+        ActIO<ACT>::store4(dl, (int64_t)m * ldd + n, d);
+    }
+    const float t = block_sum_256(loss, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+int recon_nblocks(int B_pad, int I_pad) {
+    int64_t q = (int64_t)B_pad * (I_pad / 4);
+    int64_t b = (q + 255) / 256;
+    return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+}
+int recon_launch(hipStream_t s, int act_dtype, int recon_kind, int B, int B_pad, int I, int I_pad,
+                 const float* logits, int64_t ldl, const float* x, int64_t ldx, float inv_B,
+                 void* dl, int64_t ldd, float* partials) {
+    const int nb = recon_nblocks(B_pad, I_pad);
+    ProfScope ps(s, "recon_fwd_bwd", 10.0 * B * I, (double)B * I * (8 + (act_dtype == DMVAE_BF16 ? 2 : 4)));
+    if (act_dtype == DMVAE_BF16) hipLaunchKernelGGL(recon_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, recon_kind, B, B_pad, I, I_pad, logits, ldl, x, ldx, inv_B, dl, ldd, partials);
+    else hipLaunchKernelGGL(recon_kernel<float>, dim3(nb), dim3(256), 0, s, recon_kind, B, B_pad, I, I_pad, logits, ldl, x, ldx, inv_B, dl, ldd, partials);
+    return check_launch("recon_fwd_bwd");
+}
+
+// ---------------------------------------------------------------- loss finalize
+// loss = recon + kl_ratio*(KL_C + KL_Z); base_models.py:87-93 and :130.
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* rp, int nr, const float* lp, int nl, float inv_B, dmvae_state* st) {
+    __shared__ float red[4];
+    float a = 0.f, z = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < nr; i += 256) a += rp[i];
+    for (int i = threadIdx.x; i < nl; i += 256) { z += lp[2 * i]; c += lp[2 * i + 1]; }
+    const float recon = block_sum_256(a, red) * inv_B;
+    const float klz = block_sum_256(z, red) * inv_B;
+    const float klc = block_sum_256(c, red) * inv_B;
+    if (threadIdx.x == 0) {
+        const float loss = recon + st->kl_ratio * (klc + klz);
+        st->last_loss = loss; st->last_recon = recon; st->last_klz = klz; st->last_klc = klc;
+        st->epoch_loss += loss * st->epoch_weight;
+        st->epoch_recon += recon * st->epoch_weight;
+        st->epoch_klz += klz * st->epoch_weight;
+        st->epoch_klc += klc * st->epoch_weight;
+        st->noise_step += 1;
+        st->batch_cursor = (st->batches_per_epoch > 0) ? (st->batch_cursor + 1) % st->batches_per_epoch : 0;
+    }
+}
+int loss_finalize_launch(hipStream_t s, const float* rp, int nr, const float* lp, int nl, float inv_B, void* st) {
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, rp, nr, lp, nl, inv_B, reinterpret_cast<dmvae_state*>(st));
+    return check_launch("loss_finalize");
+}
+
+// ---------------------------------------------------------------- batch assembly
+// Dataset.get_batches (includes/utils.py:449-463): row r <- data[perm[first+r]].
+// One 64-lane group per row; 16-B loads of the f32 source row; writes the act copy
+// (bf16: 8-B stores) and the f32 copy; pad rows / pad columns are zero.
+template <typename ACT>
+__global__ __launch_bounds__(256) void gather_kernel(const float* data, int64_t n_rows, int dim, const int32_t* perm,
+                                                     int64_t first, int batch, int n_valid, int B_pad,
+                                                     ACT* out_act, int64_t ld_act, float* out_f32, int64_t ld_f32,
+                                                     int cols_pad, const dmvae_state* st) {
+    if (st) first = (int64_t)st->batch_cursor * batch;
+    const int quads = cols_pad >> 2;
+    const int64_t total = (int64_t)B_pad * quads;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / quads), c = (int)(i % quads) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < n_valid) {
+            int64_t src = first + r;
+            if (perm) src = perm[src];
+            if (src < n_rows) {
+                const float* p = data + src * dim + c;
+                if (c + 3 < dim && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                    const float4 q = *reinterpret_cast<const float4*>(p);
+                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (c + j < dim) ? p[j] : 0.f;
+                }
+            }
+        }
+        if (out_act) ActIO<ACT>::store4(out_act, (int64_t)r * ld_act + c, v);
+        if (out_f32) ActIO<float>::store4(out_f32, (int64_t)r * ld_f32 + c, v);
+    }
+}
+int gather_launch(hipStream_t s, int act_dtype, const float* data, int64_t n_rows, int dim, const int32_t* perm,
+                  int64_t first, int batch, int n_valid, int B_pad, void* out_act, int64_t ld_act,
+                  float* out_f32, int64_t ld_f32, int cols_pad, const void* st) {
+    int64_t q = (int64_t)B_pad * (cols_pad / 4);
+    int nb = (int)((q + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    ProfScope ps(s, "gather_rows", 0.0, (double)n_valid * dim * (4 + 4 + (act_dtype == DMVAE_BF16 ? 2 : 4)));
+    if (act_dtype == DMVAE_BF16)
+        hipLaunchKernelGGL(gather_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, data, n_rows, dim, perm, first, batch, n_valid, B_pad,
+                           (bf16_t*)out_act, ld_act, out_f32, ld_f32, cols_pad, (const dmvae_state*)st);
+    else
+        hipLaunchKernelGGL(gather_kernel<float>, dim3(nb), dim3(256), 0, s, data, n_rows, dim, perm, first, batch, n_valid, B_pad,
+                           (float*)out_act, ld_act, out_f32, ld_f32, cols_pad, (const dmvae_state*)st);
+    return check_launch("gather_rows");
+}
+
+// ---------------------------------------------------------------- noise + casts
+__global__ __launch_bounds__(256) void philox_kernel(float* out, int64_t n, uint64_t seed, uint64_t step, uint32_t sid, int gumbel) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = gumbel ? philox_gumbel_at(seed, step, sid, (uint64_t)i) : philox_normal_at(seed, step, sid, (uint64_t)i);
+}
+int philox_launch(hipStream_t s, float* out, int64_t n, uint64_t seed, uint64_t step, uint32_t sid, int gumbel) {
+    int nb = (int)((n + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(philox_kernel, dim3(nb), dim3(256), 0, s, out, n, seed, step, sid, gumbel);
+    return check_launch("philox");
+}
+
+__global__ __launch_bounds__(256) void cast_f2b_kernel(const float* in, bf16_t* out, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(in)[i];
+        uint2 q; q.x = pack2bf(v.x, v.y); q.y = pack2bf(v.z, v.w);
+        reinterpret_cast<uint2*>(out)[i] = q;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = f2bf(in[i]);
+}
+__global__ __launch_bounds__(256) void cast_b2f_kernel(const bf16_t* in, float* out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = bf2f(in[i]);
+}
+int cast_launch(hipStream_t s, const void* in, void* out, int64_t n, int to_bf16) {
+    int nb = (int)((n / 4 + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    if (to_bf16) hipLaunchKernelGGL(cast_f2b_kernel, dim3(nb), dim3(256), 0, s, (const float*)in, (bf16_t*)out, n);
+    else hipLaunchKernelGGL(cast_b2f_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)in, (float*)out, n);
+    return check_launch("cast");
+}
+
+}  // namespace dmvae

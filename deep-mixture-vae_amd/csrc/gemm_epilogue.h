@@ -1,0 +1,126 @@
+// Fused GEMM epilogues shared by the bf16 and f32 MFMA kernels.
+//
+// Both kernels issue their MFMAs with the operands swapped (first = B
+// fragment, second = A fragment), so with the gfx950 C/D map
+//   col = lane & 15, row = 4*(lane >> 4) + reg
+// every lane ends up holding FOUR CONSECUTIVE n of ONE row m of C: the
+// epilogue works on (m, n..n+3) quads -> 8-byte bf16 / 16-byte f32 stores and
+// vector loads of bias / mask / target.
+#pragma once
+#include "common.h"
+
+namespace dmvae {
+
+struct GemmArgs {
+    const void* A; int64_t lda;
+    const void* B; int64_t ldb;
+    int M, N, K, k_split;   // k_split: contraction depth handled by one blockIdx.y
+    dmvae_epilogue epi;
+};
+
+template <typename T> struct ActIO;
+template <> struct ActIO<bf16_t> {
+    static __device__ __forceinline__ void store4(void* base, int64_t off, const float v[4]) {
+        uint2 p;
+        p.x = pack2bf(v[0], v[1]);
+        p.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(base) + off) = p;
+    }
+    static __device__ __forceinline__ void load4(const void* base, int64_t off, float v[4]) {
+        const uint2 p = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(base) + off);
+        v[0] = __uint_as_float(p.x << 16);
+        v[1] = __uint_as_float(p.x & 0xffff0000u);
+        v[2] = __uint_as_float(p.y << 16);
+        v[3] = __uint_as_float(p.y & 0xffff0000u);
+    }
+};
+template <> struct ActIO<float> {
+    static __device__ __forceinline__ void store4(void* base, int64_t off, const float v[4]) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + off) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    static __device__ __forceinline__ void load4(const void* base, int64_t off, float v[4]) {
+        const float4 p = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+        v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w;
+    }
+};
+
+__device__ __forceinline__ void loadf4(const void* base, int64_t off, float v[4]) {
+    ActIO<float>::load4(base, off, v);
+}
+
+// sigmoid cross entropy with logits, TF form: max(l,0) - l*x + log(1+exp(-|l|))
+__device__ __forceinline__ float xent_logits(float l, float x) {
+    return fmaxf(l, 0.f) - l * x + log1pf(__expf(-fabsf(l)));
+}
+__device__ __forceinline__ float sigmoidf_(float l) { return 1.0f / (1.0f + __expf(-l)); }
+
+// One quad of the epilogue.  `loss` accumulates the RECON contribution.
+template <int EPI, typename ACT>
+__device__ __forceinline__ void epilogue_quad(const dmvae_epilogue& e, int m, int n, float v[4], float& loss) {
+    if constexpr (EPI == DMVAE_EPI_BIAS_RELU) {
+        float b[4];
+        loadf4(e.bias, n, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j] + b[j], 0.f);
+        ActIO<ACT>::store4(e.out, (int64_t)m * e.ldo + n, v);
+    } else if constexpr (EPI == DMVAE_EPI_BIAS_F32) {
+        float b[4];
+        loadf4(e.bias, n, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += b[j];
+        ActIO<float>::store4(e.out, (int64_t)m * e.ldo + n, v);
+    } else if constexpr (EPI == DMVAE_EPI_BIAS_SIGMOID) {
+        float b[4];
+        loadf4(e.bias, n, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = sigmoidf_(v[j] + b[j]);
+        ActIO<float>::store4(e.out, (int64_t)m * e.ldo + n, v);
+    } else if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
+        float b[4], x[4], d[4];
+        loadf4(e.bias, n, b);
+        loadf4(e.aux0, (int64_t)m * e.ld0 + n, x);
+        const bool rowok = m < e.m_valid;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float l = v[j] + b[j];
+            v[j] = l;
+            const bool ok = rowok && (n + j) < e.n_valid;
+            if (e.recon_kind == 0) {
+                loss += ok ? xent_logits(l, x[j]) : 0.f;
+                d[j] = ok ? (sigmoidf_(l) - x[j]) * e.scale : 0.f;
+            } else {
+                const float r = l - x[j];
+                loss += ok ? 0.5f * r * r : 0.f;
+                d[j] = ok ? r * e.scale : 0.f;
+            }
+        }
+        ActIO<ACT>::store4(e.out, (int64_t)m * e.ldo + n, d);
+        if (e.out2) ActIO<float>::store4(e.out2, (int64_t)m * e.ldo2 + n, v);
+    } else if constexpr (EPI == DMVAE_EPI_RELU_MASK) {
+        float y[4];
+        ActIO<ACT>::load4(e.aux0, (int64_t)m * e.ld0 + n, y);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = y[j] > 0.f ? v[j] : 0.f;
+        ActIO<ACT>::store4(e.out, (int64_t)m * e.ldo + n, v);
+    } else if constexpr (EPI == DMVAE_EPI_LATENT) {
+        float gm[4], gl[4], cl[4], o0[4], o1[4];
+        loadf4(e.aux0, (int64_t)m * e.ld0 + n, gm);
+        loadf4(e.aux1, (int64_t)m * e.ld1 + n, gl);
+        loadf4(e.aux2, (int64_t)m * e.ld2 + n, cl);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o0[j] = v[j] + gm[j];
+            o1[j] = v[j] * cl[j] + gl[j];
+        }
+        ActIO<ACT>::store4(e.out, (int64_t)m * e.ldo + n, o0);
+        ActIO<ACT>::store4(e.out, (int64_t)m * e.ldo + e.d_off + n, o1);
+    } else if constexpr (EPI == DMVAE_EPI_STORE_F32) {
+        ActIO<float>::store4(e.out, (int64_t)m * e.ldo + n, v);
+    } else if constexpr (EPI == DMVAE_EPI_ATOMIC_F32) {
+        float* o = reinterpret_cast<float*>(e.out) + (int64_t)m * e.ldo + n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(o + j, v[j]);
+    }
+}
+
+}  // namespace dmvae

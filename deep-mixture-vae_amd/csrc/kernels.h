@@ -1,0 +1,34 @@
+// Launchers implemented in the kernel translation units (host side, namespace dmvae).
+#pragma once
+#include "gemm_epilogue.h"
+
+namespace dmvae {
+
+struct AdamArgs {
+    int64_t n;
+    float* p; float* g; float* m; float* v; bf16_t* pb;
+    float lr, b1, b2, eps, gscale;
+    int zero_grad;
+    uint64_t t_host;
+    const dmvae_state* st;
+};
+
+int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split);
+int gemm_bf16_tile_m(int M, int N, int split);
+int gemm_f32_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split);
+int latent_nblocks(int B_pad, int D, int K);
+int latent_launch(hipStream_t s, const dmvae_latent_args* a);
+int adam_launch(hipStream_t s, const AdamArgs& a);
+int adam_finish_launch(hipStream_t s, void* st);
+int colsum_prepare(int64_t max_n);
+int colsum_launch(hipStream_t s, int in_dtype, const void* in, int64_t ld, int M, int N, float* out, float* ws, int64_t ws_elems);
+int recon_nblocks(int B_pad, int I_pad);
+int recon_launch(hipStream_t s, int act_dtype, int recon_kind, int B, int B_pad, int I, int I_pad, const float* logits, int64_t ldl,
+                 const float* x, int64_t ldx, float inv_B, void* dl, int64_t ldd, float* partials);
+int loss_finalize_launch(hipStream_t s, const float* rp, int nr, const float* lp, int nl, float inv_B, void* st);
+int gather_launch(hipStream_t s, int act_dtype, const float* data, int64_t n_rows, int dim, const int32_t* perm, int64_t first, int batch,
+                  int n_valid, int B_pad, void* out_act, int64_t ld_act, float* out_f32, int64_t ld_f32, int cols_pad, const void* st);
+int philox_launch(hipStream_t s, float* out, int64_t n, uint64_t seed, uint64_t step, uint32_t sid, int gumbel);
+int cast_launch(hipStream_t s, const void* in, void* out, int64_t n, int to_bf16);
+
+}  // namespace dmvae

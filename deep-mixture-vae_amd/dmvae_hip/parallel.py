@@ -1,0 +1,56 @@
+"""Data-parallel layer of the DMVAE step (no reference counterpart: the
+reference is single-process).
+
+One process per GPU.  Every loss term is a batch mean of per-row quantities
+(base_models.py:74-79, priors.py:145,199), so with equal shards the global
+gradient is the mean of the per-rank gradients -- prior tables included.  The
+exchange is ONE collective per step on the flat fp32 gradient arena
+(torch.distributed: backend "nccl" = RCCL over xGMI on the GPU box, "gloo" on
+CPU in the tests); the 1/world factor is folded into the Adam kernel
+(grad_scale), so no separate scaling pass touches HBM.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_rows, rank, world):
+    """Rows [lo, hi) of a global batch of n_rows owned by `rank`: equal
+    contiguous shards, the remainder spread over the first ranks."""
+    base, rem = divmod(int(n_rows), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class GradExchange:
+    """all-reduce(SUM) of the gradient arena; callable usable inside a captured
+    HIP graph (RCCL collectives are capturable)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.enabled else 1
+        self.rank = dist.get_rank(group) if self.enabled else 0
+
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world
+
+    def __call__(self, flat_grad):
+        if self.enabled:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+        return flat_grad
+
+    def broadcast_(self, tensor, src=0):
+        if self.enabled:
+            dist.broadcast(tensor, src=src, group=self.group)
+        return tensor
+
+    def mean_scalars(self, values):
+        """average a few python floats over ranks (logging cadence only)"""
+        if not self.enabled:
+            return list(values)
+        t = torch.tensor(list(values), dtype=torch.float64)
+        if dist.get_backend(self.group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return (t / self.world).tolist()

@@ -1,0 +1,322 @@
+"""Host runtime of the MI355X DMVAE step: Session (the stand-in for tf.Session,
+code/train.py:238) and StepEngine (the step plan of libdmvae_hip.so bound to
+torch-owned device memory).  PyTorch is used for device memory, streams, HIP
+graphs and torch.distributed only; all arithmetic runs in the HIP library."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "dmvae_hip needs an AMD GPU (gfx950): torch.cuda.is_available() is False. "
+            "There is no CPU execution path in this package.")
+
+
+class Session:
+    """Opaque runtime handle: device, stream, rank/world.  Mirrors the role of
+    the tf.Session the reference passes around (train.py:238, base_models.py:112)."""
+
+    def __init__(self, device=None):
+        _require_gpu()
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if device is None:
+            device = torch.device("cuda", self.local_rank % max(1, torch.cuda.device_count()))
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+
+    @property
+    def stream(self):
+        return torch.cuda.current_stream(self.device)
+
+    def run(self, *a, **k):   # the reference's session.run has no counterpart: fail loudly
+        raise NotImplementedError("Session.run: there is no TensorFlow graph; use the model methods")
+
+    def close(self):
+        pass
+
+
+_default_session = None
+
+
+def default_session():
+    global _default_session
+    if _default_session is None:
+        _default_session = Session()
+    return _default_session
+
+
+def layer_table(input_dim, latent_dim, n_classes, enc_layers, head_dim, dec_layers):
+    """[(name, fan_in, fan_out, bias_kind)] in graph-construction order
+    (base_models.py:218-293).  bias_kind: 'zero' = tf.layers.dense default,
+    'xavier' = FullyConnected bias (1,out) (includes/layers.py:24-28)."""
+    t = []
+    prev = input_dim
+    for i, h in enumerate(enc_layers):
+        t.append(("enc%d" % i, prev, h, "zero"))
+        prev = h
+    trunk = prev
+    t += [("zh", trunk, head_dim, "zero"), ("mean", head_dim, latent_dim, "zero"),
+          ("logvar", head_dim, latent_dim, "zero"), ("ch", trunk, head_dim, "zero"),
+          ("logits", head_dim, n_classes, "zero")]
+    prev = latent_dim
+    for i, h in enumerate(dec_layers):
+        t.append(("dec%d" % i, prev, h, "xavier"))
+        prev = h
+    t.append(("out", prev, input_dim, "zero"))
+    return t
+
+
+class StepEngine:
+    """One DMVAE model instance on one GPU: parameter / gradient / Adam arenas,
+    activation workspace, device step state, and the enqueue methods of the
+    step plan.  All compute calls go through the C ABI."""
+
+    def __init__(self, input_dim, latent_dim, n_classes, enc_layers=(500, 500), head_dim=2000,
+                 dec_layers=(2000, 500, 500), input_type="binary", dtype="bf16", max_batch=100,
+                 mode="exact", temperature=1.0, seed=0, deterministic=False, session=None,
+                 beta1=0.9, beta2=0.999, adam_eps=1e-8):
+        self.session = session or default_session()
+        dev = self.session.device
+        self.device = dev
+        self.input_dim, self.latent_dim, self.n_classes = int(input_dim), int(latent_dim), int(n_classes)
+        self.enc_layers, self.dec_layers, self.head_dim = tuple(enc_layers), tuple(dec_layers), int(head_dim)
+        self.input_type = input_type
+        self.dtype = {"bf16": _lib.BF16, "fp32": _lib.F32, "f32": _lib.F32}[dtype]
+        self.dtype_name = "bf16" if self.dtype == _lib.BF16 else "fp32"
+        self.max_batch = int(max_batch)
+        self.mode = {"exact": 0, "relaxed": 1}[mode]
+        self.deterministic = bool(deterministic)
+        cfg = _lib.Config()
+        cfg.input_dim, cfg.latent_dim, cfg.n_classes = self.input_dim, self.latent_dim, self.n_classes
+        cfg.n_enc = len(self.enc_layers)
+        for i, v in enumerate(self.enc_layers):
+            cfg.enc[i] = int(v)
+        cfg.head_dim = self.head_dim
+        cfg.n_dec = len(self.dec_layers)
+        for i, v in enumerate(self.dec_layers):
+            cfg.dec[i] = int(v)
+        cfg.input_type = {"binary": 0, "real": 1}[input_type]
+        cfg.dtype = self.dtype
+        cfg.max_batch = self.max_batch
+        cfg.mode = self.mode
+        cfg.temperature = float(temperature)
+        cfg.beta1, cfg.beta2, cfg.adam_eps = float(beta1), float(beta2), float(adam_eps)
+        cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        cfg.deterministic = 1 if deterministic else 0
+        self._cfg = cfg
+        h = C.c_void_p()
+        check(lib.dmvae_plan_create(C.byref(cfg), C.byref(h)), "dmvae_plan_create")
+        self._plan = h
+        sz = _lib.Sizes()
+        check(lib.dmvae_plan_sizes(self._plan, C.byref(sz)), "dmvae_plan_sizes")
+        self.sizes = sz
+        self.batch_pad, self.input_pad = sz.batch_pad, sz.input_pad
+        n = sz.param_elems
+        self.param = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.param_bf16 = torch.zeros(n, dtype=torch.bfloat16, device=dev) if self.dtype == _lib.BF16 else None
+        self.work = torch.zeros(sz.work_bytes, dtype=torch.uint8, device=dev)
+        self.state_t = torch.zeros(C.sizeof(_lib.State), dtype=torch.uint8, device=dev)
+        b = _lib.Buffers(ptr(self.param), ptr(self.grad), ptr(self.m), ptr(self.v),
+                         ptr(self.param_bf16), ptr(self.work), ptr(self.state_t))
+        check(lib.dmvae_plan_bind(self._plan, C.byref(b)), "dmvae_plan_bind")
+        self.tensors = {}
+        for i in range(sz.n_tensors):
+            ti = _lib.TensorInfo()
+            check(lib.dmvae_plan_tensor(self._plan, i, C.byref(ti)), "dmvae_plan_tensor")
+            self.tensors[ti.name.decode()] = (ti.offset, ti.rows, ti.cols, ti.ld)
+        self.write_state(kl_ratio=1.0, lr=0.002, epoch_weight=1.0, batches_per_epoch=0)
+        self._graph = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_plan", None):
+                lib.dmvae_plan_destroy(self._plan)
+                self._plan = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------ parameters
+    def _strided(self, arena, name):
+        off, rows, cols, ld = self.tensors[name]
+        if name.startswith("b_"):
+            return torch.as_strided(arena, (cols,), (1,), off)
+        return torch.as_strided(arena, (rows, cols), (ld, 1), off)
+
+    def param_view(self, name):
+        return self._strided(self.param, name)
+
+    def grad_view(self, name):
+        return self._strided(self.grad, name)
+
+    def parameter_names(self):
+        return list(self.tensors.keys())
+
+    def get_parameters(self):
+        return {k: self.param_view(k).detach().cpu().numpy().copy() for k in self.tensors}
+
+    def get_gradients(self):
+        return {k: self.grad_view(k).detach().cpu().numpy().copy() for k in self.tensors}
+
+    def set_parameters(self, params):
+        for k, v in params.items():
+            self.param_view(k).copy_(torch.as_tensor(np.asarray(v, dtype=np.float32)).to(self.device))
+        self.refresh_shadow()
+
+    def init_parameters(self, seed=0):
+        """Reference-faithful initialisation: xavier-uniform
+        kernels (train.py:197), zero dense biases, xavier FullyConnected biases
+        (includes/layers.py:24-28), prior means ~ N(0,1), prior log-vars = 0
+        (priors.py:57-65)."""
+        rng = np.random.RandomState(seed)
+        p = {}
+        for name, fi, fo, bk in layer_table(self.input_dim, self.latent_dim, self.n_classes,
+                                            self.enc_layers, self.head_dim, self.dec_layers):
+            lim = math.sqrt(6.0 / (fi + fo))
+            p["W_" + name] = rng.uniform(-lim, lim, size=(fi, fo))
+            if bk == "zero":
+                p["b_" + name] = np.zeros((fo,))
+            else:
+                lb = math.sqrt(6.0 / (1 + fo))
+                p["b_" + name] = rng.uniform(-lb, lb, size=(fo,))
+        p["prior_means"] = rng.randn(self.n_classes, self.latent_dim)
+        p["prior_log_vars"] = np.zeros((self.n_classes, self.latent_dim))
+        self.param.zero_()
+        self.m.zero_()
+        self.v.zero_()
+        self.grad.zero_()
+        self.set_parameters(p)
+        st = self.read_state()
+        self.write_state(adam_t=0, noise_step=0, kl_ratio=st.kl_ratio, lr=st.lr)
+
+    def refresh_shadow(self):
+        if self.param_bf16 is not None:
+            check(lib.dmvae_cast_f32_to_bf16(self._stream(), ptr(self.param), ptr(self.param_bf16),
+                                             self.param.numel()), "dmvae_cast_f32_to_bf16")
+
+    # ------------------------------------------------------------ device step state
+    def read_state(self):
+        raw = self.state_t.cpu().numpy().tobytes()
+        return _lib.State.from_buffer_copy(raw)
+
+    def write_state(self, **kw):
+        st = self.read_state() if kw.pop("_merge", True) else _lib.State()
+        for k, v in kw.items():
+            setattr(st, k, v)
+        host = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8)
+        self.state_t.copy_(host)
+
+    def reset_epoch(self, batches_per_epoch, kl_ratio=None, epoch_weight=None):
+        kw = dict(batch_cursor=0, batches_per_epoch=int(batches_per_epoch), epoch_loss=0.0, epoch_recon=0.0,
+                  epoch_klz=0.0, epoch_klc=0.0,
+                  epoch_weight=float(epoch_weight if epoch_weight is not None else 1.0 / max(1, batches_per_epoch)))
+        if kl_ratio is not None:
+            kw["kl_ratio"] = float(kl_ratio)
+        self.write_state(**kw)
+
+    # ------------------------------------------------------------ enqueue
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def load_batch(self, data, perm=None, first=0, n_valid=None, use_state_cursor=False):
+        """Dataset.get_batches batch assembly (includes/utils.py:449-463) on the
+        device: data f32 [N, input_dim] resident in HBM, perm int32 [N] or None."""
+        assert data.dtype == torch.float32 and data.is_contiguous() and data.shape[1] == self.input_dim
+        assert perm is None or (perm.dtype == torch.int32 and perm.is_contiguous())
+        n_valid = self.max_batch if n_valid is None else int(n_valid)
+        check(lib.dmvae_plan_load_batch(self._plan, self._stream(), ptr(data), data.shape[0], ptr(perm),
+                                        int(first), n_valid, 1 if use_state_cursor else 0), "dmvae_plan_load_batch")
+
+    def forward_backward(self, n_valid=None, eps=None, gumbel=None, inv_B=None):
+        n_valid = self.max_batch if n_valid is None else int(n_valid)
+        if eps is not None:
+            assert eps.dtype == torch.float32 and eps.is_contiguous() and eps.shape == (n_valid, self.latent_dim)
+        if gumbel is not None:
+            assert gumbel.dtype == torch.float32 and gumbel.is_contiguous() and gumbel.shape == (n_valid, self.n_classes)
+        inv_B = 1.0 / n_valid if inv_B is None else float(inv_B)
+        check(lib.dmvae_plan_forward_backward(self._plan, self._stream(), n_valid, ptr(eps), self.latent_dim,
+                                              ptr(gumbel), self.n_classes, inv_B), "dmvae_plan_forward_backward")
+
+    def update(self, grad_scale=1.0):
+        check(lib.dmvae_plan_update(self._plan, self._stream(), float(grad_scale)), "dmvae_plan_update")
+
+    def encode(self, n_valid=None):
+        n_valid = self.max_batch if n_valid is None else int(n_valid)
+        check(lib.dmvae_plan_encode(self._plan, self._stream(), n_valid), "dmvae_plan_encode")
+
+    def decode(self, Z):
+        assert Z.dtype == torch.float32 and Z.is_contiguous() and Z.shape[1] == self.latent_dim
+        check(lib.dmvae_plan_decode(self._plan, self._stream(), ptr(Z), self.latent_dim, Z.shape[0]), "dmvae_plan_decode")
+
+    def view(self, name, rows=None, cols=None):
+        """torch view of a workspace tensor ("mean", "log_var", "logits", "weights",
+        "recon", "x", "Z", "dxlogits")."""
+        p, ld, dt = C.c_void_p(), C.c_int64(), C.c_int32()
+        check(lib.dmvae_plan_view(self._plan, name.encode(), C.byref(p), C.byref(ld), C.byref(dt)), "dmvae_plan_view")
+        tdt = torch.bfloat16 if dt.value == _lib.BF16 else torch.float32
+        es = 2 if dt.value == _lib.BF16 else 4
+        off = p.value - self.work.data_ptr()
+        flat = self.work[off: off + self.batch_pad * ld.value * es].view(tdt)
+        t = torch.as_strided(flat, (self.batch_pad, ld.value), (ld.value, 1))
+        full_cols = {"mean": self.latent_dim, "log_var": self.latent_dim, "logits": self.n_classes,
+                     "weights": self.n_classes, "recon": self.input_dim, "x": self.input_dim,
+                     "Z": self.latent_dim, "dxlogits": self.input_dim}[name]
+        return t[: (self.max_batch if rows is None else rows), : (full_cols if cols is None else cols)]
+
+    # ------------------------------------------------------------ whole step, HIP graph
+    def train_step(self, data, perm, n_valid=None, eps=None, gumbel=None, first=0, use_state_cursor=False,
+                   grad_sync=None, grad_scale=1.0, inv_B=None):
+        """load batch -> forward/loss/backward -> (gradient exchange) -> Adam."""
+        self.load_batch(data, perm, first, n_valid, use_state_cursor)
+        self.forward_backward(n_valid, eps, gumbel, inv_B)
+        if grad_sync is not None:
+            grad_sync(self.grad)
+        self.update(grad_scale)
+
+    def capture_step(self, data, perm, grad_sync=None, grad_scale=1.0, inv_B=None):
+        """Capture one full-batch step (device Philox noise, batch cursor read from
+        the device state) into a HIP graph; returns a callable that replays it."""
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        saved = (self.param.clone(), self.m.clone(), self.v.clone(), self.state_t.clone())
+        with torch.cuda.stream(side):
+            for _ in range(2):   # warm-up outside capture (lazy module loads, RCCL channels)
+                self.train_step(data, perm, None, None, None, 0, True, grad_sync, grad_scale, inv_B)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self.param.copy_(saved[0]); self.m.copy_(saved[1]); self.v.copy_(saved[2]); self.state_t.copy_(saved[3])
+        self.grad.zero_()
+        self.refresh_shadow()
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            self.train_step(data, perm, None, None, None, 0, True, grad_sync, grad_scale, inv_B)
+        self._graph = g
+        return g.replay
+
+
+def prof_enable(on=True):
+    check(lib.dmvae_prof_enable(1 if on else 0), "dmvae_prof_enable")
+
+
+def prof_collect(max_rows=64):
+    rows = (_lib.ProfRow * max_rows)()
+    n = lib.dmvae_prof_collect(rows, max_rows)
+    out = []
+    for i in range(n):
+        r = rows[i]
+        out.append(dict(name=r.name.decode(), launches=int(r.launches), total_ms=float(r.total_ms),
+                        flops=float(r.flops), bytes=float(r.bytes)))
+    return out

@@ -1,0 +1,280 @@
+/*
+ * dmvae_hip.h -- C ABI of the MI355X (gfx950) DMVAE training-step library.
+ *
+ * This is the drop-in boundary for the ONE hot path of ffs97/deep-mixture-vae:
+ * everything that the reference executes inside
+ *     session.run([self.loss, self.train_step], feed_dict)      code/base_models.py:126-129
+ * (forward MLPs, reparameterisation, mixture KL, Bernoulli reconstruction
+ * loss, autodiff backward, Adam) plus the host batch assembly that feeds it.
+ * The reference has no FFI of its own (pure Python over TensorFlow 1.x), so
+ * each entry point names the TensorFlow op / reference line it replaces.
+ *
+ * Conventions
+ *   - plain C: device pointers + sizes, no C++ / torch types.
+ *   - `stream` is a hipStream_t passed as void*; every call only ENQUEUES work
+ *     on it (safe under stream capture); nothing synchronises or allocates.
+ *   - every function returns 0 on success, a negative DMVAE_E* code for an
+ *     argument error, or a positive hipError_t; dmvae_last_error() gives text.
+ *   - matrices are row-major with an explicit leading dimension (elements).
+ *   - "act" buffers are bf16 when dtype == DMVAE_BF16, float when DMVAE_F32.
+ *   - not re-entrant on the same stream/plan; distinct streams are independent.
+ */
+#ifndef DMVAE_HIP_H
+#define DMVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMVAE_ABI_VERSION 1
+
+enum { DMVAE_F32 = 0, DMVAE_BF16 = 1 };
+
+enum {
+    DMVAE_EINVAL = -1,   /* bad argument (shape not tile aligned, null pointer ...) */
+    DMVAE_EUNSUPPORTED = -2,
+    DMVAE_ESTATE = -3
+};
+
+/* ---- operand layouts of dmvae_gemm -------------------------------------
+ * C[M,N] = sum_k A(m,k) * B(k,n)
+ *   DMVAE_GEMM_FWD : A = act [M][lda] (k contiguous),  B = W [K][ldb] (n contiguous)
+ *                    tf.layers.dense / tf.matmul forward   base_models.py:221-248,291-293, includes/layers.py:32
+ *   DMVAE_GEMM_DX  : A = dY  [M][lda] (k contiguous),  B = W [N][ldb] (k contiguous)
+ *                    dX = dY . W^T  (tf.gradients of the above, base_models.py:110)
+ *   DMVAE_GEMM_DW  : A = X   [K][lda] (m contiguous),  B = dY [K][ldb] (n contiguous)
+ *                    dW = X^T . dY  (tf.gradients of the above)
+ * M, N must be multiples of 64 and K of 64 (callers pad; see dmvae_plan).
+ */
+enum { DMVAE_GEMM_FWD = 0, DMVAE_GEMM_DX = 1, DMVAE_GEMM_DW = 2 };
+
+/* ---- fused epilogues ---------------------------------------------------- */
+enum {
+    DMVAE_EPI_BIAS_RELU = 0, /* out(act) = relu(acc + bias[n])                    activation=relu dense      */
+    DMVAE_EPI_BIAS_F32 = 1,  /* out(f32) = acc + bias[n]                          linear heads               */
+    DMVAE_EPI_BIAS_RECON = 2,/* l = acc + bias; loss partial + out(act) = dLoss/dl  base_models.py:72-85       */
+    DMVAE_EPI_RELU_MASK = 3, /* out(act) = acc * (aux0(act)[m][n] > 0)            ReLU backward              */
+    DMVAE_EPI_LATENT = 4,    /* dZ = acc: out[m][n] = dZ + aux0, out[m][d_off+n] = dZ*aux2 + aux1   priors.py:86-89 backward */
+    DMVAE_EPI_STORE_F32 = 5, /* out(f32) = acc            (dW, split_k == 1)                                    */
+    DMVAE_EPI_ATOMIC_F32 = 6,/* out(f32) += acc via atomics (dW, split_k > 1; out pre-zeroed)                   */
+    DMVAE_EPI_BIAS_SIGMOID = 7 /* out(f32) = sigmoid(acc + bias)  reconstructed_X  base_models.py:295-296      */
+};
+
+typedef struct dmvae_epilogue {
+    int32_t kind;        /* DMVAE_EPI_*                                              */
+    int32_t m_valid;     /* rows  < m_valid are real (RECON masks the rest), 0 = all */
+    int32_t n_valid;     /* cols  < n_valid are real (RECON masks the rest), 0 = all */
+    int32_t d_off;       /* LATENT: column offset of the log_var half                */
+    int32_t recon_kind;  /* RECON: 0 = binary (sigmoid xent), 1 = real (0.5*sq err)  */
+    float scale;         /* RECON: 1/B                                               */
+    void* out;           /* primary output                                           */
+    int64_t ldo;
+    void* out2;          /* RECON: optional f32 copy of the logits (may be NULL)     */
+    int64_t ldo2;
+    const float* bias;   /* [N] or NULL                                              */
+    const void* aux0;    /* RELU_MASK: forward activation (act); RECON: x (f32); LATENT: gmu (f32) */
+    int64_t ld0;
+    const void* aux1;    /* LATENT: glv (f32) */
+    int64_t ld1;
+    const void* aux2;    /* LATENT: clv = eps*0.5*exp(lv/2) (f32) */
+    int64_t ld2;
+    float* partials;     /* RECON: per-workgroup loss partial sums, length >= dmvae_gemm_partials() */
+} dmvae_epilogue;
+
+/* GEMM with fused epilogue.  dtype selects bf16 MFMA (v_mfma_f32_16x16x32_bf16,
+ * fp32 accumulate) or exact-f32 MFMA (v_mfma_f32_16x16x4_f32).  split_k > 1 is
+ * valid only with DMVAE_EPI_ATOMIC_F32. */
+int dmvae_gemm(void* stream, int dtype, int layout, int M, int N, int K,
+               const void* A, int64_t lda, const void* B, int64_t ldb,
+               const dmvae_epilogue* epi, int split_k);
+/* number of loss partials dmvae_gemm writes for an (M,N) RECON launch */
+int dmvae_gemm_partials(int dtype, int M, int N);
+
+/* ---- latent kernel: softmax + reparameterisation + mixture KL + all KL gradients
+ * replaces priors.py:86-89 (Z), :104-147 (KL_Z exact / relaxed), :170-181
+ * (Gumbel-Softmax), :183-201 (KL_C), base_models.py:249 (softmax) and their
+ * tf.gradients.  mode 0 = exact (cluster_sample False, live), 1 = relaxed. */
+typedef struct dmvae_latent_args {
+    int32_t B;            /* rows that are real; rows [B, B_pad) are written as zeros */
+    int32_t B_pad;
+    int32_t D, K;
+    int32_t mode;         /* 0 exact, 1 relaxed (Gumbel-Softmax weights)              */
+    int32_t act_dtype;    /* dtype of Z_act / dlogits_act                              */
+    float kl_ratio;       /* used when state == NULL                                  */
+    float temperature;
+    float inv_B;          /* 1 / (batch size the loss averages over)                  */
+    uint64_t seed;        /* Philox key when eps / gumbel are NULL                    */
+    uint64_t noise_step;  /* Philox stream position when state == NULL                */
+    const float* mean; int64_t ld_mean;       /* [B_pad][>=D] */
+    const float* log_var; int64_t ld_log_var; /* [B_pad][>=D] */
+    const float* logits; int64_t ld_logits;   /* [B_pad][>=K] */
+    const float* eps; int64_t ld_eps;         /* [B][D] or NULL -> on-device Philox N(0,1)   */
+    const float* gumbel; int64_t ld_gumbel;   /* [B][K] or NULL -> on-device Philox Gumbel    */
+    const float* prior_means;                 /* [K][D] */
+    const float* prior_log_vars;              /* [K][D] */
+    void* Z_act; int64_t ld_Z;                /* [B_pad][ld_Z] act dtype; cols >= D zeroed    */
+    float* Z_f32; int64_t ld_Zf;              /* optional f32 copy or NULL                    */
+    float* weights; int64_t ld_w;             /* optional [B_pad][K]: softmax(logits) / zeta  */
+    float* gmu; float* glv; float* clv; int64_t ld_g;  /* [B_pad][ld_g] f32: KL grads wrt mean/log_var, reparam coef */
+    void* dlogits_act; int64_t ld_dl;         /* [B_pad][ld_dl] act dtype; cols >= K zeroed   */
+    float* dprior_partials;                   /* [nblocks][2][K][D] f32 (deterministic two-pass) */
+    float* loss_partials;                     /* [nblocks][2]: sum_b KL_Z_b, sum_b KL_C_b      */
+    const void* state;                        /* optional dmvae_state* (device): kl_ratio, noise_step read from it */
+} dmvae_latent_args;
+int dmvae_latent_nblocks(int B_pad, int D, int K);
+int dmvae_latent_fwd(void* stream, const dmvae_latent_args* a);
+
+/* ---- stand-alone reconstruction loss (fused form: DMVAE_EPI_BIAS_RECON) --
+ * tf.nn.sigmoid_cross_entropy_with_logits + reduce_sum/mean, base_models.py:72-85 */
+int dmvae_recon_fwd_bwd(void* stream, int act_dtype, int recon_kind, int B, int B_pad, int I, int I_pad,
+                        const float* logits, int64_t ldl, const float* x, int64_t ldx, float inv_B,
+                        void* dlogits_act, int64_t ldd, float* partials /* [dmvae_recon_nblocks] */);
+int dmvae_recon_nblocks(int B_pad, int I_pad);
+
+/* ---- column sums (bias gradients, reduction of per-block partials) ------
+ * out[n] = sum_m in[m][n]; tf.gradients of the bias add. */
+int dmvae_colsum(void* stream, int in_dtype, const void* in, int64_t ld, int M, int N, float* out);
+
+/* ---- device-resident step state (read by kernels so a captured graph can be replayed) */
+typedef struct dmvae_state {
+    uint64_t adam_t;        /* completed Adam updates (t of the next update = adam_t + 1) */
+    uint64_t noise_step;    /* Philox stream position                                  */
+    uint32_t batch_cursor;  /* next batch within the epoch                             */
+    uint32_t batches_per_epoch;
+    float kl_ratio;
+    float lr;
+    float epoch_weight;     /* 1/epoch_len: loss += batch_loss * epoch_weight  (base_models.py:130) */
+    float pad0;
+    float epoch_loss, epoch_recon, epoch_klz, epoch_klc;   /* running epoch means   */
+    float last_loss, last_recon, last_klz, last_klc;       /* last batch            */
+} dmvae_state;
+
+/* loss = recon + kl_ratio*(KL_C + KL_Z)  (base_models.py:87-93); sums the
+ * per-block partials deterministically, updates state (epoch accumulators,
+ * batch_cursor, noise_step). */
+int dmvae_loss_finalize(void* stream, const float* recon_partials, int n_recon,
+                        const float* latent_partials, int n_latent, float inv_B, void* state);
+
+/* ---- TF-1.x Adam on a flat arena (tf.train.AdamOptimizer, base_models.py:95-110)
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t*m/(sqrt(v)+eps).  t = state->adam_t+1
+ * (or t_host when state is NULL).  grad is multiplied by grad_scale first (1/world).
+ * Optionally refreshes a bf16 shadow of the parameters and zeroes grad.
+ * dmvae_adam_finish bumps state->adam_t (separate 1-thread kernel so that all
+ * chunks of one update see the same t). */
+int dmvae_adam_tf(void* stream, int64_t n, float* param, float* grad, float* m, float* v,
+                  void* param_bf16, float lr, float beta1, float beta2, float epsilon,
+                  float grad_scale, int zero_grad, uint64_t t_host, const void* state);
+int dmvae_adam_finish(void* stream, void* state);
+
+/* ---- batch assembly (Dataset.get_batches, includes/utils.py:449-463) -----
+ * row r of the batch = data[perm[first + r]] (perm NULL: data[first + r]);
+ * first = cursor*batch (cursor from state when state != NULL).  Writes the act
+ * copy [B_pad][ld_act] and an f32 copy (either may be NULL); pad rows/cols = 0. */
+int dmvae_gather_rows(void* stream, int act_dtype, const float* data, int64_t n_rows, int dim,
+                      const int32_t* perm, int64_t first, int batch, int n_valid, int B_pad,
+                      void* out_act, int64_t ld_act, float* out_f32, int64_t ld_f32,
+                      const void* state);
+
+/* ---- noise (np.random.randn / sample_gumbel, priors.py:67-68,157-158) ---- */
+int dmvae_philox_normal(void* stream, float* out, int64_t n, uint64_t seed, uint64_t step, uint32_t stream_id);
+int dmvae_philox_gumbel(void* stream, float* out, int64_t n, uint64_t seed, uint64_t step, uint32_t stream_id);
+
+/* ---- casts ---- */
+int dmvae_cast_f32_to_bf16(void* stream, const float* in, void* out, int64_t n);
+int dmvae_cast_bf16_to_f32(void* stream, const void* in, float* out, int64_t n);
+
+/* ======================================================================
+ * Step plan: the whole session.run([loss, train_step]) as one enqueue.
+ * ====================================================================== */
+#define DMVAE_MAX_LAYERS 8
+
+typedef struct dmvae_config {
+    int32_t input_dim, latent_dim, n_classes;
+    int32_t n_enc; int32_t enc[DMVAE_MAX_LAYERS];   /* trunk widths (reference: 500,500)        */
+    int32_t head_dim;                                /* z-/c-head hidden width (reference: 2000) */
+    int32_t n_dec; int32_t dec[DMVAE_MAX_LAYERS];   /* decoder widths (reference: 2000,500,500) */
+    int32_t input_type;                              /* 0 binary, 1 real                         */
+    int32_t dtype;                                   /* DMVAE_F32 (parity) or DMVAE_BF16         */
+    int32_t max_batch;                               /* largest per-rank batch                   */
+    int32_t mode;                                    /* 0 exact KL, 1 relaxed (Gumbel-Softmax)   */
+    float temperature;
+    float beta1, beta2, adam_eps;
+    uint64_t seed;
+    int32_t deterministic;                           /* 1: no float atomics anywhere             */
+    int32_t reserved;
+} dmvae_config;
+
+typedef struct dmvae_tensor_info {
+    char name[32];
+    int64_t offset;      /* element offset in the parameter arena */
+    int32_t rows, cols;  /* logical shape (rows = 1 for biases)   */
+    int64_t ld;          /* row stride in elements                */
+} dmvae_tensor_info;
+
+typedef struct dmvae_sizes {
+    int64_t param_elems;     /* f32 arena (also grad, m, v; and the bf16 shadow in elements) */
+    int64_t work_bytes;      /* activation / scratch workspace                               */
+    int32_t batch_pad;       /* padded batch rows                                            */
+    int32_t input_pad;       /* padded input columns                                         */
+    int32_t n_tensors;
+    int32_t reserved;
+} dmvae_sizes;
+
+typedef struct dmvae_buffers {
+    float* param; float* grad; float* m; float* v;
+    void* param_bf16;     /* bf16 shadow (may be NULL when dtype == DMVAE_F32) */
+    void* work;           /* work_bytes, 256-byte aligned, zero-initialised by the caller */
+    void* state;          /* dmvae_state on the device */
+} dmvae_buffers;
+
+typedef struct dmvae_plan dmvae_plan;
+
+int dmvae_plan_create(const dmvae_config* cfg, dmvae_plan** out);
+void dmvae_plan_destroy(dmvae_plan* p);
+int dmvae_plan_sizes(const dmvae_plan* p, dmvae_sizes* out);
+int dmvae_plan_tensor(const dmvae_plan* p, int index, dmvae_tensor_info* out);
+int dmvae_plan_bind(dmvae_plan* p, const dmvae_buffers* b);
+
+/* batch assembly into the plan's input buffers (see dmvae_gather_rows) */
+int dmvae_plan_load_batch(dmvae_plan* p, void* stream, const float* data, int64_t n_rows,
+                          const int32_t* perm, int64_t first, int n_valid, int use_state_cursor);
+/* forward + loss + backward: fills the grad arena and the loss partials.
+ * eps / gumbel: caller-supplied noise (parity mode) or NULL (on-device Philox). */
+int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_valid,
+                                const float* eps, int64_t ld_eps, const float* gumbel, int64_t ld_gumbel,
+                                float inv_B);
+/* loss finalize + Adam (+ bf16 shadow refresh); grad_scale = 1/world_size */
+int dmvae_plan_update(dmvae_plan* p, void* stream, float grad_scale);
+/* inference pieces used by get_accuracy / reconstruction / sampling:
+ * encode: X (loaded batch) -> mean, log_var, logits (f32, in the workspace)
+ * decode: Z (f32 [n][latent_dim], caller) -> sigmoid/identity reconstruction (f32, workspace) */
+int dmvae_plan_encode(dmvae_plan* p, void* stream, int n_valid);
+int dmvae_plan_decode(dmvae_plan* p, void* stream, const float* Z, int64_t ldz, int n_valid);
+/* workspace views: name in {"mean","log_var","logits","recon","weights","Z","xlogits","x"};
+ * returns the device pointer, leading dimension (elements) and dtype. */
+int dmvae_plan_view(const dmvae_plan* p, const char* name, void** ptr, int64_t* ld, int32_t* dtype);
+
+/* ---- per-kernel timing with HIP events (bench.py roofline leg) ----------
+ * enable(1): every launch made through this library is bracketed by a
+ * hipEvent pair on its stream.  collect() synchronises those events and
+ * returns, per kernel family, launches / total ms / algorithmic flops / bytes. */
+typedef struct dmvae_prof_row {
+    char name[48];
+    int64_t launches;
+    double total_ms;
+    double flops;   /* algorithmic */
+    double bytes;   /* algorithmic */
+} dmvae_prof_row;
+int dmvae_prof_enable(int on);
+int dmvae_prof_collect(dmvae_prof_row* rows, int max_rows);   /* returns number of rows */
+
+int dmvae_abi_version(void);
+const char* dmvae_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMVAE_HIP_H */

@@ -1,0 +1,195 @@
+"""GPU parity tests, step level: the plan's forward/loss/backward/Adam against
+the float64 oracle on identical parameters, batches and noise.
+
+Tolerances (stated per BASELINE.json's north star):
+  fp32 (parity) mode : per-step loss |delta| <= 1e-3 nats, gradients <= 1e-4
+                       relative (to the tensor's max |g|), parameters after
+                       Adam steps <= 2e-5 absolute.
+  bf16 mode          : loss within 2e-3 relative, gradients within 5e-2 of max|g|.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import dmvae_oracle as O
+
+
+def make(cfg_kw, dtype, B, mode="exact", deterministic=True, seed=0):
+    from dmvae_hip import StepEngine
+    eng = StepEngine(dtype=dtype, max_batch=B, mode=mode, temperature=0.5, deterministic=deterministic, **cfg_kw)
+    eng.init_parameters(seed)
+    return eng
+
+
+def oracle_cfg(kw):
+    return O.Config(kw["input_dim"], kw["latent_dim"], kw["n_classes"], kw.get("enc_layers", (500, 500)),
+                    kw.get("head_dim", 2000), kw.get("dec_layers", (2000, 500, 500)), kw.get("input_type", "binary"))
+
+
+SMALL = dict(input_dim=40, latent_dim=6, n_classes=5, enc_layers=(70, 50), head_dim=90, dec_layers=(90, 50, 30))
+REF = dict(input_dim=784, latent_dim=10, n_classes=10)
+
+
+def test_init_matches_reference_rules_and_oracle_stream():
+    eng = make(REF, "fp32", 100)
+    p = eng.get_parameters()
+    o = O.init_params(oracle_cfg(REF), 0)
+    assert set(p) == set(o)
+    for k in o:
+        np.testing.assert_allclose(p[k], o[k].astype(np.float32), rtol=0, atol=0, err_msg=k)
+    assert eng.param.numel() >= oracle_cfg(REF).n_params()
+
+
+@pytest.mark.parametrize("cfg_kw,B", [(SMALL, 37), (REF, 100)])
+@pytest.mark.parametrize("mode", ["exact", "relaxed"])
+@pytest.mark.parametrize("input_type", ["binary", "real"])
+def test_fp32_step_matches_oracle(cfg_kw, B, mode, input_type):
+    kw = dict(cfg_kw, input_type=input_type)
+    if cfg_kw is REF and (mode == "relaxed" or input_type == "real"):
+        pytest.skip("reference-size case runs once (exact, binary)")
+    eng = make(kw, "fp32", B, mode)
+    cfg = oracle_cfg(kw)
+    rng = np.random.RandomState(1)
+    p = {k: v.astype(np.float64) for k, v in eng.get_parameters().items()}
+    p["prior_log_vars"] = (rng.randn(*p["prior_log_vars"].shape) * 0.3).astype(np.float32).astype(np.float64)
+    for k in p:
+        if k.startswith("b_"):
+            p[k] = (rng.randn(*p[k].shape) * 0.05).astype(np.float32).astype(np.float64)
+    eng.set_parameters(p)
+    X = (rng.rand(B, cfg.input_dim) * (rng.rand(B, cfg.input_dim) < 0.3)).astype(np.float32)
+    eps = rng.randn(B, cfg.latent_dim).astype(np.float32)
+    gum = O.sample_gumbel((B, cfg.n_classes), rng).astype(np.float32)
+    Xd, ed, gd = (torch.as_tensor(a).cuda() for a in (X, eps, gum))
+    eng.write_state(kl_ratio=0.8, lr=0.002)
+    eng.load_batch(Xd, None, 0, B)
+    eng.forward_backward(B, ed, gd if mode == "relaxed" else None)
+    torch.cuda.synchronize()
+    a = O.forward(p, cfg, X.astype(np.float64), eps.astype(np.float64), 0.8, mode, gum.astype(np.float64), 0.5)
+    g = O.backward(p, cfg, a)
+    st = eng.read_state()
+    assert abs(st.last_loss - a["loss"]) <= 1e-3, (st.last_loss, a["loss"])
+    assert abs(st.last_recon - a["recon"]) <= 1e-3
+    assert abs(st.last_klz - a["kl_z"]) <= 1e-4 * max(1.0, abs(a["kl_z"]))
+    assert abs(st.last_klc - a["kl_c"]) <= 1e-5
+    np.testing.assert_allclose(eng.view("mean", B).cpu().numpy(), a["mean"], atol=2e-5)
+    np.testing.assert_allclose(eng.view("logits", B).cpu().numpy(), a["logits"], atol=2e-5)
+    np.testing.assert_allclose(eng.view("weights", B).cpu().numpy(), a["w"], atol=1e-5)
+    gg = eng.get_gradients()
+    for k in g:
+        scale = np.abs(g[k]).max() + 1e-12
+        assert np.abs(gg[k] - g[k]).max() <= 1e-4 * scale, (k, np.abs(gg[k] - g[k]).max(), scale)
+    # pad rows/cols of the arena carry no gradient
+    total = sum(float(np.abs(v).sum()) for v in gg.values())
+    assert abs(eng.grad.abs().sum().item() - total) <= 1e-4 * total
+    # three Adam steps on the same batch
+    m, v = O.adam_tf_init(p)
+    O.adam_tf(p, g, m, v, 1, 0.002)
+    eng.update(1.0)
+    for t in (2, 3):
+        eng.forward_backward(B, ed, gd if mode == "relaxed" else None)
+        eng.update(1.0)
+        a2, _ = O.train_step(p, m, v, t, cfg, X.astype(np.float64), eps.astype(np.float64), 0.8, 0.002, mode,
+                             gum.astype(np.float64), 0.5)
+        torch.cuda.synchronize()
+        assert abs(eng.read_state().last_loss - a2["loss"]) <= 2e-3
+    assert eng.read_state().adam_t == 3
+    pg = eng.get_parameters()
+    for k in p:
+        assert np.abs(pg[k] - p[k]).max() <= 2e-4, (k, np.abs(pg[k] - p[k]).max())
+
+
+@pytest.mark.parametrize("deterministic", [True, False])
+def test_bf16_step_close_to_oracle(deterministic):
+    kw, B = dict(input_dim=784, latent_dim=64, n_classes=10), 512
+    eng = make(kw, "bf16", B, deterministic=deterministic)
+    cfg = oracle_cfg(kw)
+    rng = np.random.RandomState(2)
+    p = {k: v.astype(np.float64) for k, v in eng.get_parameters().items()}
+    X = O.synthetic_images(B, 784, seed=3)
+    eps = rng.randn(B, 64).astype(np.float32)
+    Xd, ed = torch.as_tensor(X).cuda(), torch.as_tensor(eps).cuda()
+    eng.load_batch(Xd, None, 0, B)
+    eng.forward_backward(B, ed)
+    torch.cuda.synchronize()
+    a = O.forward(p, cfg, X.astype(np.float64), eps.astype(np.float64))
+    g = O.backward(p, cfg, a)
+    st = eng.read_state()
+    assert abs(st.last_loss - a["loss"]) <= 2e-3 * abs(a["loss"]), (st.last_loss, a["loss"])
+    gg = eng.get_gradients()
+    for k in g:
+        scale = np.abs(g[k]).max() + 1e-12
+        assert np.abs(gg[k] - g[k]).max() <= 5e-2 * scale, (k, np.abs(gg[k] - g[k]).max(), scale)
+    eng.update(1.0)
+    torch.cuda.synchronize()
+    assert eng.read_state().adam_t == 1
+    if not deterministic:       # split-K atomics accumulate: Adam must have re-zeroed the arena
+        assert not eng.grad.any().item()
+    assert torch.equal(eng.param_bf16, eng.param.to(torch.bfloat16))
+
+
+def test_ragged_batch_and_determinism():
+    """n_valid < max_batch (the short last batch of an epoch, utils.py:462-463):
+    same result as an engine sized exactly; deterministic mode is bit-reproducible."""
+    kw = SMALL
+    rng = np.random.RandomState(5)
+    X = rng.rand(64, 40).astype(np.float32)
+    eps = rng.randn(64, 6).astype(np.float32)
+    res = []
+    for B in (37, 64, 37):
+        eng = make(kw, "fp32", B if len(res) != 1 else 64)
+        eng.load_batch(torch.as_tensor(X).cuda(), None, 0, 37)
+        eng.forward_backward(37, torch.as_tensor(eps[:37]).cuda())
+        torch.cuda.synchronize()
+        res.append((eng.read_state().last_loss, eng.get_gradients()))
+    assert res[0][0] == res[2][0]
+    for k in res[0][1]:
+        np.testing.assert_array_equal(res[0][1][k], res[2][1][k])
+        np.testing.assert_allclose(res[0][1][k], res[1][1][k], rtol=1e-5, atol=1e-7)
+    assert res[0][0] == pytest.approx(res[1][0], rel=1e-6)
+
+
+def test_graph_replay_matches_eager_and_epoch_accounting():
+    """HIP-graph replay of the step == the same steps issued eagerly (device
+    Philox noise and batch cursor come from the device state)."""
+    kw, B, N = dict(input_dim=784, latent_dim=10, n_classes=10), 256, 1024
+    data = torch.as_tensor(O.synthetic_images(N, 784, seed=1)).cuda()
+    perm = torch.randperm(N, device="cuda", dtype=torch.int64).to(torch.int32)
+    out = []
+    for use_graph in (False, True):
+        eng = make(kw, "bf16", B, deterministic=True, seed=4)
+        eng.reset_epoch(N // B, kl_ratio=1.0)
+        if use_graph:
+            replay = eng.capture_step(data, perm)
+            for _ in range(N // B):
+                replay()
+        else:
+            for _ in range(N // B):
+                eng.train_step(data, perm, use_state_cursor=True)
+        torch.cuda.synchronize()
+        st = eng.read_state()
+        out.append((st.epoch_loss, st.adam_t, st.batch_cursor, st.noise_step, eng.param.clone()))
+    assert out[0][1] == out[1][1] == N // B and out[0][2] == out[1][2] == 0
+    assert out[0][3] == out[1][3] == N // B
+    assert out[0][0] == out[1][0]
+    assert torch.equal(out[0][4], out[1][4])
+    assert 100 < out[0][0] < 600          # epoch-mean loss in nats, 784*ln2 = 543 at init
+
+
+def test_encode_decode_views():
+    kw, B = dict(input_dim=784, latent_dim=10, n_classes=10), 100
+    eng = make(kw, "fp32", B)
+    cfg = oracle_cfg(kw)
+    p = {k: v.astype(np.float64) for k, v in eng.get_parameters().items()}
+    X = O.synthetic_images(B, 784, seed=2)
+    eng.load_batch(torch.as_tensor(X).cuda(), None, 0, B)
+    eng.encode(B)
+    a = O.encode(p, cfg, X.astype(np.float64))
+    np.testing.assert_allclose(eng.view("mean", B).cpu().numpy(), a["mean"], atol=2e-5)
+    np.testing.assert_allclose(eng.view("log_var", B).cpu().numpy(), a["logvar"], atol=2e-5)
+    np.testing.assert_allclose(eng.view("logits", B).cpu().numpy(), a["logits"], atol=2e-5)
+    Z = np.random.RandomState(0).randn(B, 10).astype(np.float32)
+    eng.decode(torch.as_tensor(Z).cuda())
+    xl = O.decode(p, cfg, Z.astype(np.float64))["xlogits"]
+    np.testing.assert_allclose(eng.view("recon", B).cpu().numpy(), 1 / (1 + np.exp(-xl)), atol=2e-5)
