@@ -485,6 +485,14 @@ extern "C" int dmvae_plan_view(const dmvae_plan* p, const char* name, void** ptr
     else if (n == "x") { *ptr = base + p->o_xf; *ld = p->Ip; }
     else if (n == "Z") { *ptr = base + (p->cfg.dtype == DMVAE_BF16 ? p->o_Zf : p->o_Z); *ld = p->Dp; }
     else if (n == "dxlogits") { *ptr = base + p->o_dl; *ld = p->Ip; *dtype = p->cfg.dtype; }
+    else if (n == "hzc") { *ptr = base + p->o_hzc; *ld = 2 * p->Hp; *dtype = p->cfg.dtype; }   // [z-hidden | c-hidden], halves Hp apart
+    else if (n.rfind("enc", 0) == 0 && n.size() == 4 && n[3] - '0' < (int)p->enc.size()) {
+        const int i = n[3] - '0';
+        *ptr = base + p->o_enc[i]; *ld = p->enc[i].out_pad; *dtype = p->cfg.dtype;
+    } else if (n.rfind("dec", 0) == 0 && n.size() == 4 && n[3] - '0' < (int)p->dec.size()) {
+        const int i = n[3] - '0';
+        *ptr = base + p->o_dec[i]; *ld = p->dec[i].out_pad; *dtype = p->cfg.dtype;
+    }
     else { set_error("dmvae_plan_view: unknown view '%s'", name); return DMVAE_EINVAL; }
     return 0;
 }

@@ -272,8 +272,22 @@ class StepEngine:
         t = torch.as_strided(flat, (self.batch_pad, ld.value), (ld.value, 1))
         full_cols = {"mean": self.latent_dim, "log_var": self.latent_dim, "logits": self.n_classes,
                      "weights": self.n_classes, "recon": self.input_dim, "x": self.input_dim,
-                     "Z": self.latent_dim, "dxlogits": self.input_dim}[name]
+                     "Z": self.latent_dim, "dxlogits": self.input_dim}.get(name, ld.value)
         return t[: (self.max_batch if rows is None else rows), : (full_cols if cols is None else cols)]
+
+    def hidden_activations(self, rows=None):
+        """{layer name: activation [rows, width]} of the ReLU layers of the last
+        forward pass, under the names the parameters use (enc<i>, zh, ch, dec<i>)."""
+        hp = self.view("hzc", rows).shape[1] // 2
+        out = {}
+        for i, w in enumerate(self.enc_layers):
+            out["enc%d" % i] = self.view("enc%d" % i, rows, w)
+        hzc = self.view("hzc", rows)
+        out["zh"] = hzc[:, : self.head_dim]
+        out["ch"] = hzc[:, hp: hp + self.head_dim]
+        for i, w in enumerate(self.dec_layers):
+            out["dec%d" % i] = self.view("dec%d" % i, rows, w)
+        return out
 
     # ------------------------------------------------------------ whole step, HIP graph
     def train_step(self, data, perm, n_valid=None, eps=None, gumbel=None, first=0, use_state_cursor=False,

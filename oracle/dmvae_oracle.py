@@ -307,9 +307,19 @@ def latent_backward(cfg, a, p, dZ):
     return dmean, dlogvar, dlogits, dpm, dplv
 
 
-def backward(p, cfg, a):
+def backward(p, cfg, a, masks=None):
     """Gradient of a["loss"] w.r.t. every trainable (what optimizer.minimize
-    derives through tf.gradients, base_models.py:110)."""
+    derives through tf.gradients, base_models.py:110).
+
+    masks: optional {layer name: bool array} overriding the ReLU masks
+    (y > 0).  Parity tests pass the masks of the implementation under test:
+    a pre-activation within float32 rounding of zero may land on the other
+    side in float64, and with ~5e5 units per step that happens."""
+    if masks is not None:
+        a = dict(a)
+        for k, mk in masks.items():
+            # only the sign pattern of y is used below
+            a[k] = np.where(mk, np.maximum(a[k], 1e-300), 0.0)
     g = {}
     X = a["x"]
     B = X.shape[0]
