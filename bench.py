@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""DMVAE training-step benchmark on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): images/sec (train), MNIST-shaped K=10 z_dim=64
+batch=4096 per GPU, bf16 MFMA GEMMs, synthetic 28x28 inputs resident in HBM.
+One "step" = batch assembly + forward + loss + backward + (gradient all-reduce)
++ Adam, i.e. one session.run([loss, train_step]) of code/base_models.py:126-129.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus
+  "roofline"     : the dominant kernel family, measured with HIP events around
+                   every launch of a few eager steps (same process, same shapes)
+  "cpu_baseline" : the oracle (CPU restatement of the reference step, float32,
+                   NumPy/OpenBLAS on the box's host cores) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "deep-mixture-vae_amd"))
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0       # HBM3E spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch (cfg2: 4096)")
+    ap.add_argument("--latent_dim", type=int, default=64)
+    ap.add_argument("--n_clusters", type=int, default=10)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--rows", type=int, default=65536, help="synthetic dataset rows resident in HBM")
+    ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--deterministic", action="store_true", help="no float atomics (split-K off)")
+    ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def flops_per_image(I, D, K, enc=(500, 500), head=2000, dec=(2000, 500, 500)):
+    """train FLOP/img = 2*(3M - I*enc0), M = MACs of one forward."""
+    m, prev = 0, I
+    for h in enc:
+        m += prev * h
+        prev = h
+    m += 2 * prev * head + 2 * head * D + head * K
+    prev = D
+    for h in dec:
+        m += prev * h
+        prev = h
+    m += prev * I
+    return 2 * (3 * m - I * enc[0])
+
+
+def cpu_baseline(args, seconds):
+    """The oracle timed on the host cores: float32 NumPy restatement of the same
+    step (reported baseline, not the optimisation target; the TensorFlow-1.x
+    reference itself cannot run in this image)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import dmvae_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([d.get("num_threads", 1) for d in threadpool_info() if d.get("user_api") == "blas"] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    out = {}
+    for B in (args.batch, 100):
+        cfg = O.Config(784, args.latent_dim, args.n_clusters)
+        p = O.init_params(cfg, 0, np.float32)
+        m, v = O.adam_tf_init(p)
+        X = O.synthetic_images(B, 784, seed=1)
+        rng = np.random.RandomState(0)
+        eps = rng.randn(B, args.latent_dim).astype(np.float32)
+        budget = seconds * (0.75 if B == args.batch else 0.25)
+        t, n, t0 = 1, 0, None
+        start = time.perf_counter()
+        while True:
+            O.train_step(p, m, v, t, cfg, X, eps)
+            t += 1
+            if t0 is None:
+                t0 = time.perf_counter()      # first step = warm-up
+                continue
+            n += 1
+            if time.perf_counter() - start > budget or n >= 200:
+                break
+        dt = time.perf_counter() - t0
+        out[B] = (B * n / dt, n)
+    return {"value": round(out[args.batch][0], 1), "unit": "images/sec", "cores": int(cores), "kind": "port",
+            "sample": "oracle/dmvae_oracle.py float32 NumPy step, batch %d, %d timed steps after 1 warm-up" % (args.batch, out[args.batch][1]),
+            "batch100_images_per_sec": round(out[100][0], 1)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    import dmvae_hip
+    from dmvae_hip import StepEngine, GradExchange, prof_enable, prof_collect
+
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    I, D, K, B = 784, args.latent_dim, args.n_clusters, args.batch
+    eng = StepEngine(I, D, K, dtype=args.dtype, max_batch=B, seed=1234 + rank, deterministic=args.deterministic)
+    eng.init_parameters(0)
+    ex = GradExchange()
+    ex.broadcast_(eng.param)
+    eng.refresh_shadow()
+
+    # synthetic MNIST-like rows resident in HBM: x = u * 1[v < 0.19]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(rank)
+    data = torch.rand((args.rows, I), device=dev, generator=gen)
+    data = data * (torch.rand((args.rows, I), device=dev, generator=gen) < 0.19)
+    perm = torch.randperm(args.rows, device=dev, generator=gen).to(torch.int32)
+    bpe = args.rows // B
+    eng.reset_epoch(bpe, kl_ratio=1.0)
+    sync = ex if ex.enabled else None
+
+    if args.no_graph:
+        def step():
+            eng.train_step(data, perm, use_state_cursor=True, grad_sync=sync, grad_scale=ex.grad_scale)
+    else:
+        step = eng.capture_step(data, perm, grad_sync=sync, grad_scale=ex.grad_scale)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    st = eng.read_state()
+
+    # ---- per-kernel HIP-event timing: eager launches of the same step, event pair around each launch
+    rows = []
+    if args.profile_steps > 0:
+        torch.cuda.synchronize()
+        prof_enable(True)
+        for _ in range(args.profile_steps):
+            eng.train_step(data, perm, use_state_cursor=True, grad_sync=None, grad_scale=1.0)
+        torch.cuda.synchronize()
+        rows = prof_collect()
+        prof_enable(False)
+
+    if rank != 0:
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
+
+    ms_step = 1e3 * elapsed / args.steps
+    value = world * B * args.steps / elapsed
+    fpi = flops_per_image(I, D, K)
+    out = {
+        "metric": "images/sec (train), MNIST K=10 z=64 batch=4096/GPU bf16",
+        "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "configs[1]: DMVAE MLP 784-500-500-(2000|2000)-z%d/K%d-2000-500-500-784, one ELBO training step "
+                               "(gather+fwd+loss+bwd+Adam), synthetic 28x28 rows resident in HBM" % (D, K),
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                   "hip_graph": not args.no_graph, "deterministic": bool(args.deterministic)},
+        "step_flops_algorithmic": fpi * B,
+        "step_mfma_frac_of_peak": round(fpi * B / (ms_step * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4),
+        "last_loss": round(float(st.last_loss), 4),
+    }
+    if rows:
+        ps = float(args.profile_steps)
+        table = []
+        for r in rows:
+            ms = r["total_ms"] / ps
+            table.append({"kernel": r["name"], "launches_per_step": r["launches"] / ps, "ms_per_step": round(ms, 4),
+                          "avg_us": round(1e3 * r["total_ms"] / max(1, r["launches"]), 3),
+                          "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 2) if r["total_ms"] > 0 else 0.0,
+                          "gbs": round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1) if r["total_ms"] > 0 else 0.0})
+        dom = max(rows, key=lambda r: r["total_ms"])
+        is_gemm = dom["name"].startswith("gemm")
+        ach = (dom["flops"] if is_gemm else dom["bytes"]) / (dom["total_ms"] * 1e-3) / (1e12 if is_gemm else 1e9)
+        peak = PEAK_BF16_TFLOPS if is_gemm else PEAK_HBM_GBS
+        if is_gemm and args.dtype == "fp32":
+            peak = 157.3
+        out["roofline"] = {"kernel": dom["name"], "bound": "mfma" if is_gemm else "hbm", "achieved": round(ach, 2),
+                           "peak": peak, "unit": "TFLOP/s" if is_gemm else "GB/s", "frac": round(ach / peak, 4),
+                           "traffic": None,
+                           "launches_per_step": dom["launches"] / ps,
+                           "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 3),
+                           "algorithmic_per_launch": (dom["flops"] if is_gemm else dom["bytes"]) / dom["launches"],
+                           "method": "hipEvent pair around every launch, %d eager steps after the timed region" % args.profile_steps}
+        out["kernels"] = table
+        out["kernel_ms_per_step_sum"] = round(sum(t["ms_per_step"] for t in table), 4)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -340,24 +340,21 @@ extern "C" int dmvae_plan_decode(dmvae_plan* p, void* stream, const float* Z, in
     return fwd_dense(p, s, WS(p, p->o_dec[last]), p->dec[last].out_pad, p->dec[last].out_pad, L, p->Ip, 0, kind, WS(p, p->o_recon), p->Ip);
 }
 
-static int dw_split(const dmvae_plan* p, int M, int N) {
-    if (p->cfg.deterministic) return 1;
-    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    int split = 1;
-    while (split < 8 && tiles * split < 256 && p->Bp % (split * 2 * 64) == 0 && p->Bp / (split * 2) >= 256) split *= 2;
-    return split;
-}
+// Split-K of the dW GEMMs: off.  Measured (tools/gemm_sweep.py) fp32-atomic split-K loses on every
+// dW shape of the step except 512x512 (-13 %), so dW is a plain store and the whole step is
+// bit-reproducible; cfg.deterministic is kept in the ABI for a future slab-reduce split-K.
+static int dw_split(const dmvae_plan*, int, int) { return 1; }
 
 // dW = X^T dY into the grad arena, db = colsum(dY)
 static int grad_dense(dmvae_plan* p, hipStream_t s, const void* X, int64_t ldx, int Mdim, const void* dY, int64_t ldy, int N,
                       int64_t w_off, int64_t ldw, int64_t b_off) {
     dmvae_epilogue e;
     memset(&e, 0, sizeof(e));
-    const int split = dw_split(p, Mdim, N);   // 1 in deterministic mode
+    const int split = dw_split(p, Mdim, N);
     e.kind = split > 1 ? DMVAE_EPI_ATOMIC_F32 : DMVAE_EPI_STORE_F32;
     e.out = p->buf.grad + w_off; e.ldo = ldw;
-    TRY(gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_DW, Mdim, N, p->Bp, X, ldx, dY, ldy, &e, split));
-    return colsum_launch(s, p->cfg.dtype, dY, ldy, p->Bp, N, p->buf.grad + b_off, reinterpret_cast<float*>(WS(p, p->o_cs)), p->cs_elems);
+    e.out2 = p->buf.grad + b_off;             // db = column sums of dY, fused (ones-operand MFMA)
+    return gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_DW, Mdim, N, p->Bp, X, ldx, dY, ldy, &e, split);
 }
 
 static int dx_dense(dmvae_plan* p, hipStream_t s, const void* dY, int64_t ldy, int Kdim, int64_t w_off, int64_t ldw, int N,
@@ -466,7 +463,7 @@ extern "C" int dmvae_plan_update(dmvae_plan* p, void* stream, float grad_scale) 
     a.n = p->param_elems; a.p = p->buf.param; a.g = p->buf.grad; a.m = p->buf.m; a.v = p->buf.v;
     a.pb = reinterpret_cast<bf16_t*>(p->cfg.dtype == DMVAE_BF16 ? p->buf.param_bf16 : nullptr);
     a.lr = 0.f; a.b1 = p->cfg.beta1; a.b2 = p->cfg.beta2; a.eps = p->cfg.adam_eps; a.gscale = grad_scale;
-    a.zero_grad = p->cfg.deterministic ? 0 : 1;
+    a.zero_grad = 0;    // every gradient element is overwritten each step (no atomic accumulation)
     a.t_host = 0; a.st = reinterpret_cast<const dmvae_state*>(p->buf.state);
     TRY(adam_launch(s, a));
     return adam_finish_launch(s, p->buf.state);
@@ -521,7 +518,7 @@ extern "C" int dmvae_recon_fwd_bwd(void* stream, int act_dtype, int recon_kind, 
 }
 extern "C" int dmvae_colsum(void* stream, int in_dtype, const void* in, int64_t ld, int M, int N, float* out) {
     DMVAE_REQUIRE(in && out && M > 0 && N > 0, "dmvae_colsum: bad argument");
-    if (M > 512) TRY(colsum_prepare(N));
+    if (M > 64) TRY(colsum_prepare(N));   // two-pass path: lazily sized scratch (not capture-safe; plans bring their own)
     return colsum_launch((hipStream_t)stream, in_dtype, in, ld, M, N, out, nullptr, 0);
 }
 extern "C" int dmvae_loss_finalize(void* stream, const float* rp, int nr, const float* lp, int nl, float inv_B, void* state) {
@@ -602,6 +599,18 @@ extern "C" int dmvae_prof_collect(dmvae_prof_row* rows, int max_rows) {
         rows[n++] = agg[k];
     }
     return n;
+}
+
+extern "C" int dmvae_debug_set_tile(int bm, int bn) {
+    DMVAE_REQUIRE((bm == 0 && bn == 0) || ((bm == 64 || bm == 128) && (bn == 64 || bn == 128)), "dmvae_debug_set_tile: 64 or 128 (0,0 = heuristic)");
+    gemm_bf16_force_tile(bm * 1000 + bn);
+    return 0;
+}
+
+extern "C" int dmvae_debug_set_knob(int which, int value) {
+    DMVAE_REQUIRE(which == 0 || which == 1, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = ring depth of the 128x128 tile");
+    gemm_bf16_set_knob(which, value);
+    return 0;
 }
 
 extern "C" int dmvae_abi_version(void) { return DMVAE_ABI_VERSION; }

@@ -109,15 +109,15 @@ int colsum_launch(hipStream_t s, int in_dtype, const void* in, int64_t ld, int M
     const int strips = (N + 255) / 256;
     const double bytes = (double)M * N * (in_dtype == DMVAE_BF16 ? 2 : 4);
     ProfScope ps(s, "colsum", (double)M * N, bytes);
-    if (M <= 512) {
+    if (M <= 64) {
         if (in_dtype == DMVAE_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(strips, 1), dim3(256), 0, s, (const bf16_t*)in, ld, M, N, M, out, (int64_t)0);
         else hipLaunchKernelGGL(colsum_kernel<float>, dim3(strips, 1), dim3(256), 0, s, (const float*)in, ld, M, N, M, out, (int64_t)0);
         return check_launch("colsum");
     }
     if (!ws) { ws = g_colsum_ws; ws_elems = g_colsum_ws_elems; }
-    int slabs = COLSUM_SLABS;
-    int rps = (M + slabs - 1) / slabs;
-    slabs = (M + rps - 1) / rps;
+    int rps = (M + COLSUM_SLABS - 1) / COLSUM_SLABS;
+    if (rps < 8) rps = 8;
+    const int slabs = (M + rps - 1) / rps;
     if ((int64_t)slabs * N > ws_elems) {
         set_error("dmvae_colsum: scratch too small (%lld < %lld); call through a bound plan or with N <= prepared", (long long)ws_elems, (long long)slabs * N);
         return DMVAE_ESTATE;

@@ -6,80 +6,170 @@
 //   FWD: A [M][K] k-contiguous,  B = W [K][N] n-contiguous
 //   DX : A [M][K] k-contiguous,  B = W [N][K] k-contiguous
 //   DW : A = X [K][M] m-contiguous, B = dY [K][N] n-contiguous (K = batch)
-// Tiles are copied global -> LDS in the orientation they have in memory
-// (16-byte loads along the contiguous dimension).  A k-contiguous operand is
-// read into its MFMA fragment with one ds_read_b128; an m/n-contiguous operand
-// with two ds_read_b64_tr_b16 (gfx950 transposing LDS read), so no transposed
-// copy of weights, activations or gradients ever exists in HBM.
+// so no transposed copy of weights, activations or gradients exists in HBM:
+// a k-contiguous operand is read into its MFMA fragment with one
+// ds_read_b128, an m/n-contiguous operand with two ds_read_b64_tr_b16 (the
+// gfx950 transposing LDS read).
 //
-// Block = 256 threads = 4 waves (2 x 2), BK = 64, register-staged double
-// buffering: the global loads of tile t+1 are in flight while tile t is
-// multiplied, one barrier per K step.
+// Data movement: tiles go global -> LDS directly (global_load_lds_dwordx4,
+// 16 B per lane, no VGPR staging) into an NSTAGE-deep LDS ring; NSTAGE-1 K
+// tiles are in flight while one is multiplied, retired by a COUNTED
+// s_waitcnt vmcnt(N) and one raw s_barrier per K step.  The LDS-DMA is issued
+// from inline asm: through __builtin_amdgcn_global_load_lds hipcc (ROCm 7.2)
+// treats it as a may-alias LDS store and drains the ring with vmcnt(0) before
+// the first ds_read of every K step (measured: ring depth then buys nothing).
+// The ring loop is unrolled NSTAGE times so every ring slot is a compile-time
+// constant: LDS read addresses are (loop-invariant VGPR + immediate), global
+// addresses are (wave-uniform SGPR tile pointer + loop-invariant 32-bit VGPR
+// offset) -- the K loop carries no per-lane address arithmetic.
+//
+// An LDS-DMA write is lane-linear (wave-uniform base + lane*16 B), so tiles
+// cannot be padded; bank conflicts are removed (SQ_LDS_BANK_CONFLICT = 0,
+// profiles/) by an XOR swizzle of the 16-byte chunk index, applied to the
+// per-lane SOURCE address when filling and again when reading:
+//   k-contiguous tile, 128-B rows : chunk ^= (row >> 1) & 7          (ds_read_b128)
+//   n-contiguous tile, 256-B rows : chunk ^= ((k & 3) | ((k >> 3) & 1) << 2) << 1
+//   n-contiguous tile, 128-B rows : chunk ^= (((k >> 1) & 1) | ((k >> 3) & 1) << 1) << 1
+// (the last two keep each transposing read's 8 rows x 32 B of a 32-lane half
+// on distinct bank groups).
+//
+// Block = 256 threads = 4 waves (2 x 2), BK = 64.
 #include "kernels.h"
 
 namespace dmvae {
 
 constexpr int BK = 64;
-constexpr int LDK = BK + 8;     // k-contiguous tile: row stride 144 B
-constexpr int TRPAD = 16;       // m/n-contiguous tile: row stride (C + 16) * 2 B
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-template <int R, bool KC>
-__device__ __forceinline__ void stage_load(const bf16_t* __restrict__ g, int64_t ld, uint4 (&r)[R / 32], int tid) {
-#pragma unroll
-    for (int i = 0; i < R / 32; ++i) {
-        const int c = tid + i * 256;
-        int row, cc;
-        if constexpr (KC) { row = c >> 3; cc = c & 7; }
-        else { row = c / (R / 8); cc = c % (R / 8); }
-        r[i] = *reinterpret_cast<const uint4*>(g + (int64_t)row * ld + cc * 8);
-    }
+// swizzled 16-byte chunk of a k-contiguous tile row (8 chunks per 128-B row)
+__device__ __forceinline__ int swz_kc(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+// swizzled chunk of an n-contiguous tile row k; C = tile columns (128 -> 16 chunks, 64 -> 8 chunks)
+template <int C>
+__device__ __forceinline__ int swz_nc(int k, int chunk) {
+    if constexpr (C == 128) return chunk ^ ((((k & 3) | (((k >> 3) & 1) << 2))) << 1);
+    else return chunk ^ (((((k >> 1) & 1) | (((k >> 3) & 1) << 1))) << 1);
 }
+
+// Per-lane source BYTE offsets (relative to the tile origin) of the R/32 loads of one operand
+// tile; loop invariant, computed once.
+//   KC : tile [R rows][64 k]   : a wave instruction covers 8 rows x 128 B
+//   !KC: tile [64 k][R cols]   : R = 128: 4 k-rows x 256 B;  R = 64: 8 k-rows x 128 B
 template <int R, bool KC>
-__device__ __forceinline__ void stage_store(bf16_t* s, const uint4 (&r)[R / 32], int tid) {
+__device__ __forceinline__ void stage_offsets(int64_t ld, int wave, int lane, unsigned (&off)[R / 32]) {
 #pragma unroll
     for (int i = 0; i < R / 32; ++i) {
-        const int c = tid + i * 256;
-        int row, cc;
-        if constexpr (KC) { row = c >> 3; cc = c & 7; }
-        else { row = c / (R / 8); cc = c % (R / 8); }
-        constexpr int LD = KC ? LDK : (R + TRPAD);
-        *reinterpret_cast<uint4*>(s + row * LD + cc * 8) = r[i];
+        int row, c;
+        if constexpr (KC) {
+            row = i * 32 + wave * 8 + (lane >> 3);
+            c = swz_kc(row, lane & 7);
+        } else if constexpr (R == 128) {
+            row = i * 16 + wave * 4 + (lane >> 4);
+            c = swz_nc<128>(row, lane & 15);
+        } else {
+            row = i * 32 + wave * 8 + (lane >> 3);
+            c = swz_nc<64>(row, lane & 7);
+        }
+        off[i] = 2u * (unsigned)(row * (int)ld + c * 8);
     }
 }
 
-// fragment for index i0 + (lane & 15), k = ks*32 + 8*(lane >> 4) .. +7
+// LDS-DMA of one operand tile: NL wave instructions of 64 lanes x 16 B each,
+//   LDS[lds + 4096*i + lane*16 ..) <- *(tile + off[i])          (i < NL)
+// tile = wave-uniform pointer (SGPR pair), off = per-lane 32-bit byte offsets, lds = wave-uniform
+// LDS byte address of this wave's first chunk (consecutive chunks of a wave are 4 KiB apart for
+// every tile shape).  M0 (the DMA's LDS base) is compiler-reserved: saved/restored in the statement.
+__device__ __forceinline__ void glds_tile(const void* tile, const unsigned (&off)[2], unsigned lds) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+        "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(tile), "v"(off[0]), "v"(off[1]), "s"(lds), "s"(lds + 4096u)
+        : "memory");
+}
+__device__ __forceinline__ void glds_tile(const void* tile, const unsigned (&off)[4], unsigned lds) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+        "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+        "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+        "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(tile), "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(lds), "s"(lds + 4096u), "s"(lds + 8192u), "s"(lds + 12288u)
+        : "memory");
+}
+
+// LDS element offsets of the fragment for index i0 + (lane & 15), k = ks*32 + 8*(lane >> 4) .. +7
+// inside its operand tile (loop invariant): {lo, hi}; a k-contiguous operand needs one
+// ds_read_b128 (lo only), an n-contiguous one two transposing reads.
 template <int R, bool KC>
-__device__ __forceinline__ bf16x8 read_frag(const bf16_t* s, int i0, int ks, int lane) {
+__device__ __forceinline__ void frag_offsets(int i0, int ks, int lane, unsigned short& lo, unsigned short& hi) {
     const int li = lane & 15, g = lane >> 4;
     if constexpr (KC) {
-        const s16x8 v = *reinterpret_cast<const s16x8*>(s + (i0 + li) * LDK + ks * 32 + g * 8);
+        const int row = i0 + li;
+        lo = (unsigned short)(row * 64 + swz_kc(row, ks * 4 + g) * 8);
+        hi = 0;
+    } else {
+        const int q = li >> 2, p = li & 3;
+        const int k0 = ks * 32 + g * 8 + q, k1 = k0 + 4;
+        const int c = (i0 >> 3) + (p >> 1);
+        lo = (unsigned short)(k0 * R + swz_nc<R>(k0, c) * 8 + (p & 1) * 4);
+        hi = (unsigned short)(k1 * R + swz_nc<R>(k1, c) * 8 + (p & 1) * 4);
+    }
+}
+template <bool KC>
+__device__ __forceinline__ bf16x8 read_frag(const bf16_t* s, unsigned lo, unsigned hi) {
+    if constexpr (KC) {
+        const s16x8 v = *reinterpret_cast<const s16x8*>(s + lo);
         return __builtin_bit_cast(bf16x8, v);
     } else {
-        constexpr int LD = R + TRPAD;
-        const int q = li >> 2, p = li & 3;
-        const bf16_t* a0 = s + (ks * 32 + g * 8 + q) * LD + i0 + p * 4;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * LD));
-        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        const s16x4 l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(s + lo));
+        const s16x4 h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(s + hi));
+        const s16x8 v = __builtin_shufflevector(l, h, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(bf16x8, v);
     }
 }
 
-template <int BM, int BN, int LAYOUT, int EPI>
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     constexpr bool A_KC = (LAYOUT != DMVAE_GEMM_DW);
     constexpr bool B_KC = (LAYOUT == DMVAE_GEMM_DX);
-    constexpr int A_ELEMS = A_KC ? BM * LDK : BK * (BM + TRPAD);
-    constexpr int B_ELEMS = B_KC ? BN * LDK : BK * (BN + TRPAD);
-    constexpr int TM = BM / 32, TN = BN / 32;   // 16x16 tiles per wave (wave tile = BM/2 x BN/2)
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (A_ELEMS + B_ELEMS)];
+    constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
+    constexpr int TM = BM / 32, TN = BN / 32;       // 16x16 tiles per wave (wave tile = BM/2 x BN/2)
+    constexpr int LOADS = BM / 32 + BN / 32;        // LDS-DMA instructions per lane per K tile
+    static_assert(NSTAGE >= 2 && NSTAGE <= 8 && LOADS * (NSTAGE - 2) <= 63, "ring depth / vmcnt range");
+    __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * STAGE];   // the ONLY LDS object
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = a.N / BN;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    // XCD-aware tile order (speed only, never correctness): workgroups are dealt round-robin
+    // over the 8 XCDs, so ids b and b+8 share an L2.  Give each XCD a CONTIGUOUS run of tile
+    // ids (bijective for any grid size) ...
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    // ... and walk the tiles of a run in supertiles of group_m tile-rows (column-major inside a
+    // supertile): the ~32 tiles an XCD works on at one time then form a group_m x (32/group_m)
+    // block, i.e. few A and few B panels, each reused from L2 by several workgroups.
+    int tm, tn;
+    {
+        const int tiles_m = a.M / BM, gm_max = a.group_m;
+        const int gsz = gm_max * tiles_n, grp = bid / gsz, first = grp * gm_max;
+        const int gm = min(tiles_m - first, gm_max), in = bid - grp * gsz;
+        tm = first + in % gm;
+        tn = in / gm;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = blockIdx.y * a.k_split;
     const int nk = a.k_split / BK;
@@ -96,44 +186,82 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // DW layout: the bias gradient db[n] = sum_k dY[k][n] rides along as one extra MFMA per B
+    // fragment against an all-ones A operand (exact: products with 1.0, fp32 accumulate), in
+    // the workgroups of the first tile row only -- no separate column-sum pass over dY.
+    constexpr bool DW = (LAYOUT == DMVAE_GEMM_DW);
+    const bool do_bias = DW && a.epi.out2 != nullptr && tm == 0;
+    f32x4 bacc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const s16x8 ones_bits = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_bits);
 
-    uint4 ra[BM / 32], rb[BN / 32];
-    stage_load<BM, A_KC>(Ag, a.lda, ra, tid);
-    stage_load<BN, B_KC>(Bg, a.ldb, rb, tid);
-    stage_store<BM, A_KC>(smem, ra, tid);
-    stage_store<BN, B_KC>(smem + A_ELEMS, rb, tid);
-    __syncthreads();
+    // loop-invariant per-lane addressing: global source byte offsets and LDS fragment offsets
+    unsigned goA[BM / 32], goB[BN / 32];
+    stage_offsets<BM, A_KC>(a.lda, wave, lane, goA);
+    stage_offsets<BN, B_KC>(a.ldb, wave, lane, goB);
+    unsigned short foA[BK / 32][TM][2], foB[BK / 32][TN][2];
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) frag_offsets<BM, A_KC>(wm * (BM / 2) + i * 16, ks, lane, foA[ks][i][0], foA[ks][i][1]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) frag_offsets<BN, B_KC>(wn * (BN / 2) + j * 16, ks, lane, foB[ks][j][0], foB[ks][j][1]);
+    }
+    // LDS byte address of this wave's first DMA chunk in ring slot 0 (wave-uniform)
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)((__attribute__((address_space(3))) bf16_t*)smem) + 1024u * (unsigned)wave);
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const bf16_t* As = smem + (kt & 1) * (A_ELEMS + B_ELEMS);
+    // issue the loads of K tile t (clamped to the last tile: keeps the vmcnt arithmetic uniform;
+    // a clamped tile lands in a ring slot nobody reads) into ring slot `slot`
+    auto issue = [&](int t, int slot) {
+        const int tc = t < nk ? t : nk - 1;
+        const unsigned s = lds_w + 2u * (unsigned)(slot * STAGE);
+        glds_tile(Ag + tc * stepA, goA, s);
+        glds_tile(Bg + tc * stepB, goB, s + 2u * A_ELEMS);
+    };
+    auto compute = [&](int slot) {
+        const bf16_t* As = smem + slot * STAGE;
         const bf16_t* Bs = As + A_ELEMS;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            Ag += stepA; Bg += stepB;
-            stage_load<BM, A_KC>(Ag, a.lda, ra, tid);
-            stage_load<BN, B_KC>(Bg, a.ldb, rb, tid);
-        }
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8 af[TM], bfr[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = read_frag<BM, A_KC>(As, wm * (BM / 2) + i * 16, ks, lane);
+            for (int i = 0; i < TM; ++i) af[i] = read_frag<A_KC>(As, foA[ks][i][0], foA[ks][i][1]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j] = read_frag<BN, B_KC>(Bs, wn * (BN / 2) + j * 16, ks, lane);
+            for (int j = 0; j < TN; ++j) bfr[j] = read_frag<B_KC>(Bs, foB[ks][j][0], foB[ks][j][1]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     // operands swapped: D[row = n][col = m] -> each lane owns 4 consecutive n of one m
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            if constexpr (DW) {
+                if (do_bias) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], ones, bacc[j], 0, 0, 0);
+                }
+            }
         }
-        if (more) {
-            bf16_t* nxt = smem + ((kt + 1) & 1) * (A_ELEMS + B_ELEMS);
-            stage_store<BM, A_KC>(nxt, ra, tid);
-            stage_store<BN, B_KC>(nxt + A_ELEMS, rb, tid);
+    };
+
+#pragma unroll
+    for (int t = 0; t < NSTAGE - 1; ++t) issue(t, t);          // prologue: NSTAGE-1 tiles in flight
+
+    for (int kt = 0; kt < nk; kt += NSTAGE) {
+#pragma unroll
+        for (int s = 0; s < NSTAGE; ++s) {                      // ring slot s is a compile-time constant here
+            if (kt + s < nk) {
+                wait_vmcnt<LOADS*(NSTAGE - 2)>();               // tile kt+s has landed (this wave's share)
+                __builtin_amdgcn_s_barrier();                   // ... every wave's share; all waves are done with the slot refilled next
+                issue(kt + s + NSTAGE - 1, (s + NSTAGE - 1) % NSTAGE);   // refill the slot read in the previous step
+                compute(s);
+            }
         }
-        __syncthreads();
     }
+    wait_vmcnt<0>();                                            // drain the clamped tail loads before LDS is reused / the wave ends
+    __builtin_amdgcn_s_barrier();
 
     float loss = 0.f;
     const int li = lane & 15, g = lane >> 4;
@@ -146,30 +274,78 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             epilogue_quad<EPI, bf16_t>(a.epi, m, n, v, loss);
         }
+    if constexpr (DW) {
+        if (do_bias && wm == 0 && li == 0) {      // D[row = n][col = any m]: column 0 of the wm == 0 waves writes
+            float* db = reinterpret_cast<float*>(a.epi.out2);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + g * 4;
+                if constexpr (EPI == DMVAE_EPI_ATOMIC_F32) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(db + n + e, bacc[j][e]);
+                } else {
+                    *reinterpret_cast<float4*>(db + n) = make_float4(bacc[j][0], bacc[j][1], bacc[j][2], bacc[j][3]);
+                }
+            }
+        }
+    }
     if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
-        float* red = reinterpret_cast<float*>(smem);   // all waves are past the last barrier of the K loop
+        float* red = reinterpret_cast<float*>(smem);
         const float t = block_sum_256(loss, red);
         if (tid == 0) a.epi.partials[blockIdx.x] = t;
     }
 }
 
 // ---------------------------------------------------------------- host side
-template <int BM, int BN, int LAYOUT, int EPI>
+template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE>
 static int launch(hipStream_t s, const GemmArgs& a, int split) {
     dim3 grid((a.M / BM) * (a.N / BN), split);
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, LAYOUT, EPI>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, LAYOUT, EPI, NSTAGE>), grid, dim3(256), 0, s, a);
     return check_launch("gemm_bf16");
 }
 
+static int g_force_tile = 0;   // debug override (dmvae_debug_set_tile): BM*1000+BN, 0 = heuristic
+void gemm_bf16_force_tile(int t) { g_force_tile = t; }
+static int g_group_m = 8;                   // tuning knob (dmvae_debug_set_knob 0): supertile rows
+void gemm_bf16_set_knob(int which, int v) {
+    if (which == 0) g_group_m = v < 1 ? 1 : v;
+}
+
+// Tile choice, BM*1000+BN.  These GEMMs run at the per-CU L2->LDS streaming rate, so the figure
+// of merit is (flops per byte loaded) x (fraction of the 256 CUs that get a workgroup):
+//   intensity ~ BM*BN/(BM+BN):  128x128 64, 128x64 / 64x128 42.7, 64x64 32.
+// M, N are multiples of 64.
+int gemm_bf16_tile_m(int M, int N, int split) {
+    if (g_force_tile) {
+        const int bm = g_force_tile / 1000, bn = g_force_tile % 1000;
+        if (M % bm == 0 && N % bn == 0) return g_force_tile;
+    }
+    static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    double best = -1.0;
+    int pick = 64 * 1000 + 64;
+    for (auto& c : cand) {
+        if (M % c[0] || N % c[1]) continue;
+        const double wgs = (double)(M / c[0]) * (N / c[1]) * split;
+        const double score = (double)c[0] * c[1] / (c[0] + c[1]) * (wgs >= 256.0 ? 1.0 : wgs / 256.0);
+        if (score > best * 1.0001) { best = score; pick = c[0] * 1000 + c[1]; }
+    }
+    return pick;
+}
+
+// Ring depth (measured, tools/gemm_sweep.py): two workgroups per CU with a shallow ring each
+// beat one workgroup with a deep ring on every shape of the step (the K loop is issue-bound at
+// one wave per SIMD; a second resident workgroup fills the gaps):
+//   128x128: 2 x 32 KiB, 128x64 / 64x128: 3 x 24 KiB, 64x64: 4 x 16 KiB  (<= 72 KiB -> 2 blocks/CU)
 template <int LAYOUT, int EPI>
-static int launch_tiled(hipStream_t s, const GemmArgs& a, int split) {
-    // Largest tile that still yields >= ~1.5 workgroups per CU; M, N multiples of 64 guaranteed.
-    const bool m128 = a.M % 128 == 0, n128 = a.N % 128 == 0;
-    auto wgs = [&](int bm, int bn) { return (long)(a.M / bm) * (a.N / bn) * split; };
-    if (m128 && n128 && wgs(128, 128) >= 384) return launch<128, 128, LAYOUT, EPI>(s, a, split);
-    if (m128 && wgs(128, 64) >= 384) return launch<128, 64, LAYOUT, EPI>(s, a, split);
-    if (n128 && wgs(64, 128) >= 384) return launch<64, 128, LAYOUT, EPI>(s, a, split);
-    return launch<64, 64, LAYOUT, EPI>(s, a, split);
+static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split) {
+    GemmArgs a = a0;
+    a.group_m = g_group_m;
+    switch (gemm_bf16_tile_m(a.M, a.N, split)) {
+        case 128128: return launch<128, 128, LAYOUT, EPI, 2>(s, a, split);
+        case 128064: return launch<128, 64, LAYOUT, EPI, 3>(s, a, split);
+        case 64128: return launch<64, 128, LAYOUT, EPI, 3>(s, a, split);
+        default: return launch<64, 64, LAYOUT, EPI, 4>(s, a, split);
+    }
 }
 
 int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split) {
@@ -189,15 +365,6 @@ int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split) 
 #undef CASE
     set_error("dmvae_gemm(bf16): layout %d with epilogue %d is not instantiated", layout, epi);
     return DMVAE_EUNSUPPORTED;
-}
-
-int gemm_bf16_tile_m(int M, int N, int split) {   // BM the dispatcher will pick (for partial counts)
-    const bool m128 = M % 128 == 0, n128 = N % 128 == 0;
-    auto wgs = [&](int bm, int bn) { return (long)(M / bm) * (N / bn) * split; };
-    if (m128 && n128 && wgs(128, 128) >= 384) return 128 * 1000 + 128;
-    if (m128 && wgs(128, 64) >= 384) return 128 * 1000 + 64;
-    if (n128 && wgs(64, 128) >= 384) return 64 * 1000 + 128;
-    return 64 * 1000 + 64;
 }
 
 }  // namespace dmvae

@@ -15,6 +15,7 @@ struct GemmArgs {
     const void* A; int64_t lda;
     const void* B; int64_t ldb;
     int M, N, K, k_split;   // k_split: contraction depth handled by one blockIdx.y
+    int group_m;            // supertile height (tile rows) of the L2-friendly tile order
     dmvae_epilogue epi;
 };
 

@@ -62,21 +62,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    constexpr bool DW = (LAYOUT == DMVAE_GEMM_DW);
+    const bool do_bias = DW && a.epi.out2 != nullptr && m0 == 0;   // bias gradient db[n] = sum_k dY[k][n], see gemm_bf16.hip
+    f32x4 bacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     float4 ra = f32_stage_load<A_KC>(Ag, a.lda, tid);
     float4 rb = f32_stage_load<B_KC>(Bg, a.ldb, tid);
     f32_stage_store<A_KC>(smem, ra, tid);
     f32_stage_store<B_KC>(smem + T, rb, tid);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const float* As = smem + (kt & 1) * 2 * T;
+    auto compute = [&](int buf) {
+        const float* As = smem + buf * 2 * T;
         const float* Bs = As + T;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            Ag += stepA; Bg += stepB;
-            ra = f32_stage_load<A_KC>(Ag, a.lda, tid);
-            rb = f32_stage_load<B_KC>(Bg, a.ldb, tid);
-        }
 #pragma unroll
         for (int ks = 0; ks < FBK / 4; ++ks) {
             float av[2], bv[2];
@@ -89,14 +86,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], av[i], acc[i][j], 0, 0, 0);
+            if constexpr (DW) {
+                if (do_bias) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], 1.0f, bacc[j], 0, 0, 0);
+                }
+            }
         }
-        if (more) {
-            float* nxt = smem + ((kt + 1) & 1) * 2 * T;
-            f32_stage_store<A_KC>(nxt, ra, tid);
-            f32_stage_store<B_KC>(nxt + T, rb, tid);
-        }
+    };
+    for (int kt = 0; kt < nk - 1; ++kt) {   // branch-free steady state, last step peeled
+        Ag += stepA; Bg += stepB;
+        ra = f32_stage_load<A_KC>(Ag, a.lda, tid);
+        rb = f32_stage_load<B_KC>(Bg, a.ldb, tid);
+        compute(kt & 1);
+        float* nxt = smem + ((kt + 1) & 1) * 2 * T;
+        f32_stage_store<A_KC>(nxt, ra, tid);
+        f32_stage_store<B_KC>(nxt + T, rb, tid);
         __syncthreads();
     }
+    compute((nk - 1) & 1);
+    __syncthreads();
 
     float loss = 0.f;
 #pragma unroll
@@ -108,6 +117,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             epilogue_quad<EPI, float>(a.epi, m, n, v, loss);
         }
+    if constexpr (DW) {
+        if (do_bias && wm == 0 && li == 0) {
+            float* db = reinterpret_cast<float*>(a.epi.out2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 32 + j * 16 + g * 4;
+                if constexpr (EPI == DMVAE_EPI_ATOMIC_F32) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(db + n + e, bacc[j][e]);
+                } else {
+                    *reinterpret_cast<float4*>(db + n) = make_float4(bacc[j][0], bacc[j][1], bacc[j][2], bacc[j][3]);
+                }
+            }
+        }
+    }
     if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
         const float t = block_sum_256(loss, smem);
         if (tid == 0) a.epi.partials[blockIdx.x] = t;

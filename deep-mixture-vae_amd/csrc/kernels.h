@@ -15,6 +15,8 @@ struct AdamArgs {
 
 int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split);
 int gemm_bf16_tile_m(int M, int N, int split);
+void gemm_bf16_force_tile(int t);
+void gemm_bf16_set_knob(int which, int v);
 int gemm_f32_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split);
 int latent_nblocks(int B_pad, int D, int K);
 int latent_launch(hipStream_t s, const dmvae_latent_args* a);

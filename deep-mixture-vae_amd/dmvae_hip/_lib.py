@@ -6,6 +6,12 @@ time -- there is no CPU fallback of any kind.
 import ctypes as C
 import os
 
+# torch must load its HIP runtime FIRST: libdmvae_hip.so then binds to that same
+# libamdhip64 instance (streams and device pointers are shared with torch).  Loading
+# the library before torch pulls in a second runtime and every launch fails with
+# "no ROCm-capable device is detected".
+import torch  # noqa: F401  (import order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdmvae_hip.so")
 
@@ -23,7 +29,7 @@ EXPORTS = [
     "dmvae_plan_create", "dmvae_plan_destroy", "dmvae_plan_sizes", "dmvae_plan_tensor",
     "dmvae_plan_bind", "dmvae_plan_load_batch", "dmvae_plan_forward_backward",
     "dmvae_plan_update", "dmvae_plan_encode", "dmvae_plan_decode", "dmvae_plan_view",
-    "dmvae_prof_enable", "dmvae_prof_collect", "dmvae_abi_version", "dmvae_last_error",
+    "dmvae_prof_enable", "dmvae_prof_collect", "dmvae_debug_set_tile", "dmvae_debug_set_knob", "dmvae_abi_version", "dmvae_last_error",
 ]
 
 
@@ -142,6 +148,8 @@ def _load():
         "dmvae_plan_view": [vp, C.c_char_p, P(vp), P(i64), P(C.c_int32)],
         "dmvae_prof_enable": [i32],
         "dmvae_prof_collect": [P(ProfRow), i32],
+        "dmvae_debug_set_tile": [i32, i32],
+        "dmvae_debug_set_knob": [i32, i32],
         "dmvae_abi_version": [],
         "dmvae_last_error": [],
     }

@@ -314,11 +314,27 @@ class StepEngine:
         self.grad.zero_()
         self.refresh_shadow()
         torch.cuda.synchronize(self.device)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side):
-            self.train_step(data, perm, None, None, None, 0, True, grad_sync, grad_scale, inv_B)
-        self._graph = g
-        return g.replay
+        if grad_sync is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                self.train_step(data, perm, None, None, None, 0, True, None, grad_scale, inv_B)
+            self._graph = (g,)
+            return g.replay
+        # data parallel: two graphs with the collective issued eagerly between them on the
+        # same stream (keeps RCCL out of stream capture)
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga, stream=side):
+            self.load_batch(data, perm, 0, None, True)
+            self.forward_backward(None, None, None, inv_B)
+        with torch.cuda.graph(gb, stream=side):
+            self.update(grad_scale)
+        self._graph = (ga, gb)
+
+        def replay():
+            ga.replay()
+            grad_sync(self.grad)
+            gb.replay()
+        return replay
 
 
 def prof_enable(on=True):

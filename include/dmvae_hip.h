@@ -72,7 +72,9 @@ typedef struct dmvae_epilogue {
     float scale;         /* RECON: 1/B                                               */
     void* out;           /* primary output                                           */
     int64_t ldo;
-    void* out2;          /* RECON: optional f32 copy of the logits (may be NULL)     */
+    void* out2;          /* RECON: optional f32 copy of the logits (may be NULL).
+                          * DW layout: optional f32 bias gradient db[N] = sum_k B[k][n]
+                          * (ones-operand MFMA in the first tile row; may be NULL)    */
     int64_t ldo2;
     const float* bias;   /* [N] or NULL                                              */
     const void* aux0;    /* RELU_MASK: forward activation (act); RECON: x (f32); LATENT: gmu (f32) */
@@ -270,6 +272,12 @@ typedef struct dmvae_prof_row {
 } dmvae_prof_row;
 int dmvae_prof_enable(int on);
 int dmvae_prof_collect(dmvae_prof_row* rows, int max_rows);   /* returns number of rows */
+
+/* tuning aid: force the bf16 GEMM tile (64|128 x 64|128); (0,0) restores the heuristic */
+int dmvae_debug_set_tile(int bm, int bn);
+/* tuning aid: knob 0 = supertile height (tile rows) of the L2-friendly tile order,
+ *             knob 1 = LDS ring depth (2|3) of the 128x128 tile */
+int dmvae_debug_set_knob(int which, int value);
 
 int dmvae_abi_version(void);
 const char* dmvae_last_error(void);

@@ -109,6 +109,26 @@ def test_gemm_split_k_atomic(hip, dtype):
     np.testing.assert_array_equal(out.cpu().numpy().astype(np.float64), A @ B)
 
 
+@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("shape", [(64, 64, 128), (512, 832, 1024), (2048, 128, 256), (128, 192, 4096)])
+def test_gemm_dw_fused_bias_gradient(hip, dtype, shape):
+    """DW layout with epi.out2: db[n] = sum_k dY[k][n] from the ones-operand MFMA (exact on integers)."""
+    L = hip
+    M, N, K = shape
+    rng = np.random.RandomState(M + N + K)
+    A, B, Am, Bm = operands(2, M, N, K, rng, True)
+    tdt = torch.bfloat16 if dtype == 1 else torch.float32
+    Ad, Bd = dev(Am, tdt), dev(Bm, tdt)
+    out = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    db = torch.full((N,), 5.0, dtype=torch.float32, device="cuda")
+    e = L.Epilogue()
+    e.kind = L.EPI_STORE_F32
+    e.out, e.ldo, e.out2 = L.ptr(out).value, N, L.ptr(db).value
+    gemm(L, dtype, 2, M, N, K, Ad, M, Bd, N, e)
+    np.testing.assert_array_equal(out.cpu().numpy().astype(np.float64), A @ B)
+    np.testing.assert_array_equal(db.cpu().numpy().astype(np.float64), B.sum(0))
+
+
 def _act(dtype):
     return torch.bfloat16 if dtype == 1 else torch.float32
 

@@ -135,8 +135,6 @@ def test_bf16_step_close_to_oracle(deterministic):
     eng.update(1.0)
     torch.cuda.synchronize()
     assert eng.read_state().adam_t == 1
-    if not deterministic:       # split-K atomics accumulate: Adam must have re-zeroed the arena
-        assert not eng.grad.any().item()
     assert torch.equal(eng.param_bf16, eng.param.to(torch.bfloat16))
 
 
