@@ -1,0 +1,311 @@
+"""VAE / DeepMixtureVAE -- drop-in for the class surface of code/base_models.py
+(:14-147 VAE, :150-432 DeepMixtureVAE) with the per-batch path executed by the
+MI355X HIP library (dmvae_hip) instead of a TensorFlow session.
+
+Same constructor arguments, method names, argument order and return types:
+    DeepMixtureVAE(name, input_type, input_dim, latent_dim, n_classes,
+                   activation=None, initializer=None, cnn=False).build_graph()
+    .define_train_step(init_lr, decay_steps, decay_rate=0.9)
+    .train_op(session, data, kl_ratio=1.0) -> float      (epoch-mean loss)
+    .get_accuracy(session, data) -> float
+    .sample_reparametrization_variables(n, variables=None) -> dict
+    .sample_generative_feed(n, **kwargs) -> dict
+`session` is a dmvae_hip.Session (device / stream / rank) or None.  What were
+graph tensors to fetch (mean, log_var, logits, cluster_probs, Z, decoded_X,
+reconstructed_X) are methods evaluating on demand: encode(X), decode(Z),
+reconstruct(X, epsilon=None).  Extensions are keyword-only and default to the
+reference's behaviour: batch_size (reference hard-codes 100, train.py:215-216),
+dtype ("bf16" throughput / "fp32" parity), enc_layers / head_dim / dec_layers
+(reference literals 500,500 / 2000 / 2000,500,500), gumbel + temperature
+(Gumbel-Softmax relaxed KL; default off = the live graph),
+noise ("device" Philox | "host" NumPy stream of the reference), seed.
+"""
+import math
+
+import numpy as np
+
+import priors
+from includes.network import DeepNetwork
+from includes.utils import get_clustering_accuracy
+
+
+class VAE:
+    def __init__(self, name, input_type, input_dim, latent_dim, activation=None, initializer=None):
+        self.name = name
+        self.input_dim = input_dim
+        self.latent_dim = latent_dim
+        self.input_type = input_type
+        self.activation = activation
+        self.initializer = initializer
+        self.path = ""
+        self.kl_ratio = 1.0          # placeholder_with_default(1.0), base_models.py:28-30
+        self.is_training = True      # placeholder_with_default(True), :32-34 (no BN on the path: unused)
+        self.X = None
+        self.decoded_X = None
+        self.train_step = None
+        self.latent_variables = dict()
+
+    def build_graph(self, encoder_layer_sizes, decoder_layer_sizes):
+        raise NotImplementedError
+
+    def sample_reparametrization_variables(self, n, variables=None):
+        """base_models.py:44-56: {epsilon placeholder name: host noise}; draws in
+        the dict order of latent_variables (C then Z) from the global NumPy RNG."""
+        samples = dict()
+        if variables is None:
+            for lv, eps, _ in self.latent_variables.values():
+                if eps is not None:
+                    samples[eps] = lv.sample_reparametrization_variable(n)
+        else:
+            for var in variables:
+                lv, eps, _ = self.latent_variables[var]
+                if eps is not None:
+                    samples[eps] = lv.sample_reparametrization_variable(n)
+        return samples
+
+    def sample_generative_feed(self, n, **kwargs):
+        samples = dict()
+        for name, (lv, _, _) in self.latent_variables.items():
+            kwargs_ = dict() if name not in kwargs else kwargs[name]
+            samples[name] = lv.sample_generative_feed(n, **kwargs_)
+        return samples
+
+    # the three loss definitions exist as graph-building steps in the reference
+    # (:66-93); here the loss is computed inside the fused step, nothing to build
+    def define_latent_loss(self):
+        self.latent_loss = "KL_C + KL_Z (dmvae_latent_fwd)"
+
+    def define_recon_loss(self):
+        if self.input_type not in ("binary", "real"):
+            raise NotImplementedError
+        self.recon_loss = "reconstruction loss (DMVAE_EPI_BIAS_RECON)"
+
+    def define_train_loss(self):
+        self.define_latent_loss()
+        self.define_recon_loss()
+        self.loss = "recon + kl_ratio * latent"
+
+    def define_train_step(self, init_lr, decay_steps, decay_rate=0.9):
+        """base_models.py:95-110.  exponential_decay is called with a literal
+        global_step=0, so the learning rate is the constant init_lr;
+        decay_steps / decay_rate are accepted and, as in the reference, inert."""
+        self.define_train_loss()
+        self._lr = float(init_lr)
+        self._engine.write_state(lr=self._lr)
+        self.train_step = "adam_tf"
+
+    def debug(self, session, data):
+        import pdb
+        for batch in data.get_batches():
+            feed = {"X": batch}
+            feed.update(self.sample_reparametrization_variables(len(batch)))
+            pdb.set_trace()
+            break
+
+
+class DeepMixtureVAE(VAE):
+    def __init__(self, name, input_type, input_dim, latent_dim, n_classes, activation=None, initializer=None,
+                 cnn=False, *, batch_size=100, dtype="bf16", enc_layers=(500, 500), head_dim=2000,
+                 dec_layers=(2000, 500, 500), gumbel=False, temperature=1.0, noise="device", seed=0,
+                 deterministic=True, session=None):
+        VAE.__init__(self, name, input_type, input_dim, latent_dim, activation=activation, initializer=initializer)
+        self.n_classes = n_classes
+        # The checked-in reference forces cnn = True (base_models.py:156); the path this build
+        # accelerates is the MLP branch (:218-226) named by BASELINE.json.
+        self.cnn = bool(cnn)
+        if self.cnn:
+            raise NotImplementedError("cnn=True: the convolutional trunk is a 'next' row (SURVEY.md 8f); use cnn=False")
+        if activation not in (None, "relu") and getattr(activation, "__name__", "") != "relu":
+            raise NotImplementedError("activation must be ReLU (train.py:196 passes tf.nn.relu)")
+        if noise not in ("device", "host"):
+            raise ValueError("noise must be 'device' or 'host'")
+        self.batch_size = int(batch_size)
+        self.dtype = dtype
+        self.enc_layers, self.head_dim, self.dec_layers = tuple(enc_layers), int(head_dim), tuple(dec_layers)
+        self.gumbel, self.temperature = bool(gumbel), float(temperature)
+        self.noise, self.seed, self.deterministic = noise, int(seed), bool(deterministic)
+        self._session = session
+        self._engine = None
+        self._replay = None
+        self._perm = None
+
+    # ------------------------------------------------------------------ graph
+    def build_graph(self):
+        from dmvae_hip import StepEngine, default_session
+        sess = self._session or default_session()
+        self._session = sess
+        # decoder spec exactly as the reference writes it (base_models.py:280-288)
+        prev, spec = self.latent_dim, []
+        for w in self.dec_layers:
+            spec.append(("fc", {"input_dim": prev, "output_dim": w}))
+            prev = w
+        self.decoder_network = DeepNetwork("layers", spec, activation="relu", initializer="xavier")
+        assert self.decoder_network.widths() == self.dec_layers
+        self._engine = StepEngine(self.input_dim, self.latent_dim, self.n_classes, enc_layers=self.enc_layers,
+                                  head_dim=self.head_dim, dec_layers=self.dec_layers, input_type=self.input_type,
+                                  dtype=self.dtype, max_batch=self.batch_size, mode="relaxed" if self.gumbel else "exact",
+                                  temperature=self.temperature, seed=self.seed + 7919 * sess.rank,
+                                  deterministic=self.deterministic, session=sess)
+        self._engine.init_parameters(self.seed)
+        # names of the graph's placeholders / tensors (fetch through the methods below)
+        self.X, self.epsilon, self.cluster = "X", "epsilon_Z", "epsilon_C"
+        self.mean, self.log_var, self.logits = "mean", "log_var", "logits"
+        self.cluster_probs, self.Z = "cluster_probs", "Z"
+        self.decoded_X, self.reconstructed_X = "decoded_X", "reconstructed_X"
+        self.latent_variables = dict()
+        self.latent_variables.update({
+            "C": (priors.DiscreteFactorial("cluster", 1, self.n_classes), self.cluster, {"logits": self.logits}),
+            "Z": (priors.NormalMixtureFactorial("representation", self.latent_dim, self.n_classes, engine=self._engine),
+                  self.epsilon,
+                  {"mean": self.mean, "log_var": self.log_var, "weights": self.cluster_probs,
+                   "cluster_sample": self.gumbel}),
+        })
+        return self
+
+    @property
+    def engine(self):
+        return self._engine
+
+    # ------------------------------------------------------------------ training
+    def _epoch_perm(self, data, sess):
+        """the epoch's row order -> this rank's slice of every global batch, on the device"""
+        import torch
+        from dmvae_hip import shard_range
+        order = data.reshuffle()
+        B = data.batch_size
+        if sess.world_size > 1:
+            lo, hi = shard_range(B, sess.rank, sess.world_size)
+            n_full = len(order) // B
+            mine = [order[i * B + lo: i * B + hi] for i in range(n_full)]
+            tail = order[n_full * B:]
+            tlo, thi = shard_range(len(tail), sess.rank, sess.world_size)
+            mine.append(tail[tlo:thi])
+            order = np.concatenate(mine)
+        t = torch.as_tensor(np.ascontiguousarray(order, dtype=np.int32))
+        if self._perm is None or self._perm.numel() != t.numel():
+            self._perm = torch.empty(t.numel(), dtype=torch.int32, device=sess.device)
+            self._replay = None          # the captured graph holds the old pointer
+        self._perm.copy_(t)
+        return self._perm
+
+    def train_op(self, session, data, kl_ratio=1.0):
+        """One epoch, base_models.py:112-132: for every batch of data.get_batches()
+        run [loss, train_step]; return sum(batch_loss) / epoch_len.  The loss is
+        accumulated on the device and read back once per epoch."""
+        assert(self.train_step is not None)
+        import torch
+        from dmvae_hip import GradExchange
+        sess = session or self._session
+        eng = self._engine
+        world = sess.world_size
+        gb = data.batch_size                                  # global batch
+        if gb % world:
+            raise ValueError("batch_size %d is not divisible by the world size %d" % (gb, world))
+        b = gb // world                                       # per-rank batch
+        if b != eng.max_batch:
+            raise ValueError("per-rank batch %d != the size the model was built for (%d)" % (b, eng.max_batch))
+        rows = data.device_rows(sess.device)
+        perm = self._epoch_perm(data, sess)
+        n_local = perm.numel()
+        n_full, tail = n_local // b, n_local % b
+        if world > 1:
+            tail = 0       # data parallel: the ragged last batch is dropped (shards would be unequal)
+        ex = GradExchange()
+        sync = ex if ex.enabled else None
+        eng.reset_epoch(n_full + (1 if tail else 0), kl_ratio=kl_ratio, epoch_weight=1.0 / data.epoch_len)
+        host_noise = self.noise == "host"
+        if host_noise and world > 1:
+            raise NotImplementedError("noise='host' replays the reference's single-process NumPy stream; use noise='device' with more than one rank")
+
+        def host_feed(n):
+            feed = self.sample_reparametrization_variables(n)        # C (gumbel) first, then Z: reference order
+            eps = torch.as_tensor(np.ascontiguousarray(feed[self.epsilon], dtype=np.float32)).to(sess.device)
+            g = None
+            if self.gumbel:
+                g = torch.as_tensor(np.ascontiguousarray(feed[self.cluster].reshape(n, self.n_classes), dtype=np.float32)).to(sess.device)
+            return eps, g
+
+        if host_noise:
+            for i in range(n_full):
+                eps, g = host_feed(b)
+                eng.train_step(rows, perm, b, eps, g, first=i * b, grad_sync=sync, grad_scale=ex.grad_scale)
+        else:
+            if self._replay is None and n_full > 0:
+                self._replay = eng.capture_step(rows, perm, grad_sync=sync, grad_scale=ex.grad_scale)
+                eng.reset_epoch(n_full + (1 if tail else 0), kl_ratio=kl_ratio, epoch_weight=1.0 / data.epoch_len)
+            for _ in range(n_full):
+                self._replay()
+        if tail:                                             # the short last batch (utils.py:462-463), issued eagerly
+            eps, g = host_feed(tail) if host_noise else (None, None)
+            inv_B = 1.0 / tail
+            eng.train_step(rows, perm, tail, eps, g, first=n_full * b, grad_sync=sync, grad_scale=ex.grad_scale, inv_B=inv_B)
+        torch.cuda.synchronize(sess.device)
+        loss = float(eng.read_state().epoch_loss)
+        if world > 1:
+            loss = ex.mean_scalars([loss])[0]
+        return loss
+
+    # ------------------------------------------------------------------ inference pieces
+    def _batches(self, X):
+        import torch
+        X = np.ascontiguousarray(np.asarray(X, dtype=np.float32))
+        dev = self._session.device
+        b = self._engine.max_batch
+        for s in range(0, len(X), b):
+            yield s, torch.as_tensor(X[s:s + b]).to(dev)
+
+    def encode(self, X):
+        """(mean, log_var, logits) of q(z|x), q(c|x): base_models.py:229-248."""
+        eng = self._engine
+        out = [[], [], []]
+        for _, xb in self._batches(X):
+            n = xb.shape[0]
+            eng.load_batch(xb, None, 0, n)
+            eng.encode(n)
+            for k, name in enumerate(("mean", "log_var", "logits")):
+                out[k].append(eng.view(name, n).cpu().numpy().copy())
+        return tuple(np.concatenate(o, axis=0) for o in out)
+
+    def decode(self, Z):
+        """reconstructed_X for given Z (what visualization.py:83-87 fetches by feeding model.Z)."""
+        import torch
+        eng = self._engine
+        Z = np.ascontiguousarray(np.asarray(Z, dtype=np.float32))
+        out = []
+        for s in range(0, len(Z), eng.max_batch):
+            zb = torch.as_tensor(Z[s:s + eng.max_batch]).to(self._session.device)
+            eng.decode(zb)
+            out.append(eng.view("recon", zb.shape[0]).cpu().numpy().copy())
+        return np.concatenate(out, axis=0)
+
+    def reconstruct(self, X, epsilon=None):
+        """reconstructed_X with the given noise (zeros by default, as
+        visualization.py:39-46 feeds): Z = mean + exp(log_var/2) * epsilon."""
+        mean, log_var, _ = self.encode(X)
+        Z = mean if epsilon is None else mean + np.exp(log_var / 2) * np.asarray(epsilon)
+        return self.decode(Z)
+
+    def get_accuracy(self, session, data):
+        """base_models.py:425-432: logits of every batch -> clustering accuracy."""
+        order = data.reshuffle()               # the reference iterates data.get_batches(), which reshuffles
+        _, _, logits = self.encode(data._rows[order])
+        return get_clustering_accuracy(logits, data._cls[order])
+
+    # ------------------------------------------------------------------ pretraining (next row)
+    def define_pretrain_step(self, vae_lr, prior_lr):
+        raise NotImplementedError("pretraining stages (base_models.py:304-423) are a 'next' row of SURVEY.md 8f")
+
+    def pretrain(self, session, data, n_epochs_vae, n_epochs_gmm):
+        raise NotImplementedError("pretraining stages (base_models.py:304-423) are a 'next' row of SURVEY.md 8f")
+
+    # ------------------------------------------------------------------ checkpoint (trainables only, like tf.train.Saver)
+    def state_dict(self):
+        return {k: v for k, v in self._engine.get_parameters().items()}
+
+    def load_state_dict(self, sd):
+        self._engine.set_parameters(sd)
+
+
+class VaDE(VAE):
+    def __init__(self, *a, **k):
+        raise NotImplementedError("VaDE (base_models.py:435-670) is a different model, outside the DMVAE hot path (SURVEY.md 2.1)")

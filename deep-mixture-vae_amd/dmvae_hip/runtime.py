@@ -337,6 +337,58 @@ class StepEngine:
         return replay
 
 
+def latent_eval(mean, log_var, logits, prior_means, prior_log_vars, eps=None, gumbel=None, mode="exact",
+                temperature=1.0, kl_ratio=1.0, session=None):
+    """Evaluate the latent-variable math of code/priors.py on the GPU through
+    dmvae_latent_fwd: returns dict(Z, weights, kl_z, kl_c).  Arrays are
+    numpy / array-like [B, D] / [B, K] / [K, D]."""
+    sess = session or default_session()
+    dev = sess.device
+    f = lambda a: torch.as_tensor(np.ascontiguousarray(np.asarray(a, dtype=np.float32))).to(dev)
+    mean = np.asarray(mean, dtype=np.float32)
+    logits = np.asarray(logits, dtype=np.float32)
+    B, D = mean.shape
+    K = logits.shape[1]
+    Bp = (B + 63) // 64 * 64
+    ldD, ldK = (D + 63) // 64 * 64, (K + 63) // 64 * 64
+
+    def padded(a, ld):
+        t = torch.zeros((Bp, ld), dtype=torch.float32, device=dev)
+        a = f(a)
+        t[: a.shape[0], : a.shape[1]] = a
+        return t
+    md, lvd, lgd = padded(mean, ldD), padded(log_var, ldD), padded(logits, ldK)
+    epsd = f(eps) if eps is not None else torch.zeros((B, D), dtype=torch.float32, device=dev)
+    gd = f(np.asarray(gumbel).reshape(B, K)) if gumbel is not None else torch.zeros((B, K), dtype=torch.float32, device=dev)
+    pmd, plvd = f(prior_means), f(prior_log_vars)
+    Z = torch.zeros((Bp, ldD), dtype=torch.float32, device=dev)
+    w = torch.zeros((Bp, K), dtype=torch.float32, device=dev)
+    gmu, glv, clv = (torch.zeros((Bp, ldD), dtype=torch.float32, device=dev) for _ in range(3))
+    dlg = torch.zeros((Bp, ldK), dtype=torch.float32, device=dev)
+    nblk = lib.dmvae_latent_nblocks(Bp, D, K)
+    dpri = torch.zeros((nblk, 2 * K * D), dtype=torch.float32, device=dev)
+    lp = torch.zeros((nblk, 2), dtype=torch.float32, device=dev)
+    a = _lib.LatentArgs()
+    a.B, a.B_pad, a.D, a.K = B, Bp, D, K
+    a.mode, a.act_dtype = {"exact": 0, "relaxed": 1}[mode], _lib.F32
+    a.kl_ratio, a.temperature, a.inv_B = float(kl_ratio), float(temperature), 1.0 / B
+    a.mean, a.ld_mean = md.data_ptr(), ldD
+    a.log_var, a.ld_log_var = lvd.data_ptr(), ldD
+    a.logits, a.ld_logits = lgd.data_ptr(), ldK
+    a.eps, a.ld_eps = epsd.data_ptr(), D
+    a.gumbel, a.ld_gumbel = gd.data_ptr(), K
+    a.prior_means, a.prior_log_vars = pmd.data_ptr(), plvd.data_ptr()
+    a.Z_act, a.ld_Z = Z.data_ptr(), ldD
+    a.weights, a.ld_w = w.data_ptr(), K
+    a.gmu, a.glv, a.clv, a.ld_g = gmu.data_ptr(), glv.data_ptr(), clv.data_ptr(), ldD
+    a.dlogits_act, a.ld_dl = dlg.data_ptr(), ldK
+    a.dprior_partials, a.loss_partials = dpri.data_ptr(), lp.data_ptr()
+    check(lib.dmvae_latent_fwd(C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), C.byref(a)), "dmvae_latent_fwd")
+    torch.cuda.synchronize(dev)
+    return dict(Z=Z[:B, :D].cpu().numpy(), weights=w[:B].cpu().numpy(),
+                kl_z=float(lp[:, 0].double().sum().item() / B), kl_c=float(lp[:, 1].double().sum().item() / B))
+
+
 def prof_enable(on=True):
     check(lib.dmvae_prof_enable(1 if on else 0), "dmvae_prof_enable")
 

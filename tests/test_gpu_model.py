@@ -1,0 +1,154 @@
+"""GPU parity tests through the drop-in class surface (base_models.DeepMixtureVAE,
+priors.*, train.main) -- the tests a maintainer of the reference would write
+against code/base_models.py if it had a test suite."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import dmvae_oracle as O
+
+SMALL = dict(enc_layers=(70, 50), head_dim=90, dec_layers=(90, 50, 30))
+
+
+def build(input_dim=40, latent_dim=6, n_classes=5, **kw):
+    import base_models
+    args = dict(SMALL, batch_size=16, dtype="fp32", noise="host", seed=3)
+    args.update(kw)
+    m = base_models.DeepMixtureVAE("dmvae", "binary", input_dim, latent_dim, n_classes, activation="relu",
+                                   initializer="xavier", **args).build_graph()
+    m.define_train_step(0.002, 1000, 0.9)
+    return m
+
+
+def test_train_op_epoch_matches_reference_semantics_with_host_noise():
+    """One epoch of VAE.train_op (base_models.py:112-132) with the reference's NumPy
+    noise stream: identical shuffles, identical epsilon, short last batch, loss =
+    sum(batch_loss)/epoch_len -- against the oracle's train_epoch on the same stream."""
+    from includes.utils import Dataset
+    rng = np.random.RandomState(0)
+    N = 16 * 3 + 5
+    X = (rng.rand(N, 40) * (rng.rand(N, 40) < 0.4)).astype(np.float32)
+    cls = rng.randint(0, 5, N)
+    m = build()
+    cfg = O.Config(40, 6, 5, SMALL["enc_layers"], SMALL["head_dim"], SMALL["dec_layers"])
+    p = {k: v.astype(np.float64) for k, v in m.engine.get_parameters().items()}
+    mo, vo = O.adam_tf_init(p)
+    np.random.seed(42)
+    data = Dataset((X, cls), batch_size=16)
+    losses = [m.train_op(None, data, 1.0) for _ in range(2)]
+    # oracle on the same global-RNG stream
+    np.random.seed(42)
+    odata = O.Dataset((X.astype(np.float64), cls), batch_size=16)
+
+    def noise(n):
+        O.sample_gumbel((n, 1, 5))                 # C is drawn first (and unused), base_models.py:122-124
+        return np.random.randn(n, 6).astype(np.float32).astype(np.float64)
+    t = 0
+    for ep in range(2):
+        lo, t = O.train_epoch(p, mo, vo, t, cfg, odata, noise, 1.0, 0.002)
+        assert losses[ep] == pytest.approx(lo, abs=2e-3), (ep, losses[ep], lo)
+    assert m.engine.read_state().adam_t == 8
+    pg = m.engine.get_parameters()
+    for k in p:
+        assert np.percentile(np.abs(pg[k] - p[k]), 99) <= 5e-4, k
+
+
+def test_train_op_device_noise_graph_path_and_relaxed_mode():
+    from includes.utils import Dataset
+    X = O.synthetic_images(256 * 3 + 50, 784, seed=2)
+    cls = np.zeros(len(X), np.int64)
+    for gumbel in (False, True):
+        import base_models
+        m = base_models.DeepMixtureVAE("dmvae", "binary", 784, 10, 10, batch_size=256, dtype="bf16", noise="device",
+                                       gumbel=gumbel, temperature=0.7, seed=1).build_graph()
+        m.define_train_step(0.002, 1000)
+        np.random.seed(1)
+        data = Dataset((X, cls), batch_size=256)
+        l0 = m.train_op(None, data, 1.0)
+        l1 = m.train_op(None, data, 1.0)
+        l2 = m.train_op(None, data, 0.5)
+        assert np.isfinite([l0, l1, l2]).all() and l1 < l0 and 50 < l1 < 560
+        assert m.engine.read_state().adam_t == 12
+
+
+def test_encode_decode_reconstruct_and_accuracy():
+    from includes.utils import Dataset
+    m = build(784, 10, 10, batch_size=64, enc_layers=(500, 500), head_dim=2000, dec_layers=(2000, 500, 500))
+    cfg = O.Config(784, 10, 10)
+    p = {k: v.astype(np.float64) for k, v in m.engine.get_parameters().items()}
+    X = O.synthetic_images(150, 784, seed=5)             # 2 full batches + a short one
+    mean, log_var, logits = m.encode(X)
+    a = O.encode(p, cfg, X.astype(np.float64))
+    np.testing.assert_allclose(mean, a["mean"], atol=3e-5)
+    np.testing.assert_allclose(log_var, a["logvar"], atol=3e-5)
+    np.testing.assert_allclose(logits, a["logits"], atol=3e-5)
+    rec = m.reconstruct(X)                                # epsilon = 0 -> Z = mean (visualization.py:39-46)
+    xl = O.decode(p, cfg, a["mean"])["xlogits"]
+    np.testing.assert_allclose(rec, 1 / (1 + np.exp(-xl)), atol=3e-5)
+    Z = np.random.RandomState(1).randn(70, 10)
+    np.testing.assert_allclose(m.decode(Z), 1 / (1 + np.exp(-O.decode(p, cfg, Z.astype(np.float32).astype(np.float64))["xlogits"])), atol=3e-5)
+    cls = np.random.RandomState(2).randint(0, 10, 150)
+    np.random.seed(0)
+    acc = m.get_accuracy(None, Dataset((X, cls), batch_size=64))
+    assert acc == pytest.approx(O.clustering_accuracy(a["logits"], cls), abs=1e-12)
+    feed = m.sample_generative_feed(12, Z={"session": None, "c": np.arange(12) % 10})
+    assert feed["Z"].shape == (12, 10) and feed["C"].shape == (12, 1, 10) and (feed["C"].sum(-1) == 1).all()
+    eps = m.sample_reparametrization_variables(9)
+    assert list(eps) == ["epsilon_C", "epsilon_Z"] and eps["epsilon_C"].shape == (9, 1, 10) and eps["epsilon_Z"].shape == (9, 10)
+
+
+def test_latent_variable_classes_against_reference_golden_vectors(golden):
+    import priors
+    for ci in range(int(golden["n_cases"])):
+        pre = "c%d_s1_" % ci
+        g = lambda k: golden[pre + k]
+        B, D, K = (int(v) for v in g("shape"))
+        mix = priors.NormalMixtureFactorial("representation", D, K)
+        mix.means, mix.log_vars = g("prior_means"), g("prior_log_vars")
+        disc = priors.DiscreteFactorial("cluster", 1, K)
+        Z = mix.inverse_reparametrize(g("eps"), {"mean": g("mean"), "log_var": g("log_var")})
+        np.testing.assert_allclose(Z, g("Z"), rtol=3e-6, atol=3e-6)
+        klz = mix.kl_from_prior({"mean": g("mean"), "log_var": g("log_var"), "weights": g("w"), "cluster_sample": False})
+        assert klz == pytest.approx(float(g("kl_z_exact")), rel=5e-5)
+        assert disc.kl_from_prior({"logits": g("logits")}) == pytest.approx(float(g("kl_c")), rel=5e-5, abs=1e-6)
+        assert disc.kl_from_prior({"probs": g("w")}) == pytest.approx(float(g("kl_c")), rel=5e-5, abs=1e-6)
+        for ti, tau in enumerate((1.0, 0.5)):
+            zeta = disc.inverse_reparametrize(g("gumbel"), {"logits": g("logits"), "temperature": tau})
+            assert zeta.shape == (B, 1, K)
+            np.testing.assert_allclose(zeta, g("zeta_t%d" % ti), rtol=3e-5, atol=1e-7)
+            klr = mix.kl_from_prior({"mean": g("mean"), "log_var": g("log_var"), "weights": g("zeta_t%d" % ti), "cluster_sample": True})
+            assert klr == pytest.approx(float(g("kl_z_relaxed_t%d" % ti)), rel=1e-4)
+        nf = priors.NormalFactorial("n", D)
+        assert nf.kl_from_prior({"mean": g("mean"), "log_var": g("log_var")}) == pytest.approx(float(g("kl_normal")), rel=5e-5)
+
+
+def test_unsupported_surfaces_fail_loudly():
+    import base_models
+    with pytest.raises(NotImplementedError):
+        base_models.DeepMixtureVAE("m", "binary", 784, 10, 10, cnn=True)
+    with pytest.raises(NotImplementedError):
+        base_models.VaDE("v", "binary", 784, 10, 10)
+    m = build()
+    with pytest.raises(NotImplementedError):
+        m.define_pretrain_step(1e-3, 1e-3)
+
+
+def test_train_cli_one_epoch(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("DMVAE_DATA", str(tmp_path / "nodata"))
+    import importlib
+    import includes.utils as U
+    real = U.load_data
+    monkeypatch.setattr(U, "load_data", lambda name, **kw: real(name, n_train=900, n_test=300, **kw))
+    sys.argv = ["train.py"]
+    train = importlib.import_module("train")
+    args = train.parser.parse_args(["--n_epochs", "2", "--batch_size", "256", "--latent_dim", "10", "--seed", "1"])
+    loss = train.main(args)
+    assert np.isfinite(loss) and 50 < loss < 560
+    assert os.path.exists(tmp_path / "saved-models" / "mnist" / "dmvae" / "model" / "parameters.ckpt")
+    assert "Max Accuracy" in open(tmp_path / "dmvae_logs.txt").read()

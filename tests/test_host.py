@@ -1,0 +1,218 @@
+"""CPU tests (-m "not gpu"): the C-ABI library loads and exports every symbol the
+header declares, host-side logic of the drop-in (samplers, Dataset, CLI flags,
+sharding) against the reference's golden vectors, and the data-parallel
+exchange on a world_size-2 gloo group.  No GPU compute is called here."""
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from dmvae_hip import _lib
+    hdr = open(os.path.join(ROOT, "include", "dmvae_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(dmvae_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    for name in sorted(declared):
+        assert hasattr(_lib.lib, name), "libdmvae_hip.so does not export %s" % name
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert _lib.lib.dmvae_abi_version() == 1
+
+
+def test_ctypes_structs_match_header_layout():
+    import ctypes as C
+    from dmvae_hip import _lib
+    # sizes computed from the C declarations (natural alignment, LP64)
+    assert C.sizeof(_lib.State) == 8 + 8 + 4 + 4 + 4 * 4 + 4 * 4 + 4 * 4
+    assert C.sizeof(_lib.Epilogue) == 24 + 12 * 8
+    assert C.sizeof(_lib.Buffers) == 7 * 8
+    assert C.sizeof(_lib.TensorInfo) == 32 + 8 + 4 + 4 + 8
+    assert C.sizeof(_lib.ProfRow) == 48 + 8 + 8 + 8 + 8
+    assert C.sizeof(_lib.Config) == 4 * 3 + 4 + 32 + 4 + 4 + 32 + 4 * 4 + 4 * 4 + 8 + 4 + 4
+
+
+def test_plan_layout_without_gpu():
+    """plan creation is host-only: arena layout, padding and the tensor table."""
+    import ctypes as C
+    from dmvae_hip import _lib
+    cfg = _lib.Config()
+    cfg.input_dim, cfg.latent_dim, cfg.n_classes = 784, 64, 10
+    cfg.n_enc, cfg.head_dim, cfg.n_dec = 2, 2000, 3
+    cfg.enc[0] = cfg.enc[1] = 500
+    cfg.dec[0], cfg.dec[1], cfg.dec[2] = 2000, 500, 500
+    cfg.dtype, cfg.max_batch = _lib.BF16, 4096
+    cfg.beta1, cfg.beta2, cfg.adam_eps = 0.9, 0.999, 1e-8
+    h = C.c_void_p()
+    _lib.check(_lib.lib.dmvae_plan_create(C.byref(cfg), C.byref(h)))
+    sz = _lib.Sizes()
+    _lib.check(_lib.lib.dmvae_plan_sizes(h, C.byref(sz)))
+    assert sz.batch_pad == 4096 and sz.input_pad == 832 and sz.n_tensors == 24
+    names = {}
+    for i in range(sz.n_tensors):
+        ti = _lib.TensorInfo()
+        _lib.check(_lib.lib.dmvae_plan_tensor(h, i, C.byref(ti)))
+        names[ti.name.decode()] = (ti.offset, ti.rows, ti.cols, ti.ld)
+    assert names["W_enc0"][1:] == (784, 500, 512) and names["W_zh"][3] == names["W_ch"][3] == 4096
+    assert names["W_ch"][0] - names["W_zh"][0] == 2048 and names["W_logvar"][0] - names["W_mean"][0] == 64
+    assert names["prior_log_vars"][0] - names["prior_means"][0] == 640
+    logical = sum(r * c for (_, r, c, _) in names.values())
+    assert logical == 4697868 - 0 or abs(logical - 4.698e6) < 2e3      # P = 4.698 M (cfg2)
+    assert sz.param_elems % 4 == 0 and sz.param_elems < 1.08 * logical   # padding overhead < 8 %
+    bad = _lib.Config()
+    assert _lib.lib.dmvae_plan_create(C.byref(bad), C.byref(h)) == -1
+    _lib.lib.dmvae_plan_destroy(h)
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from dmvae_hip import StepEngine
+    with pytest.raises(RuntimeError, match="no CPU execution path"):
+        StepEngine(784, 10, 10)
+    src = ""
+    for d, _, fs in os.walk(os.path.join(ROOT, "deep-mixture-vae_amd")):
+        for f in fs:
+            if f.endswith(".py"):
+                src += open(os.path.join(d, f)).read()
+    assert "dmvae_oracle" not in src and "import oracle" not in src      # the product never touches oracle/
+
+
+def test_host_samplers_follow_reference_stream(golden):
+    import priors
+    for ci in range(int(golden["n_cases"])):
+        pre = "c%d_s0_" % ci
+        B, D, K = golden[pre + "shape"]
+        np.random.seed(int(golden[pre + "np_seed"]))
+        g = priors.DiscreteFactorial("cluster", 1, int(K)).sample_reparametrization_variable(int(B))
+        mix = priors.NormalMixtureFactorial("representation", int(D), int(K))     # draws its table init first in TF too;
+        np.random.seed(int(golden[pre + "np_seed"]))                               # re-seed: compare the samplers only
+        g = priors.DiscreteFactorial("cluster", 1, int(K)).sample_reparametrization_variable(int(B))
+        eps = mix.sample_reparametrization_variable(int(B))
+        np.testing.assert_array_equal(g, golden[pre + "gumbel"])
+        np.testing.assert_array_equal(eps, golden[pre + "eps"])
+    from includes.utils import sample_gumbel
+    np.random.seed(5)
+    np.testing.assert_array_equal(sample_gumbel((7, 1, 4)), golden["gumbel_seed5"])
+
+
+def test_dataset_matches_reference_epoch_semantics(golden):
+    from includes.utils import Dataset, get_clustering_accuracy
+    N, Bsz = 23, 5
+    data = np.arange(N, dtype=np.float64)[:, None] * np.ones((1, 3))
+    classes = np.arange(N) % 4
+    np.random.seed(11)
+    ds = Dataset((data, classes), batch_size=Bsz)
+    assert ds.epoch_len == int(golden["ds_epoch_len"])
+    for ep in range(2):
+        batches = list(ds.get_batches())
+        order = np.concatenate([b[:, 0] for b in batches]).astype(np.int64)
+        np.testing.assert_array_equal(order, golden["ds_order_ep%d" % ep])
+        np.testing.assert_array_equal(ds.data[:, 0].astype(np.int64), golden["ds_order_ep%d" % ep])
+        np.testing.assert_array_equal(ds.classes, classes[order])
+        assert [len(b) for b in batches] == list(golden["ds_batch_sizes"])
+    assert get_clustering_accuracy(golden["acc_weights"], golden["acc_classes"]) == pytest.approx(float(golden["acc_value"]), abs=1e-15)
+
+
+def test_cli_keeps_every_reference_flag():
+    sys.argv = ["train.py"]
+    import importlib
+    train = importlib.import_module("train")
+    ref_flags = ["model", "model_name", "dataset", "latent_dim", "output_dim", "n_clusters", "n_experts", "classification",
+                 "n_epochs", "pretrain_epochs_vae", "pretrain_epochs_prior", "init_lr", "decay_rate", "decay_epochs",
+                 "pretrain", "pretrain_vae_lr", "pretrain_decay_rate", "pretrain_decay_epochs", "pretrain_prior_lr",
+                 "kl_annealing", "anneal_step", "anneal_epochs", "plotting", "plot_epochs", "save_epochs", "debug",
+                 "visdom", "featLearn"]
+    a = train.parser.parse_args([])
+    for f in ref_flags:
+        assert hasattr(a, f), f
+    # reference defaults (code/train.py:28-97)
+    assert (a.model, a.dataset, a.latent_dim, a.n_clusters, a.n_epochs, a.init_lr) == ("dmvae", "mnist", 10, -1, 500, 0.002)
+    assert (a.decay_rate, a.decay_epochs, a.anneal_step, a.anneal_epochs, a.save_epochs) == (0.9, 25, 0.1, 1000, 10)
+    assert a.batch_size == 100 and not a.gumbel and not a.host_noise
+
+
+def test_load_data_synthetic_standin_shapes():
+    from includes.utils import load_data
+    ds = load_data("mnist", n_train=300, n_test=100)
+    assert ds.input_dim == 784 and ds.input_type == "binary" and ds.n_classes == 10
+    assert ds.train_data.shape == (300, 784) and ds.test_data.shape == (100, 784)
+    assert 0.0 <= ds.train_data.min() and ds.train_data.max() < 1.0
+    with pytest.raises(NotImplementedError):
+        load_data("reuters")
+
+
+def test_shard_range_partitions():
+    from dmvae_hip import shard_range
+    for n in (0, 1, 7, 100, 4096, 65000):
+        for world in (1, 2, 3, 8):
+            cuts = [shard_range(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    for p in (os.path.join(ROOT, "deep-mixture-vae_amd"), os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dmvae_oracle as O
+    from dmvae_hip import GradExchange, shard_range
+    cfg = O.Config(32, 4, 3, (12, 10), 14, (14, 10, 9))
+    p = O.init_params(cfg, 5)
+    rng = np.random.RandomState(5)
+    X, eps = rng.rand(8, 32), rng.randn(8, 4)
+    lo, hi = shard_range(8, rank, world)
+    g = O.backward(p, cfg, O.forward(p, cfg, X[lo:hi], eps[lo:hi]))        # this rank's shard, local mean
+    names = O.param_names(cfg)
+    flat = torch.cat([torch.as_tensor(g[k]).reshape(-1) for k in names])     # the flat gradient arena
+    ex = GradExchange()
+    assert ex.enabled and ex.world == world and ex.grad_scale == 1.0 / world
+    ex(flat)                                                                 # ONE all-reduce(SUM) per step
+    flat = flat * ex.grad_scale                                              # folded into the Adam kernel on the GPU
+    full = O.backward(p, cfg, O.forward(p, cfg, X, eps))
+    ref = torch.cat([torch.as_tensor(full[k]).reshape(-1) for k in names])
+    err = (flat - ref).abs().max().item()
+    par = torch.arange(10, dtype=torch.float32) * (rank + 1)
+    ex.broadcast_(par, src=0)
+    m = ex.mean_scalars([float(rank), 2.0])
+    out.put((rank, err, par.tolist() == list(range(10)), m))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_exchange_world2_gloo():
+    """N ranks x B/N == 1 rank x B: the all-reduce + 1/world scale
+    reproduces the full-batch gradient of the oracle on a 2-rank gloo group."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, bc_ok, m in res:
+        assert err < 1e-12, (rank, err)
+        assert bc_ok
+        assert m == pytest.approx([0.5, 2.0])
