@@ -63,7 +63,7 @@ static const char* gemm_name(int dtype, int layout) {
 }
 
 static int gemm_checked(hipStream_t s, int dtype, int layout, int M, int N, int K, const void* A, int64_t lda,
-                        const void* B, int64_t ldb, const dmvae_epilogue* epi, int split) {
+                        const void* B, int64_t ldb, const dmvae_epilogue* epi, int split, GemmArgs* deferred = nullptr) {
     DMVAE_REQUIRE(dtype == DMVAE_F32 || dtype == DMVAE_BF16, "dmvae_gemm: bad dtype %d", dtype);
     DMVAE_REQUIRE(layout >= 0 && layout <= 2, "dmvae_gemm: bad layout %d", layout);
     DMVAE_REQUIRE(A && B && epi && epi->out, "dmvae_gemm: null pointer");
@@ -76,13 +76,15 @@ static int gemm_checked(hipStream_t s, int dtype, int layout, int M, int N, int 
                   "dmvae_gemm: operands must be 16-byte aligned with 16-byte multiple row strides");
     GemmArgs a;
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb;
-    a.M = M; a.N = N; a.K = K; a.k_split = K / split;
+    a.M = M; a.N = N; a.K = K; a.k_split = K / split; a.group_m = 8;
     a.epi = *epi;
     if (a.epi.m_valid <= 0) a.epi.m_valid = M;
     if (a.epi.n_valid <= 0) a.epi.n_valid = N;
-    const double bytes = (double)esz * ((double)M * K + (double)K * N) + (double)M * N * (epi->kind == DMVAE_EPI_STORE_F32 || epi->kind == DMVAE_EPI_ATOMIC_F32 || epi->kind == DMVAE_EPI_BIAS_F32 ? 4 : esz);
+    if (deferred) { *deferred = a; return 0; }      // caller batches it into a grouped launch
+    if (dtype == DMVAE_BF16) return gemm_bf16_dispatch(s, layout, a, split);   // (profiled per template instantiation inside)
+    const double bytes = 4.0 * ((double)M * K + (double)K * N + (double)M * N);
     ProfScope ps(s, gemm_name(dtype, layout), 2.0 * M * N * (double)K, bytes);
-    return dtype == DMVAE_BF16 ? gemm_bf16_dispatch(s, layout, a, split) : gemm_f32_dispatch(s, layout, a, split);
+    return gemm_f32_dispatch(s, layout, a, split);
 }
 
 static int gemm_partials(int dtype, int M, int N) {
@@ -123,6 +125,7 @@ struct dmvae_plan {
     int64_t work_bytes;
     dmvae_buffers buf;
     bool bound;
+    std::vector<GemmArgs> dw_queue;   // dW problems of the step in flight (bf16: flushed as one grouped launch)
 };
 
 static void add_tensor(dmvae_plan* p, const std::string& name, int64_t off, int rows, int cols, int64_t ld) {
@@ -354,6 +357,13 @@ static int grad_dense(dmvae_plan* p, hipStream_t s, const void* X, int64_t ldx, 
     e.kind = split > 1 ? DMVAE_EPI_ATOMIC_F32 : DMVAE_EPI_STORE_F32;
     e.out = p->buf.grad + w_off; e.ldo = ldw;
     e.out2 = p->buf.grad + b_off;             // db = column sums of dY, fused (ones-operand MFMA)
+    if (p->cfg.dtype == DMVAE_BF16) {         // bf16: queued, all dW problems of the step go out as ONE grouped launch
+        DMVAE_REQUIRE((int)p->dw_queue.size() < DMVAE_MAX_GROUP, "more than %d dW problems in one step", DMVAE_MAX_GROUP);
+        GemmArgs a;
+        TRY(gemm_checked(s, DMVAE_BF16, DMVAE_GEMM_DW, Mdim, N, p->Bp, X, ldx, dY, ldy, &e, 1, &a));
+        p->dw_queue.push_back(a);
+        return 0;
+    }
     return gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_DW, Mdim, N, p->Bp, X, ldx, dY, ldy, &e, split);
 }
 
@@ -372,6 +382,7 @@ extern "C" int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_va
     hipStream_t s = (hipStream_t)stream;
     const dmvae_config& c = p->cfg;
     const int dt = c.dtype;
+    p->dw_queue.clear();
     TRY(encode_impl(p, s));
 
     dmvae_latent_args la;
@@ -447,6 +458,13 @@ extern "C" int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_va
             TRY(dx_dense(p, s, WS(p, p->o_denc[i]), L.out_pad, L.out_pad, L.w_off, L.ldw, L.in_pad,
                          WS(p, p->o_enc[i - 1]), p->enc[i - 1].out_pad, WS(p, p->o_denc[i - 1]), p->enc[i - 1].out_pad));
     }
+    // ---- all weight gradients dW = X^T dY (+ db) of the step: independent of the dX chain above and of
+    //      each other -> one grouped launch that fills the chip (each alone covers 16..512 of 256 x 2 slots)
+    if (!p->dw_queue.empty()) {
+        const int rc = gemm_bf16_grouped_dw(s, p->dw_queue.data(), (int)p->dw_queue.size());
+        p->dw_queue.clear();
+        if (rc) return rc;
+    }
     // ---- prior-table gradients: fixed-order sum of the per-block partials
     const int KD2 = 2 * c.n_classes * c.latent_dim;
     TRY(colsum_launch(s, DMVAE_F32, WS(p, p->o_dprior), KD2, p->n_lblk, KD2, p->buf.grad + p->prior_off,
@@ -500,6 +518,19 @@ extern "C" int dmvae_gemm(void* stream, int dtype, int layout, int M, int N, int
     return gemm_checked((hipStream_t)stream, dtype, layout, M, N, K, A, lda, B, ldb, epi, split_k);
 }
 extern "C" int dmvae_gemm_partials(int dtype, int M, int N) { return gemm_partials(dtype, M, N); }
+
+extern "C" int dmvae_gemm_grouped_dw(void* stream, int dtype, const dmvae_gemm_problem* probs, int n) {
+    DMVAE_REQUIRE(probs && n >= 1 && n <= DMVAE_MAX_GROUP, "dmvae_gemm_grouped_dw: 1..%d problems", DMVAE_MAX_GROUP);
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<GemmArgs> q(n);
+    for (int i = 0; i < n; ++i) {
+        const dmvae_gemm_problem& pr = probs[i];
+        DMVAE_REQUIRE(pr.epi.kind == DMVAE_EPI_STORE_F32, "dmvae_gemm_grouped_dw: problems must use DMVAE_EPI_STORE_F32");
+        if (dtype == DMVAE_BF16) TRY(gemm_checked(s, dtype, DMVAE_GEMM_DW, pr.M, pr.N, pr.K, pr.A, pr.lda, pr.B, pr.ldb, &pr.epi, 1, &q[i]));
+        else TRY(gemm_checked(s, dtype, DMVAE_GEMM_DW, pr.M, pr.N, pr.K, pr.A, pr.lda, pr.B, pr.ldb, &pr.epi, 1));
+    }
+    return dtype == DMVAE_BF16 ? gemm_bf16_grouped_dw(s, q.data(), n) : 0;
+}
 
 extern "C" int dmvae_latent_nblocks(int B_pad, int D, int K) { return latent_nblocks(B_pad, D, K); }
 extern "C" int dmvae_latent_fwd(void* stream, const dmvae_latent_args* a) {

@@ -137,8 +137,10 @@ __device__ __forceinline__ bf16x8 read_frag(const bf16_t* s, unsigned lo, unsign
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// One output tile of one GEMM problem.  bid_raw = tile id within the problem, nwg = number of
+// workgroups of the launch when the launch is this single problem (XCD-aware remap), else 0.
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
+__device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_raw, const int nwg) {
     constexpr bool A_KC = (LAYOUT != DMVAE_GEMM_DW);
     constexpr bool B_KC = (LAYOUT == DMVAE_GEMM_DX);
     constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
@@ -154,9 +156,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     // XCD-aware tile order (speed only, never correctness): workgroups are dealt round-robin
     // over the 8 XCDs, so ids b and b+8 share an L2.  Give each XCD a CONTIGUOUS run of tile
     // ids (bijective for any grid size) ...
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    int bid = bid_raw;
+    if (nwg > 0) {          // (grouped launches pass nwg = 0: their tile ids do not start at an XCD boundary)
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     // ... and walk the tiles of a run in supertiles of group_m tile-rows (column-major inside a
@@ -292,21 +294,81 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
         float* red = reinterpret_cast<float*>(smem);
         const float t = block_sum_256(loss, red);
-        if (tid == 0) a.epi.partials[blockIdx.x] = t;
+        if (tid == 0) a.epi.partials[bid_raw] = t;
     }
 }
 
+template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
+    gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE>(a, blockIdx.x, gridDim.x);
+}
+
+// Grouped launch: several independent GEMM problems of one layout / epilogue / tile shape in ONE
+// grid (the nine dW = X^T dY products of a training step: each alone fills a fraction of the 256
+// CUs, together they keep every CU at two resident workgroups).  Problem i owns the workgroups
+// [start[i], start[i+1]).
+struct GroupedArgs {
+    int nprob;
+    int start[DMVAE_MAX_GROUP + 1];
+    GemmArgs p[DMVAE_MAX_GROUP];
+};
+template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE>
+__global__ __launch_bounds__(256) void gemm_bf16_grouped_kernel(GroupedArgs g) {
+    int i = 0;
+    while (i + 1 < g.nprob && (int)blockIdx.x >= g.start[i + 1]) ++i;
+    gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE>(g.p[i], (int)blockIdx.x - g.start[i], 0);
+}
+
 // ---------------------------------------------------------------- host side
+static int g_group_m = 8;                   // tuning knob (dmvae_debug_set_knob 0): supertile rows
+template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE>
+static const char* kernel_name(bool grouped) {   // the template instantiation, as rocprofv3 prints it
+    static char nm[2][64];
+    static bool init = false;
+    if (!init) {
+        snprintf(nm[0], 64, "gemm_bf16_kernel<%d, %d, %d, %d, %d>", BM, BN, LAYOUT, EPI, NSTAGE);
+        snprintf(nm[1], 64, "gemm_bf16_grouped_kernel<%d, %d, %d, %d, %d>", BM, BN, LAYOUT, EPI, NSTAGE);
+        init = true;
+    }
+    return nm[grouped ? 1 : 0];
+}
+static double gemm_bytes(const GemmArgs& a) {    // algorithmic: each operand once + the output once
+    const int k = a.epi.kind;
+    const double osz = (k == DMVAE_EPI_STORE_F32 || k == DMVAE_EPI_ATOMIC_F32 || k == DMVAE_EPI_BIAS_F32 || k == DMVAE_EPI_BIAS_SIGMOID) ? 4.0 : 2.0;
+    return 2.0 * ((double)a.M * a.K + (double)a.K * a.N) + osz * a.M * a.N;
+}
+
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE>
 static int launch(hipStream_t s, const GemmArgs& a, int split) {
     dim3 grid((a.M / BM) * (a.N / BN), split);
+    ProfScope ps(s, kernel_name<BM, BN, LAYOUT, EPI, NSTAGE>(false), 2.0 * a.M * a.N * (double)a.K, gemm_bytes(a));
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, LAYOUT, EPI, NSTAGE>), grid, dim3(256), 0, s, a);
     return check_launch("gemm_bf16");
 }
 
+// all problems: DW layout, STORE_F32 epilogue, 64x64 tiles (the only tile every dW shape divides)
+int gemm_bf16_grouped_dw(hipStream_t s, const GemmArgs* probs, int nprob) {
+    if (nprob < 1 || nprob > DMVAE_MAX_GROUP) { set_error("dmvae_gemm_grouped: 1..%d problems", DMVAE_MAX_GROUP); return DMVAE_EINVAL; }
+    GroupedArgs g;
+    g.nprob = nprob;
+    int total = 0;
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < nprob; ++i) {
+        g.start[i] = total;
+        g.p[i] = probs[i];
+        g.p[i].group_m = g_group_m;
+        total += (probs[i].M / 64) * (probs[i].N / 64);
+        flops += 2.0 * probs[i].M * probs[i].N * (double)probs[i].K;
+        bytes += gemm_bytes(probs[i]);
+    }
+    for (int i = nprob; i <= DMVAE_MAX_GROUP; ++i) g.start[i] = total;
+    ProfScope ps(s, kernel_name<64, 64, DMVAE_GEMM_DW, DMVAE_EPI_STORE_F32, 4>(true), flops, bytes);
+    hipLaunchKernelGGL((gemm_bf16_grouped_kernel<64, 64, DMVAE_GEMM_DW, DMVAE_EPI_STORE_F32, 4>), dim3(total), dim3(256), 0, s, g);
+    return check_launch("gemm_bf16_grouped");
+}
+
 static int g_force_tile = 0;   // debug override (dmvae_debug_set_tile): BM*1000+BN, 0 = heuristic
 void gemm_bf16_force_tile(int t) { g_force_tile = t; }
-static int g_group_m = 8;                   // tuning knob (dmvae_debug_set_knob 0): supertile rows
 void gemm_bf16_set_knob(int which, int v) {
     if (which == 0) g_group_m = v < 1 ? 1 : v;
 }

@@ -13,7 +13,9 @@ struct AdamArgs {
     const dmvae_state* st;
 };
 
+#define DMVAE_MAX_GROUP 16
 int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split);
+int gemm_bf16_grouped_dw(hipStream_t s, const GemmArgs* probs, int nprob);
 int gemm_bf16_tile_m(int M, int N, int split);
 void gemm_bf16_force_tile(int t);
 void gemm_bf16_set_knob(int which, int v);

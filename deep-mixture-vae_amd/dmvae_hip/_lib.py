@@ -22,7 +22,7 @@ GEMM_FWD, GEMM_DX, GEMM_DW = 0, 1, 2
 MAX_LAYERS = 8
 
 EXPORTS = [
-    "dmvae_gemm", "dmvae_gemm_partials", "dmvae_latent_nblocks", "dmvae_latent_fwd",
+    "dmvae_gemm", "dmvae_gemm_partials", "dmvae_gemm_grouped_dw", "dmvae_latent_nblocks", "dmvae_latent_fwd",
     "dmvae_recon_fwd_bwd", "dmvae_recon_nblocks", "dmvae_colsum", "dmvae_loss_finalize",
     "dmvae_adam_tf", "dmvae_adam_finish", "dmvae_gather_rows", "dmvae_philox_normal",
     "dmvae_philox_gumbel", "dmvae_cast_f32_to_bf16", "dmvae_cast_bf16_to_f32",
@@ -45,6 +45,12 @@ class Epilogue(C.Structure):
         ("aux2", C.c_void_p), ("ld2", C.c_int64),
         ("partials", C.c_void_p),
     ]
+
+
+class GemmProblem(C.Structure):
+    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("reserved", C.c_int32),
+                ("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64),
+                ("epi", Epilogue)]
 
 
 class LatentArgs(C.Structure):
@@ -122,6 +128,7 @@ def _load():
     sig = {
         "dmvae_gemm": [vp, i32, i32, i32, i32, i32, vp, i64, vp, i64, P(Epilogue), i32],
         "dmvae_gemm_partials": [i32, i32, i32],
+        "dmvae_gemm_grouped_dw": [vp, i32, P(GemmProblem), i32],
         "dmvae_latent_nblocks": [i32, i32, i32],
         "dmvae_latent_fwd": [vp, P(LatentArgs)],
         "dmvae_recon_fwd_bwd": [vp, i32, i32, i32, i32, i32, i32, vp, i64, vp, i64, f32, vp, i64, vp],

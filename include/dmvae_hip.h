@@ -95,6 +95,19 @@ int dmvae_gemm(void* stream, int dtype, int layout, int M, int N, int K,
 /* number of loss partials dmvae_gemm writes for an (M,N) RECON launch */
 int dmvae_gemm_partials(int dtype, int M, int N);
 
+/* Grouped weight-gradient GEMMs: n (<= 16) independent DMVAE_GEMM_DW problems
+ * (dW_l = X_l^T . dY_l, optional fused db_l through epi.out2; epi.kind must be
+ * DMVAE_EPI_STORE_F32) enqueued as ONE grid for bf16 -- every tf.gradients(loss, W_l)
+ * of base_models.py:110 in one launch.  Each problem alone covers a fraction of the
+ * 256 CUs; together they keep the chip full without split-K (bit-reproducible). */
+typedef struct dmvae_gemm_problem {
+    int32_t M, N, K, reserved;
+    const void* A; int64_t lda;
+    const void* B; int64_t ldb;
+    dmvae_epilogue epi;
+} dmvae_gemm_problem;
+int dmvae_gemm_grouped_dw(void* stream, int dtype, const dmvae_gemm_problem* probs, int n);
+
 /* ---- latent kernel: softmax + reparameterisation + mixture KL + all KL gradients
  * replaces priors.py:86-89 (Z), :104-147 (KL_Z exact / relaxed), :170-181
  * (Gumbel-Softmax), :183-201 (KL_C), base_models.py:249 (softmax) and their

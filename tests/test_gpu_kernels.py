@@ -129,6 +129,35 @@ def test_gemm_dw_fused_bias_gradient(hip, dtype, shape):
     np.testing.assert_array_equal(db.cpu().numpy().astype(np.float64), B.sum(0))
 
 
+@pytest.mark.parametrize("dtype", [1, 0])
+def test_gemm_grouped_dw_matches_individual_products(hip, dtype):
+    """nine dW problems of mixed shapes in ONE launch (exact on integers), each with its fused db."""
+    L = hip
+    K = 512
+    shapes = [(512, 832), (512, 512), (2048, 512), (64, 2048), (2048, 128), (2048, 64), (512, 4096), (512, 512), (832, 512)]
+    rng = np.random.RandomState(9)
+    tdt = torch.bfloat16 if dtype == 1 else torch.float32
+    probs = (L.GemmProblem * len(shapes))()
+    keep, refs = [], []
+    for i, (M, N) in enumerate(shapes):
+        A, B, Am, Bm = operands(2, M, N, K, rng, True)
+        Ad, Bd = dev(Am, tdt), dev(Bm, tdt)
+        out = torch.full((M, N), 3.0, dtype=torch.float32, device="cuda")
+        db = torch.full((N,), 3.0, dtype=torch.float32, device="cuda")
+        keep.append((Ad, Bd, out, db))
+        refs.append((A @ B, B.sum(0)))
+        p = probs[i]
+        p.M, p.N, p.K = M, N, K
+        p.A, p.lda, p.B, p.ldb = L.ptr(Ad).value, M, L.ptr(Bd).value, N
+        p.epi.kind = L.EPI_STORE_F32
+        p.epi.out, p.epi.ldo, p.epi.out2 = L.ptr(out).value, N, L.ptr(db).value
+    L.check(L.lib.dmvae_gemm_grouped_dw(stream(), dtype, probs, len(shapes)), "dmvae_gemm_grouped_dw")
+    torch.cuda.synchronize()
+    for (Ad, Bd, out, db), (ref, dbref) in zip(keep, refs):
+        np.testing.assert_array_equal(out.cpu().numpy().astype(np.float64), ref)
+        np.testing.assert_array_equal(db.cpu().numpy().astype(np.float64), dbref)
+
+
 def _act(dtype):
     return torch.bfloat16 if dtype == 1 else torch.float32
 
