@@ -471,7 +471,7 @@ extern "C" int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_va
                       reinterpret_cast<float*>(WS(p, p->o_cs)), p->cs_elems));
     // ---- loss scalars
     return loss_finalize_launch(s, reinterpret_cast<float*>(WS(p, p->o_rpart)), p->n_rpart, reinterpret_cast<float*>(WS(p, p->o_lpart)),
-                                p->n_lblk, inv_B, p->buf.state);
+                                p->n_lblk, inv_B, p->buf.state, 1);
 }
 
 extern "C" int dmvae_plan_update(dmvae_plan* p, void* stream, float grad_scale) {
@@ -482,9 +482,9 @@ extern "C" int dmvae_plan_update(dmvae_plan* p, void* stream, float grad_scale) 
     a.pb = reinterpret_cast<bf16_t*>(p->cfg.dtype == DMVAE_BF16 ? p->buf.param_bf16 : nullptr);
     a.lr = 0.f; a.b1 = p->cfg.beta1; a.b2 = p->cfg.beta2; a.eps = p->cfg.adam_eps; a.gscale = grad_scale;
     a.zero_grad = 0;    // every gradient element is overwritten each step (no atomic accumulation)
-    a.t_host = 0; a.st = reinterpret_cast<const dmvae_state*>(p->buf.state);
-    TRY(adam_launch(s, a));
-    return adam_finish_launch(s, p->buf.state);
+    a.t_host = ~0ull;    // t = state->adam_t, already advanced by this step's loss_finalize (saves a launch)
+    a.st = reinterpret_cast<const dmvae_state*>(p->buf.state);
+    return adam_launch(s, a);
 }
 
 extern "C" int dmvae_plan_view(const dmvae_plan* p, const char* name, void** ptr, int64_t* ld, int32_t* dtype) {
@@ -554,7 +554,7 @@ extern "C" int dmvae_colsum(void* stream, int in_dtype, const void* in, int64_t 
 }
 extern "C" int dmvae_loss_finalize(void* stream, const float* rp, int nr, const float* lp, int nl, float inv_B, void* state) {
     DMVAE_REQUIRE(rp && lp && state, "dmvae_loss_finalize: null pointer");
-    return loss_finalize_launch((hipStream_t)stream, rp, nr, lp, nl, inv_B, state);
+    return loss_finalize_launch((hipStream_t)stream, rp, nr, lp, nl, inv_B, state, 0);
 }
 extern "C" int dmvae_adam_tf(void* stream, int64_t n, float* param, float* grad, float* m, float* v, void* param_bf16, float lr,
                              float beta1, float beta2, float epsilon, float grad_scale, int zero_grad, uint64_t t_host, const void* state) {

@@ -11,7 +11,8 @@ namespace dmvae {
 // correction: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t*m/(sqrt(v)+eps).
 // 4 elements per lane: 16-B loads of p, g, m, v; 16-B stores of p, m, v (+8 B bf16).
 __global__ __launch_bounds__(256) void adam_tf_kernel(AdamArgs a) {
-    const uint64_t t = a.st ? a.st->adam_t + 1 : a.t_host;
+    // state given: t = adam_t + 1, or adam_t itself when the step's loss_finalize already advanced it (t_host == ~0)
+    const uint64_t t = a.st ? (a.t_host == ~0ull ? a.st->adam_t : a.st->adam_t + 1) : a.t_host;
     const float lr = a.st ? a.st->lr : a.lr;
     // powf on the exact integer t; double keeps 1-b2^t accurate for small t
     const double b1t = pow((double)a.b1, (double)t), b2t = pow((double)a.b2, (double)t);
@@ -177,7 +178,7 @@ int recon_launch(hipStream_t s, int act_dtype, int recon_kind, int B, int B_pad,
 
 // ---------------------------------------------------------------- loss finalize
 // loss = recon + kl_ratio*(KL_C + KL_Z); base_models.py:87-93 and :130.
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* rp, int nr, const float* lp, int nl, float inv_B, dmvae_state* st) {
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* rp, int nr, const float* lp, int nl, float inv_B, dmvae_state* st, int bump_adam) {
     __shared__ float red[4];
     float a = 0.f, z = 0.f, c = 0.f;
     for (int i = threadIdx.x; i < nr; i += 256) a += rp[i];
@@ -193,11 +194,12 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* rp, int
         st->epoch_klz += klz * st->epoch_weight;
         st->epoch_klc += klc * st->epoch_weight;
         st->noise_step += 1;
+        if (bump_adam) st->adam_t += 1;      // the update that follows in the same step reads t = adam_t
         st->batch_cursor = (st->batches_per_epoch > 0) ? (st->batch_cursor + 1) % st->batches_per_epoch : 0;
     }
 }
-int loss_finalize_launch(hipStream_t s, const float* rp, int nr, const float* lp, int nl, float inv_B, void* st) {
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, rp, nr, lp, nl, inv_B, reinterpret_cast<dmvae_state*>(st));
+int loss_finalize_launch(hipStream_t s, const float* rp, int nr, const float* lp, int nl, float inv_B, void* st, int bump_adam) {
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, rp, nr, lp, nl, inv_B, reinterpret_cast<dmvae_state*>(st), bump_adam);
     return check_launch("loss_finalize");
 }
 

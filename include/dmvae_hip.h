@@ -261,7 +261,9 @@ int dmvae_plan_load_batch(dmvae_plan* p, void* stream, const float* data, int64_
 int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_valid,
                                 const float* eps, int64_t ld_eps, const float* gumbel, int64_t ld_gumbel,
                                 float inv_B);
-/* loss finalize + Adam (+ bf16 shadow refresh); grad_scale = 1/world_size */
+/* Adam (+ bf16 shadow refresh); grad_scale = 1/world_size.  The loss finalize at the end of
+ * dmvae_plan_forward_backward has already advanced state->adam_t for this step: every
+ * forward_backward is to be followed by exactly one update. */
 int dmvae_plan_update(dmvae_plan* p, void* stream, float grad_scale);
 /* inference pieces used by get_accuracy / reconstruction / sampling:
  * encode: X (loaded batch) -> mean, log_var, logits (f32, in the workspace)
