@@ -2,6 +2,7 @@
 // checking, the step plan (arena layout + the launch sequence of one
 // session.run([loss, train_step])), and HIP-event profiling of every launch.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -125,7 +126,11 @@ struct dmvae_plan {
     int64_t work_bytes;
     dmvae_buffers buf;
     bool bound;
-    std::vector<GemmArgs> dw_queue;   // dW problems of the step in flight (bf16: flushed as one grouped launch)
+    std::vector<GemmArgs> dw_queue;   // dW problems queued (bf16: flushed as grouped launches)
+    hipStream_t side = nullptr;       // side stream the dW groups run on, concurrently with the dX chain
+    hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_join = nullptr;
+    bool side_busy = false;
+    bool overlap_dw = true;
 };
 
 static void add_tensor(dmvae_plan* p, const std::string& name, int64_t off, int rows, int cols, int64_t ld) {
@@ -239,7 +244,13 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
     return 0;
 }
 
-extern "C" void dmvae_plan_destroy(dmvae_plan* p) { delete p; }
+extern "C" void dmvae_plan_destroy(dmvae_plan* p) {
+    if (!p) return;
+    for (auto& e : p->ev_fork) if (e) (void)hipEventDestroy(e);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+    if (p->side) (void)hipStreamDestroy(p->side);
+    delete p;
+}
 
 extern "C" int dmvae_plan_sizes(const dmvae_plan* p, dmvae_sizes* o) {
     DMVAE_REQUIRE(p && o, "dmvae_plan_sizes: null argument");
@@ -262,6 +273,13 @@ extern "C" int dmvae_plan_bind(dmvae_plan* p, const dmvae_buffers* b) {
     DMVAE_REQUIRE((uintptr_t)b->work % 256 == 0 && (uintptr_t)b->param % 256 == 0 && (uintptr_t)b->grad % 256 == 0, "dmvae_plan_bind: buffers must be 256-byte aligned");
     p->buf = *b;
     p->bound = true;
+    if (p->cfg.dtype == DMVAE_BF16 && !p->side) {   // setup-time resources (never created while enqueueing)
+        hipError_t e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
+        for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ev_fork[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming);
+        if (e != hipSuccess) { set_error("dmvae_plan_bind: side stream / events: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    p->overlap_dw = getenv("DMVAE_DW_OVERLAP") != nullptr;
     return 0;
 }
 
@@ -367,6 +385,34 @@ static int grad_dense(dmvae_plan* p, hipStream_t s, const void* X, int64_t ldx, 
     return gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_DW, Mdim, N, p->Bp, X, ldx, dY, ldy, &e, split);
 }
 
+// Launch the queued weight-gradient problems as ONE grouped grid.  They depend only on tensors
+// that already exist (X_l from the forward pass, dY_l just produced) and nothing on the dX chain
+// depends on them, so they go to the plan's side stream (fork: event on `s`, awaited by `side`;
+// the join is at the end of forward_backward) and share the CUs with the chain's GEMMs, which
+// leave half of each CU's LDS and wave slots free.  The fork/join is plain event record/wait, so
+// it is captured into the same HIP graph as the rest of the step.
+//
+// MEASURED (cfg2, MI355X, round 1): overlapping is SLOWER -- 0.4235 vs 0.391 ms/step.  The dW grid
+// and the dX chain are bound by the same per-CU L2->LDS path, and three small groups are less
+// efficient than one large one (164 vs 109 us).  So by default everything queues until the last
+// call (group 2) and goes out as ONE grouped launch on the main stream; DMVAE_DW_OVERLAP=1
+// re-enables the side-stream form for re-measurement on other shapes.
+static int flush_dw(dmvae_plan* p, hipStream_t s, int group) {
+    if (p->dw_queue.empty()) return 0;
+    if (!p->overlap_dw && group != 2) return 0;
+    hipStream_t target = s;
+    if (p->side && p->overlap_dw) {
+        hipError_t e = hipEventRecord(p->ev_fork[group], s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(p->side, p->ev_fork[group], 0);
+        if (e != hipSuccess) { set_error("dW side stream fork: %s", hipGetErrorString(e)); return (int)e; }
+        target = p->side;
+        p->side_busy = true;
+    }
+    const int rc = gemm_bf16_grouped_dw(target, p->dw_queue.data(), (int)p->dw_queue.size());
+    p->dw_queue.clear();
+    return rc;
+}
+
 static int dx_dense(dmvae_plan* p, hipStream_t s, const void* dY, int64_t ldy, int Kdim, int64_t w_off, int64_t ldw, int N,
                     const void* Yfwd, int64_t ldyf, void* out, int64_t ldo) {
     dmvae_epilogue e;
@@ -439,6 +485,7 @@ extern "C" int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_va
             TRY(gemm_checked(s, dt, DMVAE_GEMM_DX, p->Bp, p->Dp, L.out_pad, WS(p, p->o_ddec[0]), L.out_pad, Wp(p, L.w_off), L.ldw, &e, 1));
         }
     }
+    TRY(flush_dw(p, s, 0));   // decoder dW group: overlaps the rest of the dX chain on the side stream
     // ---- backward: heads
     TRY(grad_dense(p, s, WS(p, p->o_hzc), 2 * p->Hp, p->Hp, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->mv.b_off));
     TRY(grad_dense(p, s, act_off(p, p->o_hzc, p->Hp), 2 * p->Hp, p->Hp, WS(p, p->o_dlg), p->Kp, p->Kp, p->lg.w_off, p->lg.ldw, p->lg.b_off));
@@ -447,6 +494,7 @@ extern "C" int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_va
                  const_cast<void*>(act_off(p, p->o_dhzc, p->Hp)), 2 * p->Hp));
     // ---- backward: trunk
     TRY(grad_dense(p, s, WS(p, p->o_enc[ne - 1]), p->Tp, p->Tp, WS(p, p->o_dhzc), 2 * p->Hp, 2 * p->Hp, p->zc.w_off, p->zc.ldw, p->zc.b_off));
+    TRY(flush_dw(p, s, 1));   // heads dW group ([mean|log_var], logits, [zh|ch])
     TRY(dx_dense(p, s, WS(p, p->o_dhzc), 2 * p->Hp, 2 * p->Hp, p->zc.w_off, p->zc.ldw, p->Tp, WS(p, p->o_enc[ne - 1]), p->Tp,
                  WS(p, p->o_denc[ne - 1]), p->Tp));
     for (int i = ne - 1; i >= 0; --i) {
@@ -458,12 +506,12 @@ extern "C" int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_va
             TRY(dx_dense(p, s, WS(p, p->o_denc[i]), L.out_pad, L.out_pad, L.w_off, L.ldw, L.in_pad,
                          WS(p, p->o_enc[i - 1]), p->enc[i - 1].out_pad, WS(p, p->o_denc[i - 1]), p->enc[i - 1].out_pad));
     }
-    // ---- all weight gradients dW = X^T dY (+ db) of the step: independent of the dX chain above and of
-    //      each other -> one grouped launch that fills the chip (each alone covers 16..512 of 256 x 2 slots)
-    if (!p->dw_queue.empty()) {
-        const int rc = gemm_bf16_grouped_dw(s, p->dw_queue.data(), (int)p->dw_queue.size());
-        p->dw_queue.clear();
-        if (rc) return rc;
+    TRY(flush_dw(p, s, 2));   // trunk dW group
+    if (p->side_busy) {       // join: Adam / the next step must see every dW
+        hipError_t e = hipEventRecord(p->ev_join, p->side);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, p->ev_join, 0);
+        p->side_busy = false;
+        if (e != hipSuccess) { set_error("dW side stream join: %s", hipGetErrorString(e)); return (int)e; }
     }
     // ---- prior-table gradients: fixed-order sum of the per-block partials
     const int KD2 = 2 * c.n_classes * c.latent_dim;
@@ -639,7 +687,7 @@ extern "C" int dmvae_debug_set_tile(int bm, int bn) {
 }
 
 extern "C" int dmvae_debug_set_knob(int which, int value) {
-    DMVAE_REQUIRE(which == 0 || which == 1, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = ring depth of the 128x128 tile");
+    DMVAE_REQUIRE(which >= 0 && which <= 2, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in the grouped dW grid");
     gemm_bf16_set_knob(which, value);
     return 0;
 }

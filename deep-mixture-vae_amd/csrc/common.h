@@ -48,6 +48,22 @@ __device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 float
     return r;
 }
 
+// Fixed-order block sum over NW waves; result valid in thread 0.
+template <int NW>
+__device__ __forceinline__ float block_sum_waves(float v, float* red /* >= NW floats LDS */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) r += red[i];
+    }
+    __syncthreads();
+    return r;
+}
+
 // ---- Philox4x32-10 (counter-based; same stream on every replay of a graph) ----
 __host__ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll

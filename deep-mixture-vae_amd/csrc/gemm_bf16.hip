@@ -55,19 +55,19 @@ __device__ __forceinline__ int swz_nc(int k, int chunk) {
 // tile; loop invariant, computed once.
 //   KC : tile [R rows][64 k]   : a wave instruction covers 8 rows x 128 B
 //   !KC: tile [64 k][R cols]   : R = 128: 4 k-rows x 256 B;  R = 64: 8 k-rows x 128 B
-template <int R, bool KC>
-__device__ __forceinline__ void stage_offsets(int64_t ld, int wave, int lane, unsigned (&off)[R / 32]) {
+template <int R, bool KC, int NW>
+__device__ __forceinline__ void stage_offsets(int64_t ld, int wave, int lane, unsigned (&off)[R / (8 * NW)]) {
 #pragma unroll
-    for (int i = 0; i < R / 32; ++i) {
+    for (int i = 0; i < R / (8 * NW); ++i) {
         int row, c;
         if constexpr (KC) {
-            row = i * 32 + wave * 8 + (lane >> 3);
+            row = i * (8 * NW) + wave * 8 + (lane >> 3);
             c = swz_kc(row, lane & 7);
         } else if constexpr (R == 128) {
-            row = i * 16 + wave * 4 + (lane >> 4);
+            row = i * (4 * NW) + wave * 4 + (lane >> 4);
             c = swz_nc<128>(row, lane & 15);
         } else {
-            row = i * 32 + wave * 8 + (lane >> 3);
+            row = i * (8 * NW) + wave * 8 + (lane >> 3);
             c = swz_nc<64>(row, lane & 7);
         }
         off[i] = 2u * (unsigned)(row * (int)ld + c * 8);
@@ -75,11 +75,21 @@ __device__ __forceinline__ void stage_offsets(int64_t ld, int wave, int lane, un
 }
 
 // LDS-DMA of one operand tile: NL wave instructions of 64 lanes x 16 B each,
-//   LDS[lds + 4096*i + lane*16 ..) <- *(tile + off[i])          (i < NL)
+//   LDS[lds + stride*i + lane*16 ..) <- *(tile + off[i])        (i < NL; stride = 1 KiB x waves)
 // tile = wave-uniform pointer (SGPR pair), off = per-lane 32-bit byte offsets, lds = wave-uniform
-// LDS byte address of this wave's first chunk (consecutive chunks of a wave are 4 KiB apart for
-// every tile shape).  M0 (the DMA's LDS base) is compiler-reserved: saved/restored in the statement.
-__device__ __forceinline__ void glds_tile(const void* tile, const unsigned (&off)[2], unsigned lds) {
+// LDS byte address of this wave's first chunk (a pass of all waves covers 1 KiB x waves for every
+// tile shape).  M0 (the DMA's LDS base) is compiler-reserved: saved/restored in the statement.
+__device__ __forceinline__ void glds_tile(const void* tile, const unsigned (&off)[1], unsigned lds, unsigned) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(tile), "v"(off[0]), "s"(lds)
+        : "memory");
+}
+__device__ __forceinline__ void glds_tile(const void* tile, const unsigned (&off)[2], unsigned lds, unsigned stride) {
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
@@ -87,10 +97,10 @@ __device__ __forceinline__ void glds_tile(const void* tile, const unsigned (&off
         "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "s"(tile), "v"(off[0]), "v"(off[1]), "s"(lds), "s"(lds + 4096u)
+        : "s"(tile), "v"(off[0]), "v"(off[1]), "s"(lds), "s"(lds + stride)
         : "memory");
 }
-__device__ __forceinline__ void glds_tile(const void* tile, const unsigned (&off)[4], unsigned lds) {
+__device__ __forceinline__ void glds_tile(const void* tile, const unsigned (&off)[4], unsigned lds, unsigned stride) {
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
@@ -100,7 +110,7 @@ __device__ __forceinline__ void glds_tile(const void* tile, const unsigned (&off
         "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "s"(tile), "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(lds), "s"(lds + 4096u), "s"(lds + 8192u), "s"(lds + 12288u)
+        : "s"(tile), "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(lds), "s"(lds + stride), "s"(lds + 2u * stride), "s"(lds + 3u * stride)
         : "memory");
 }
 
@@ -139,15 +149,17 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // One output tile of one GEMM problem.  bid_raw = tile id within the problem, nwg = number of
 // workgroups of the launch when the launch is this single problem (XCD-aware remap), else 0.
-template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE>
-__device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_raw, const int nwg) {
+// NW = waves per workgroup: 4 (2 x 2) or 8 (4 x 2: two waves per SIMD share one tile's LDS traffic).
+template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW>
+__device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_raw, const int nwg, bf16_t* smem) {
     constexpr bool A_KC = (LAYOUT != DMVAE_GEMM_DW);
     constexpr bool B_KC = (LAYOUT == DMVAE_GEMM_DX);
     constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
-    constexpr int TM = BM / 32, TN = BN / 32;       // 16x16 tiles per wave (wave tile = BM/2 x BN/2)
-    constexpr int LOADS = BM / 32 + BN / 32;        // LDS-DMA instructions per lane per K tile
+    constexpr int WM = NW / 2;                       // waves along M (2 along N)
+    constexpr int TM = BM / (16 * WM), TN = BN / 32; // 16x16 tiles per wave (wave tile = BM/WM x BN/2)
+    constexpr int LOADS = (BM + BN) / (8 * NW);      // LDS-DMA instructions per lane per K tile
     static_assert(NSTAGE >= 2 && NSTAGE <= 8 && LOADS * (NSTAGE - 2) <= 63, "ring depth / vmcnt range");
-    __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * STAGE];   // the ONLY LDS object
+    // smem: NSTAGE * STAGE elements, the kernel's ONLY LDS object (owned by the __global__ wrapper)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -200,14 +212,14 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_bits);
 
     // loop-invariant per-lane addressing: global source byte offsets and LDS fragment offsets
-    unsigned goA[BM / 32], goB[BN / 32];
-    stage_offsets<BM, A_KC>(a.lda, wave, lane, goA);
-    stage_offsets<BN, B_KC>(a.ldb, wave, lane, goB);
+    unsigned goA[BM / (8 * NW)], goB[BN / (8 * NW)];
+    stage_offsets<BM, A_KC, NW>(a.lda, wave, lane, goA);
+    stage_offsets<BN, B_KC, NW>(a.ldb, wave, lane, goB);
     unsigned short foA[BK / 32][TM][2], foB[BK / 32][TN][2];
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) frag_offsets<BM, A_KC>(wm * (BM / 2) + i * 16, ks, lane, foA[ks][i][0], foA[ks][i][1]);
+        for (int i = 0; i < TM; ++i) frag_offsets<BM, A_KC>(wm * (BM / WM) + i * 16, ks, lane, foA[ks][i][0], foA[ks][i][1]);
 #pragma unroll
         for (int j = 0; j < TN; ++j) frag_offsets<BN, B_KC>(wn * (BN / 2) + j * 16, ks, lane, foB[ks][j][0], foB[ks][j][1]);
     }
@@ -220,8 +232,8 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     auto issue = [&](int t, int slot) {
         const int tc = t < nk ? t : nk - 1;
         const unsigned s = lds_w + 2u * (unsigned)(slot * STAGE);
-        glds_tile(Ag + tc * stepA, goA, s);
-        glds_tile(Bg + tc * stepB, goB, s + 2u * A_ELEMS);
+        glds_tile(Ag + tc * stepA, goA, s, 1024u * NW);
+        glds_tile(Bg + tc * stepB, goB, s + 2u * A_ELEMS, 1024u * NW);
     };
     auto compute = [&](int slot) {
         const bf16_t* As = smem + slot * STAGE;
@@ -271,7 +283,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int m = m0 + wm * (BM / 2) + i * 16 + li;
+            const int m = m0 + wm * (BM / WM) + i * 16 + li;
             const int n = n0 + wn * (BN / 2) + j * 16 + g * 4;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             epilogue_quad<EPI, bf16_t>(a.epi, m, n, v, loss);
@@ -293,14 +305,15 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     }
     if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
         float* red = reinterpret_cast<float*>(smem);
-        const float t = block_sum_256(loss, red);
+        const float t = block_sum_waves<NW>(loss, red);
         if (tid == 0) a.epi.partials[bid_raw] = t;
     }
 }
 
-template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
-    gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE>(a, blockIdx.x, gridDim.x);
+template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * (BM + BN) * BK];
+    gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW>(a, blockIdx.x, gridDim.x, smem);
 }
 
 // Grouped launch: several independent GEMM problems of one layout / epilogue / tile shape in ONE
@@ -309,24 +322,33 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
 // [start[i], start[i+1]).
 struct GroupedArgs {
     int nprob;
+    int kind[DMVAE_MAX_GROUP];
     int start[DMVAE_MAX_GROUP + 1];
     GemmArgs p[DMVAE_MAX_GROUP];
 };
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE>
 __global__ __launch_bounds__(256) void gemm_bf16_grouped_kernel(GroupedArgs g) {
+    // every problem takes the largest tile its shape divides (traffic per flop ~ (BM+BN)/(BM*BN)):
+    // kind 0 = 128x128 / 2 stages, 1 = 128x64 / 3, 2 = 64x64 / 4  -- one LDS array of the largest ring
+    __shared__ __attribute__((aligned(16))) bf16_t smem[3 * (128 + 64) * BK];   // 72 KiB >= 2*(128+128)*64, 4*(64+64)*64
     int i = 0;
     while (i + 1 < g.nprob && (int)blockIdx.x >= g.start[i + 1]) ++i;
-    gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE>(g.p[i], (int)blockIdx.x - g.start[i], 0);
+    const int bid = (int)blockIdx.x - g.start[i];
+    const int kind = g.kind[i];
+    if (kind == 0) gemm_bf16_body<128, 128, LAYOUT, EPI, 2, 4>(g.p[i], bid, 0, smem);
+    else if (kind == 1) gemm_bf16_body<128, 64, LAYOUT, EPI, 3, 4>(g.p[i], bid, 0, smem);
+    else gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, 4>(g.p[i], bid, 0, smem);
 }
 
 // ---------------------------------------------------------------- host side
 static int g_group_m = 8;                   // tuning knob (dmvae_debug_set_knob 0): supertile rows
-template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE>
+static int g_grouped_mixed = 1;             // tuning knob (dmvae_debug_set_knob 2): per-problem tiles in the grouped dW grid
+template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4>
 static const char* kernel_name(bool grouped) {   // the template instantiation, as rocprofv3 prints it
     static char nm[2][64];
     static bool init = false;
     if (!init) {
-        snprintf(nm[0], 64, "gemm_bf16_kernel<%d, %d, %d, %d, %d>", BM, BN, LAYOUT, EPI, NSTAGE);
+        snprintf(nm[0], 64, "gemm_bf16_kernel<%d, %d, %d, %d, %d, %d>", BM, BN, LAYOUT, EPI, NSTAGE, NW);
         snprintf(nm[1], 64, "gemm_bf16_grouped_kernel<%d, %d, %d, %d, %d>", BM, BN, LAYOUT, EPI, NSTAGE);
         init = true;
     }
@@ -338,11 +360,11 @@ static double gemm_bytes(const GemmArgs& a) {    // algorithmic: each operand on
     return 2.0 * ((double)a.M * a.K + (double)a.K * a.N) + osz * a.M * a.N;
 }
 
-template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE>
+template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4>
 static int launch(hipStream_t s, const GemmArgs& a, int split) {
     dim3 grid((a.M / BM) * (a.N / BN), split);
-    ProfScope ps(s, kernel_name<BM, BN, LAYOUT, EPI, NSTAGE>(false), 2.0 * a.M * a.N * (double)a.K, gemm_bytes(a));
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, LAYOUT, EPI, NSTAGE>), grid, dim3(256), 0, s, a);
+    ProfScope ps(s, kernel_name<BM, BN, LAYOUT, EPI, NSTAGE, NW>(false), 2.0 * a.M * a.N * (double)a.K, gemm_bytes(a));
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, LAYOUT, EPI, NSTAGE, NW>), grid, dim3(64 * NW), 0, s, a);
     return check_launch("gemm_bf16");
 }
 
@@ -351,16 +373,24 @@ int gemm_bf16_grouped_dw(hipStream_t s, const GemmArgs* probs, int nprob) {
     if (nprob < 1 || nprob > DMVAE_MAX_GROUP) { set_error("dmvae_gemm_grouped: 1..%d problems", DMVAE_MAX_GROUP); return DMVAE_EINVAL; }
     GroupedArgs g;
     g.nprob = nprob;
-    int total = 0;
+    int total = 0, n = 0;
     double flops = 0.0, bytes = 0.0;
-    for (int i = 0; i < nprob; ++i) {
-        g.start[i] = total;
-        g.p[i] = probs[i];
-        g.p[i].group_m = g_group_m;
-        total += (probs[i].M / 64) * (probs[i].N / 64);
-        flops += 2.0 * probs[i].M * probs[i].N * (double)probs[i].K;
-        bytes += gemm_bytes(probs[i]);
+    for (int kind = 0; kind < 3; ++kind) {          // large tiles first: the longest workgroups start first
+        for (int i = 0; i < nprob; ++i) {
+            const int k = g_grouped_mixed == 0 ? 2 : (probs[i].M % 128 == 0 && probs[i].N % 128 == 0) ? 0 : (probs[i].M % 128 == 0 ? 1 : 2);
+            if (k != kind) continue;
+            const int bm = kind == 2 ? 64 : 128, bn = kind == 0 ? 128 : 64;
+            g.start[n] = total;
+            g.kind[n] = kind;
+            g.p[n] = probs[i];
+            g.p[n].group_m = g_group_m;
+            total += (probs[i].M / bm) * (probs[i].N / bn);
+            flops += 2.0 * probs[i].M * probs[i].N * (double)probs[i].K;
+            bytes += gemm_bytes(probs[i]);
+            ++n;
+        }
     }
+    for (int i = nprob; i < DMVAE_MAX_GROUP; ++i) g.kind[i] = 2;
     for (int i = nprob; i <= DMVAE_MAX_GROUP; ++i) g.start[i] = total;
     ProfScope ps(s, kernel_name<64, 64, DMVAE_GEMM_DW, DMVAE_EPI_STORE_F32, 4>(true), flops, bytes);
     hipLaunchKernelGGL((gemm_bf16_grouped_kernel<64, 64, DMVAE_GEMM_DW, DMVAE_EPI_STORE_F32, 4>), dim3(total), dim3(256), 0, s, g);
@@ -369,8 +399,11 @@ int gemm_bf16_grouped_dw(hipStream_t s, const GemmArgs* probs, int nprob) {
 
 static int g_force_tile = 0;   // debug override (dmvae_debug_set_tile): BM*1000+BN, 0 = heuristic
 void gemm_bf16_force_tile(int t) { g_force_tile = t; }
+static int g_nw8 = 1;          // tuning knob (dmvae_debug_set_knob 1): 8-wave workgroups for the 128-row tiles
 void gemm_bf16_set_knob(int which, int v) {
     if (which == 0) g_group_m = v < 1 ? 1 : v;
+    if (which == 1) g_nw8 = v;
+    if (which == 2) g_grouped_mixed = v;
 }
 
 // Tile choice, BM*1000+BN.  These GEMMs run at the per-CU L2->LDS streaming rate, so the figure
@@ -403,8 +436,8 @@ static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split) {
     GemmArgs a = a0;
     a.group_m = g_group_m;
     switch (gemm_bf16_tile_m(a.M, a.N, split)) {
-        case 128128: return launch<128, 128, LAYOUT, EPI, 2>(s, a, split);
-        case 128064: return launch<128, 64, LAYOUT, EPI, 3>(s, a, split);
+        case 128128: return g_nw8 ? launch<128, 128, LAYOUT, EPI, 2, 8>(s, a, split) : launch<128, 128, LAYOUT, EPI, 2>(s, a, split);
+        case 128064: return g_nw8 ? launch<128, 64, LAYOUT, EPI, 3, 8>(s, a, split) : launch<128, 64, LAYOUT, EPI, 3>(s, a, split);
         case 64128: return launch<64, 128, LAYOUT, EPI, 3>(s, a, split);
         default: return launch<64, 64, LAYOUT, EPI, 4>(s, a, split);
     }

@@ -12,9 +12,10 @@
 //   block = 256 threads = 4 waves, owns RB consecutive rows of the batch;
 //   prior tables (mu_k, and exp(-logvar_k) or logvar_k) are staged in LDS in
 //   D-chunks of DC columns (KL is separable in d);
-//   phase 1: one wave per row, lanes over d (coalesced 4-byte loads, 256 B per
-//            wave instruction), loop over k with the table row broadcast from
-//            LDS, one wavefront reduction per (row, k);
+//   phase 1: SIXTEEN lanes per row (four rows per wave): lane l of a row owns
+//            columns d = l, l+16, ...; loop over k with the table row read from
+//            LDS; reductions run over 16 lanes only (4 DPP-width shuffle steps,
+//            no 64-lane ds_bpermute chains);
 //   phase 2: threads over (k, d) pairs, loop over the block's rows held in
 //            LDS -> per-block partial of the prior-table gradients, written
 //            to [nblocks][2][K][D] and summed by dmvae_colsum in a fixed
@@ -25,18 +26,28 @@ namespace dmvae {
 
 struct LatentLaunch {
     dmvae_latent_args a;
-    int RB;       // rows per block (multiple of 4)
-    int DC;       // columns per chunk (16..256)
+    int RB;       // rows per block (multiple of 16)
+    int DC;       // columns per chunk = 16 * DSL
     int nchunks;
 };
 
-constexpr int LAT_DS = 4;   // d slots per lane: DC <= 256
+__device__ __forceinline__ float row_sum16(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    return v;
+}
+__device__ __forceinline__ float row_max16(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 16));
+    return v;
+}
 
-template <int MODE>   // 0 exact, 1 relaxed
+template <int MODE, int DSL>   // MODE 0 exact, 1 relaxed; DSL = columns per lane per chunk (DC = 16*DSL)
 __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
     const dmvae_latent_args& a = L.a;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int K = a.K, D = a.D, RB = L.RB, DC = L.DC;
+    const int K = a.K, D = a.D, RB = L.RB;
+    constexpr int DC = 16 * DSL;
     float* t1 = lds;                  // [K][DC] prior means
     float* t2 = t1 + K * DC;          // [K][DC] exp(-prior_log_var) (exact) | prior_log_var (relaxed)
     float* ck = t2 + K * DC;          // [K]     sum_d prior_log_var
@@ -46,9 +57,11 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
     float* r1 = sk + RB * K;          // [RB][DC] exact: mu   | relaxed: dLoss/d(bar mean)
     float* r2 = r1 + RB * DC;         // [RB][DC] exact: e^lv | relaxed: dLoss/d(bar log_var)
     float* rowlv = r2 + RB * DC;      // [RB] sum_d log_var (exact) | sum_d relaxed KL integrand
-    float* red = rowlv + RB;          // [8]
+    float* red = rowlv + RB;          // [32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15;                       // lane within the row group
+    const int rsub = wave * 4 + (lane >> 4);        // row slot of this 16-lane group within a pass of 16 rows
     const int row0 = blockIdx.x * RB;
     const dmvae_state* st = reinterpret_cast<const dmvae_state*>(a.state);
     const float klr = st ? st->kl_ratio : a.kl_ratio;
@@ -58,19 +71,18 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
     const float logK = __logf((float)K);
 
     // ---- prologue: c_k, per-row softmax / zeta, KL_C ----
-    for (int k = wave; k < K; k += 4) {
+    for (int k = tid >> 4; k < K; k += 16) {
         float s = 0.f;
-        for (int d = lane; d < D; d += 64) s += a.prior_log_vars[(int64_t)k * D + d];
-        s = wave_sum(s);
-        if (lane == 0) ck[k] = s;
+        for (int d = lr; d < D; d += 16) s += a.prior_log_vars[(int64_t)k * D + d];
+        s = row_sum16(s);
+        if (lr == 0) ck[k] = s;
     }
-    float klc_acc = 0.f, klz_acc = 0.f;   // per-wave (lane 0 meaningful)
-    for (int r = wave; r < RB; r += 4) {
+    float klc_acc = 0.f, klz_acc = 0.f;   // per 16-lane group (all lanes of the group hold the same value)
+    for (int r = rsub; r < RB; r += 16) {
         const int b = row0 + r;
         const bool valid = b < a.B;
-        // softmax over k (lanes stride k)
         float mx = -INFINITY, mz = -INFINITY;
-        for (int k = lane; k < K; k += 64) {
+        for (int k = lr; k < K; k += 16) {
             const float lg = valid ? a.logits[(int64_t)b * a.ld_logits + k] : 0.f;
             mx = fmaxf(mx, lg);
             if (MODE == 1) {
@@ -80,10 +92,10 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                 mz = fmaxf(mz, (lg + gk) / a.temperature);
             }
         }
-        mx = wave_max(mx);
-        if (MODE == 1) mz = wave_max(mz);
+        mx = row_max16(mx);
+        if (MODE == 1) mz = row_max16(mz);
         float se = 0.f, sz = 0.f;
-        for (int k = lane; k < K; k += 64) {
+        for (int k = lr; k < K; k += 16) {
             const float lg = valid ? a.logits[(int64_t)b * a.ld_logits + k] : 0.f;
             const float ex = __expf(lg - mx);
             qs[r * K + k] = ex;
@@ -97,10 +109,10 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                 sz += ez;
             }
         }
-        se = wave_sum(se);
-        if (MODE == 1) sz = wave_sum(sz);
+        se = row_sum16(se);
+        if (MODE == 1) sz = row_sum16(sz);
         float kc = 0.f;
-        for (int k = lane; k < K; k += 64) {
+        for (int k = lr; k < K; k += 16) {
             const float q = valid ? qs[r * K + k] / se : 0.f;
             qs[r * K + k] = q;
             if (MODE == 1) ws[r * K + k] = valid ? ws[r * K + k] / sz : 0.f;
@@ -108,11 +120,11 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
             sk[r * K + k] = 0.f;
             kc += valid ? q * (__logf(q + 1e-20f) + logK) : 0.f;
         }
-        kc = wave_sum(kc);
+        kc = row_sum16(kc);
         klc_acc += kc;
-        if (lane == 0) rowlv[r] = 0.f;
+        if (lr == 0) rowlv[r] = 0.f;
         // zero the pad columns of Z (they are K-dim padding of the first decoder GEMM)
-        for (int d = D + lane; d < a.ld_Z; d += 64) {
+        for (int d = D + lr; d < a.ld_Z; d += 16) {
             if (a.act_dtype == DMVAE_BF16) reinterpret_cast<bf16_t*>(a.Z_act)[(int64_t)b * a.ld_Z + d] = 0;
             else reinterpret_cast<float*>(a.Z_act)[(int64_t)b * a.ld_Z + d] = 0.f;
         }
@@ -132,16 +144,16 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
         }
         __syncthreads();
 
-        // phase 1: one wave per row
-        for (int r = wave; r < RB; r += 4) {
+        // phase 1: sixteen lanes per row, column d = lr + 16*i
+        for (int r = rsub; r < RB; r += 16) {
             const int b = row0 + r;
             const bool valid = b < a.B;
-            float mu[LAT_DS], e[LAT_DS], lvv[LAT_DS];
-            bool ok[LAT_DS];
+            float mu[DSL], e[DSL], lvv[DSL];
+            bool ok[DSL];
             float lvsum = 0.f;
 #pragma unroll
-            for (int i = 0; i < LAT_DS; ++i) {
-                const int d = lane + 64 * i;
+            for (int i = 0; i < DSL; ++i) {
+                const int d = lr + 16 * i;
                 ok[i] = d < dc;
                 mu[i] = 0.f; e[i] = 0.f; lvv[i] = 0.f;
                 if (ok[i]) {
@@ -165,14 +177,16 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                 }
             }
             if (MODE == 0) {
-                float gm[LAT_DS] = {0.f, 0.f, 0.f, 0.f}, A[LAT_DS] = {0.f, 0.f, 0.f, 0.f};
+                float gm[DSL], A[DSL];
+#pragma unroll
+                for (int i = 0; i < DSL; ++i) { gm[i] = 0.f; A[i] = 0.f; }
                 for (int k = 0; k < K; ++k) {
                     const float wk = ws[r * K + k];
                     float part = 0.f;
 #pragma unroll
-                    for (int i = 0; i < LAT_DS; ++i) {
+                    for (int i = 0; i < DSL; ++i) {
                         if (ok[i]) {
-                            const int d = lane + 64 * i;
+                            const int d = lr + 16 * i;
                             const float ipk = t2[k * DC + d];
                             const float diff = mu[i] - t1[k * DC + d];
                             part += (e[i] + diff * diff) * ipk;
@@ -180,15 +194,15 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                             A[i] += wk * ipk;
                         }
                     }
-                    part = wave_sum(part);
-                    if (lane == 0) sk[r * K + k] += part;
+                    part = row_sum16(part);
+                    if (lr == 0) sk[r * K + k] += part;
                 }
-                lvsum = wave_sum(lvsum);
-                if (lane == 0) rowlv[r] += lvsum;
+                lvsum = row_sum16(lvsum);
+                if (lr == 0) rowlv[r] += lvsum;
 #pragma unroll
-                for (int i = 0; i < LAT_DS; ++i) {
+                for (int i = 0; i < DSL; ++i) {
                     if (ok[i]) {
-                        const int d = lane + 64 * i, dg = d0 + d;
+                        const int d = lr + 16 * i, dg = d0 + d;
                         a.gmu[(int64_t)b * a.ld_g + dg] = valid ? rB * gm[i] : 0.f;
                         a.glv[(int64_t)b * a.ld_g + dg] = valid ? rB2 * (e[i] * A[i] - 1.f) : 0.f;
                         r1[r * DC + d] = mu[i];
@@ -196,24 +210,26 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                     }
                 }
             } else {
-                float bm[LAT_DS] = {0.f, 0.f, 0.f, 0.f}, bl[LAT_DS] = {0.f, 0.f, 0.f, 0.f};
+                float bm[DSL], bl[DSL];
+#pragma unroll
+                for (int i = 0; i < DSL; ++i) { bm[i] = 0.f; bl[i] = 0.f; }
                 for (int k = 0; k < K; ++k) {
                     const float wk = ws[r * K + k];
 #pragma unroll
-                    for (int i = 0; i < LAT_DS; ++i) {
+                    for (int i = 0; i < DSL; ++i) {
                         if (ok[i]) {
-                            const int d = lane + 64 * i;
+                            const int d = lr + 16 * i;
                             bm[i] += wk * t1[k * DC + d];
                             bl[i] += wk * t2[k * DC + d];
                         }
                     }
                 }
-                float dbm[LAT_DS], dbl[LAT_DS], integ = 0.f;
+                float dbm[DSL], dbl[DSL], integ = 0.f;
 #pragma unroll
-                for (int i = 0; i < LAT_DS; ++i) {
+                for (int i = 0; i < DSL; ++i) {
                     dbm[i] = 0.f; dbl[i] = 0.f;
                     if (ok[i]) {
-                        const int d = lane + 64 * i, dg = d0 + d;
+                        const int d = lr + 16 * i, dg = d0 + d;
                         const float ib = __expf(-bl[i]);
                         const float diff = mu[i] - bm[i];
                         const float gmu = rB * diff * ib;
@@ -228,19 +244,19 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                         r2[r * DC + d] = dbl[i];
                     }
                 }
-                integ = wave_sum(integ);
-                if (lane == 0) rowlv[r] += integ;
+                integ = row_sum16(integ);
+                if (lr == 0) rowlv[r] += integ;
                 for (int k = 0; k < K; ++k) {
                     float part = 0.f;
 #pragma unroll
-                    for (int i = 0; i < LAT_DS; ++i) {
+                    for (int i = 0; i < DSL; ++i) {
                         if (ok[i]) {
-                            const int d = lane + 64 * i;
+                            const int d = lr + 16 * i;
                             part += dbm[i] * t1[k * DC + d] + dbl[i] * t2[k * DC + d];
                         }
                     }
-                    part = wave_sum(part);
-                    if (lane == 0) sk[r * K + k] += part;
+                    part = row_sum16(part);
+                    if (lr == 0) sk[r * K + k] += part;
                 }
             }
         }
@@ -275,13 +291,12 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
     }
 
     // ---- finalize rows: KL_Z, dlogits ----
-    for (int r = wave; r < RB; r += 4) {
+    for (int r = rsub; r < RB; r += 16) {
         const int b = row0 + r;
         const bool valid = b < a.B;
         const float rl = rowlv[r];
-        // pass 1: weighted sums
         float s_wdw = 0.f, s_qdq = 0.f, klz = 0.f;
-        for (int k = lane; k < K; k += 64) {
+        for (int k = lr; k < K; k += 16) {
             const float w = ws[r * K + k], q = qs[r * K + k];
             float dw;
             if (MODE == 0) {
@@ -295,13 +310,13 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
             s_wdw += w * dw;
             s_qdq += q * dq;
         }
-        s_wdw = wave_sum(s_wdw);
-        s_qdq = wave_sum(s_qdq);
-        klz = wave_sum(klz);
+        s_wdw = row_sum16(s_wdw);
+        s_qdq = row_sum16(s_qdq);
+        klz = row_sum16(klz);
         if (MODE == 1) klz = 0.5f * rl;
         if (valid) klz_acc += klz;
         const float wscale = (MODE == 1) ? 1.0f / a.temperature : 1.0f;
-        for (int k = lane; k < a.ld_dl; k += 64) {
+        for (int k = lr; k < a.ld_dl; k += 16) {
             float dl = 0.f;
             if (k < K && valid) {
                 const float w = ws[r * K + k], q = qs[r * K + k];
@@ -316,23 +331,26 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
             if (a.weights && k < K) a.weights[(int64_t)b * a.ld_w + k] = ws[r * K + k];
         }
     }
-    // block loss partials, fixed order
-    if (lane == 0) { red[wave] = klz_acc; red[4 + wave] = klc_acc; }
+    // block loss partials, fixed order over the 16 row groups
+    if (lr == 0) { red[rsub] = klz_acc; red[16 + rsub] = klc_acc; }
     __syncthreads();
     if (tid == 0) {
-        a.loss_partials[2 * blockIdx.x + 0] = (red[0] + red[1]) + (red[2] + red[3]);
-        a.loss_partials[2 * blockIdx.x + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+        float z = 0.f, c = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { z += red[i]; c += red[16 + i]; }
+        a.loss_partials[2 * blockIdx.x + 0] = z;
+        a.loss_partials[2 * blockIdx.x + 1] = c;
     }
 }
 
 static void latent_geometry(int B_pad, int D, int K, int& RB, int& DC, int& nchunks, size_t& lds_bytes) {
-    const int want = (B_pad + 511) / 512;      // aim at ~512 blocks
-    RB = 4;                                      // power of two <= 64: divides B_pad (multiple of 64)
+    const int want = (B_pad + 511) / 512;      // aim at >= 256..512 blocks
+    RB = 16;                                    // power of two in [16, 64]: divides B_pad (multiple of 64)
     while (RB < want && RB < 64) RB *= 2;
     DC = 256;
-    while (DC > 64 && DC / 2 >= D) DC /= 2;          // no wider than D rounded up to 64
+    while (DC > 16 && DC / 2 >= D) DC /= 2;     // no wider than D rounded up to a power of two >= 16
     auto bytes = [&](int dc) {
-        return sizeof(float) * ((size_t)2 * K * dc + K + (size_t)3 * RB * K + (size_t)2 * RB * dc + RB + 8);
+        return sizeof(float) * ((size_t)2 * K * dc + K + (size_t)3 * RB * K + (size_t)2 * RB * dc + RB + 32);
     };
     while (DC > 16 && bytes(DC) > 60 * 1024) DC /= 2;
     nchunks = (D + DC - 1) / DC;
@@ -343,6 +361,15 @@ int latent_nblocks(int B_pad, int D, int K) {
     int RB, DC, nc; size_t lb;
     latent_geometry(B_pad, D, K, RB, DC, nc, lb);
     return (B_pad + RB - 1) / RB;
+}
+
+template <int MODE, int DSL>
+static void latent_launch_t(hipStream_t s, const LatentLaunch& L, int nblk, size_t lb) {
+    if (lb > 64 * 1024) {
+        static bool set = false;
+        if (!set) { (void)hipFuncSetAttribute((const void*)latent_fwd_kernel<MODE, DSL>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set = true; }
+    }
+    hipLaunchKernelGGL((latent_fwd_kernel<MODE, DSL>), dim3(nblk), dim3(256), lb, s, L);
 }
 
 int latent_launch(hipStream_t s, const dmvae_latent_args* a) {
@@ -359,16 +386,18 @@ int latent_launch(hipStream_t s, const dmvae_latent_args* a) {
         return DMVAE_EUNSUPPORTED;
     }
     const int nblk = (a->B_pad + L.RB - 1) / L.RB;
-    static bool attr_set[2] = {false, false};
-    if (lb > 64 * 1024 && !attr_set[a->mode]) {
-        if (a->mode == 0) hipFuncSetAttribute((const void*)latent_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        else hipFuncSetAttribute((const void*)latent_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set[a->mode] = true;
-    }
     const double bytes = 4.0 * ((double)a->B * (6.0 * a->D + 3.0 * a->K) + 2.0 * a->K * a->D * (nblk + 1));
     ProfScope ps(s, a->mode == 0 ? "latent_fwd_exact" : "latent_fwd_relaxed", 6.0 * a->B * (double)a->K * a->D, bytes);
-    if (a->mode == 0) hipLaunchKernelGGL(latent_fwd_kernel<0>, dim3(nblk), dim3(256), lb, s, L);
-    else hipLaunchKernelGGL(latent_fwd_kernel<1>, dim3(nblk), dim3(256), lb, s, L);
+#define LAT(MODE_) \
+    switch (L.DC) { \
+        case 16: latent_launch_t<MODE_, 1>(s, L, nblk, lb); break; \
+        case 32: latent_launch_t<MODE_, 2>(s, L, nblk, lb); break; \
+        case 64: latent_launch_t<MODE_, 4>(s, L, nblk, lb); break; \
+        case 128: latent_launch_t<MODE_, 8>(s, L, nblk, lb); break; \
+        default: latent_launch_t<MODE_, 16>(s, L, nblk, lb); break; \
+    }
+    if (a->mode == 0) { LAT(0) } else { LAT(1) }
+#undef LAT
     return check_launch("latent_fwd");
 }
 

@@ -291,7 +291,8 @@ int dmvae_prof_collect(dmvae_prof_row* rows, int max_rows);   /* returns number 
 /* tuning aid: force the bf16 GEMM tile (64|128 x 64|128); (0,0) restores the heuristic */
 int dmvae_debug_set_tile(int bm, int bn);
 /* tuning aid: knob 0 = supertile height (tile rows) of the L2-friendly tile order,
- *             knob 1 = LDS ring depth (2|3) of the 128x128 tile */
+ *             knob 1 = 8-wave workgroups for the 128-row tiles (0|1),
+ *             knob 2 = per-problem tile shapes in the grouped dW grid (0 = all 64x64) */
 int dmvae_debug_set_knob(int which, int value);
 
 int dmvae_abi_version(void);

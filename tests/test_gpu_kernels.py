@@ -322,9 +322,11 @@ def oracle_latent(mean, log_var, logits, eps, gumbel, pm, plv, mode, tau, r):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("shape", [(4, 3, 5), (100, 10, 10), (200, 64, 10), (130, 300, 50), (70, 96, 130)])
+@pytest.mark.parametrize("shape", [(4, 3, 5), (100, 10, 10), (200, 64, 10), (130, 300, 50), (70, 96, 130),
+                                   (128, 256, 50), (64, 512, 256)])
 def test_latent_fwd_matches_oracle(hip, mode, shape):
-    """covers D < 64, D-chunking (D=300 -> chunks of 64), K > 64, ragged B."""
+    """covers D < 16, D-chunking (D=300 -> chunks), K > 64, ragged B, and the prior-table
+    shapes of BASELINE.json configs[3] (K=50, D=256) and configs[4] (K=256, D=512)."""
     L = hip
     B, D, K = shape
     rng = np.random.RandomState(B + D + K + mode)
