@@ -171,7 +171,11 @@ def main():
     if args.profile_steps > 0:
         torch.cuda.synchronize()
         prof_enable(True)
+        import ctypes
         for _ in range(args.profile_steps):
+            # keep the stream busy ~2 ms so the host enqueues the whole step before the GPU starts it:
+            # the event brackets then hold kernel time only (no host launch latency inside them)
+            dmvae_hip.lib.dmvae_debug_spin(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), 2000)
             eng.train_step(data, perm, use_state_cursor=True, grad_sync=None, grad_scale=1.0)
         torch.cuda.synchronize()
         rows = prof_collect()
@@ -214,9 +218,16 @@ def main():
         peak = PEAK_BF16_TFLOPS if is_gemm else PEAK_HBM_GBS
         if is_gemm and args.dtype == "fp32":
             peak = 157.3
+        traffic = None      # HBM bytes per launch from PMC counters: a separate rocprofv3 --pmc run (tools/pmc_traffic.sh)
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(dom["name"], {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
         out["roofline"] = {"kernel": dom["name"], "bound": "mfma" if is_gemm else "hbm", "achieved": round(ach, 2),
                            "peak": peak, "unit": "TFLOP/s" if is_gemm else "GB/s", "frac": round(ach / peak, 4),
-                           "traffic": None,
+                           "traffic": traffic,
                            "launches_per_step": dom["launches"] / ps,
                            "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 3),
                            "algorithmic_per_launch": (dom["flops"] if is_gemm else dom["bytes"]) / dom["launches"],

@@ -304,12 +304,12 @@ extern "C" int dmvae_plan_load_batch(dmvae_plan* p, void* stream, const float* d
 }
 
 static int fwd_dense(dmvae_plan* p, hipStream_t s, const void* A, int64_t lda, int Kdim, const PLayer& L, int N, int64_t w_col,
-                     int kind, void* out, int64_t ldo) {
+                     int kind, void* out, int64_t ldo, GemmArgs* deferred = nullptr) {
     dmvae_epilogue e;
     memset(&e, 0, sizeof(e));
     e.kind = kind; e.out = out; e.ldo = ldo; e.bias = p->buf.param + L.b_off + w_col;
     return gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_FWD, p->Bp, N, Kdim, A, lda,
-                        reinterpret_cast<const char*>(Wp(p, L.w_off + w_col)), L.ldw, &e, 1);
+                        reinterpret_cast<const char*>(Wp(p, L.w_off + w_col)), L.ldw, &e, 1, deferred);
 }
 
 static int encode_impl(dmvae_plan* p, hipStream_t s) {
@@ -322,8 +322,13 @@ static int encode_impl(dmvae_plan* p, hipStream_t s) {
         in = WS(p, p->o_enc[i]); ld = L.out_pad; kd = L.out_pad;
     }
     TRY(fwd_dense(p, s, in, ld, kd, p->zc, 2 * p->Hp, 0, DMVAE_EPI_BIAS_RELU, WS(p, p->o_hzc), 2 * p->Hp));
-    TRY(fwd_dense(p, s, WS(p, p->o_hzc), 2 * p->Hp, p->Hp, p->mv, 2 * p->Dp, 0, DMVAE_EPI_BIAS_F32, WS(p, p->o_mv), 2 * p->Dp));
-    TRY(fwd_dense(p, s, act_off(p, p->o_hzc, p->Hp), 2 * p->Hp, p->Hp, p->lg, p->Kp, 0, DMVAE_EPI_BIAS_F32, WS(p, p->o_lg), p->Kp));
+    // the two head layers [mean|log_var] = hz.Wmv and logits = hc.Wl are independent siblings:
+    // bf16 issues them as one grouped grid (each alone is 64..128 workgroups)
+    GemmArgs q[2];
+    const bool grp = p->cfg.dtype == DMVAE_BF16;
+    TRY(fwd_dense(p, s, WS(p, p->o_hzc), 2 * p->Hp, p->Hp, p->mv, 2 * p->Dp, 0, DMVAE_EPI_BIAS_F32, WS(p, p->o_mv), 2 * p->Dp, grp ? &q[0] : nullptr));
+    TRY(fwd_dense(p, s, act_off(p, p->o_hzc, p->Hp), 2 * p->Hp, p->Hp, p->lg, p->Kp, 0, DMVAE_EPI_BIAS_F32, WS(p, p->o_lg), p->Kp, grp ? &q[1] : nullptr));
+    if (grp) TRY(gemm_bf16_grouped(s, DMVAE_GEMM_FWD, q, 2));
     return 0;
 }
 
@@ -414,11 +419,11 @@ static int flush_dw(dmvae_plan* p, hipStream_t s, int group) {
 }
 
 static int dx_dense(dmvae_plan* p, hipStream_t s, const void* dY, int64_t ldy, int Kdim, int64_t w_off, int64_t ldw, int N,
-                    const void* Yfwd, int64_t ldyf, void* out, int64_t ldo) {
+                    const void* Yfwd, int64_t ldyf, void* out, int64_t ldo, GemmArgs* deferred = nullptr) {
     dmvae_epilogue e;
     memset(&e, 0, sizeof(e));
     e.kind = DMVAE_EPI_RELU_MASK; e.out = out; e.ldo = ldo; e.aux0 = Yfwd; e.ld0 = ldyf;
-    return gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_DX, p->Bp, N, Kdim, dY, ldy, Wp(p, w_off), ldw, &e, 1);
+    return gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_DX, p->Bp, N, Kdim, dY, ldy, Wp(p, w_off), ldw, &e, 1, deferred);
 }
 
 extern "C" int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_valid, const float* eps, int64_t ld_eps,
@@ -489,9 +494,15 @@ extern "C" int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_va
     // ---- backward: heads
     TRY(grad_dense(p, s, WS(p, p->o_hzc), 2 * p->Hp, p->Hp, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->mv.b_off));
     TRY(grad_dense(p, s, act_off(p, p->o_hzc, p->Hp), 2 * p->Hp, p->Hp, WS(p, p->o_dlg), p->Kp, p->Kp, p->lg.w_off, p->lg.ldw, p->lg.b_off));
-    TRY(dx_dense(p, s, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->Hp, WS(p, p->o_hzc), 2 * p->Hp, WS(p, p->o_dhzc), 2 * p->Hp));
-    TRY(dx_dense(p, s, WS(p, p->o_dlg), p->Kp, p->Kp, p->lg.w_off, p->lg.ldw, p->Hp, act_off(p, p->o_hzc, p->Hp), 2 * p->Hp,
-                 const_cast<void*>(act_off(p, p->o_dhzc, p->Hp)), 2 * p->Hp));
+    {   // d(z-hidden) and d(c-hidden): independent siblings writing the two halves of dhzc -> one grouped grid (bf16)
+        GemmArgs q[2];
+        const bool grp = dt == DMVAE_BF16;
+        TRY(dx_dense(p, s, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->Hp, WS(p, p->o_hzc), 2 * p->Hp, WS(p, p->o_dhzc), 2 * p->Hp,
+                     grp ? &q[0] : nullptr));
+        TRY(dx_dense(p, s, WS(p, p->o_dlg), p->Kp, p->Kp, p->lg.w_off, p->lg.ldw, p->Hp, act_off(p, p->o_hzc, p->Hp), 2 * p->Hp,
+                     const_cast<void*>(act_off(p, p->o_dhzc, p->Hp)), 2 * p->Hp, grp ? &q[1] : nullptr));
+        if (grp) TRY(gemm_bf16_grouped(s, DMVAE_GEMM_DX, q, 2));
+    }
     // ---- backward: trunk
     TRY(grad_dense(p, s, WS(p, p->o_enc[ne - 1]), p->Tp, p->Tp, WS(p, p->o_dhzc), 2 * p->Hp, 2 * p->Hp, p->zc.w_off, p->zc.ldw, p->zc.b_off));
     TRY(flush_dw(p, s, 1));   // heads dW group ([mean|log_var], logits, [zh|ch])
@@ -567,17 +578,22 @@ extern "C" int dmvae_gemm(void* stream, int dtype, int layout, int M, int N, int
 }
 extern "C" int dmvae_gemm_partials(int dtype, int M, int N) { return gemm_partials(dtype, M, N); }
 
-extern "C" int dmvae_gemm_grouped_dw(void* stream, int dtype, const dmvae_gemm_problem* probs, int n) {
-    DMVAE_REQUIRE(probs && n >= 1 && n <= DMVAE_MAX_GROUP, "dmvae_gemm_grouped_dw: 1..%d problems", DMVAE_MAX_GROUP);
+extern "C" int dmvae_gemm_grouped(void* stream, int dtype, int layout, const dmvae_gemm_problem* probs, int n) {
+    DMVAE_REQUIRE(probs && n >= 1 && n <= DMVAE_MAX_GROUP, "dmvae_gemm_grouped: 1..%d problems", DMVAE_MAX_GROUP);
     hipStream_t s = (hipStream_t)stream;
     std::vector<GemmArgs> q(n);
     for (int i = 0; i < n; ++i) {
         const dmvae_gemm_problem& pr = probs[i];
-        DMVAE_REQUIRE(pr.epi.kind == DMVAE_EPI_STORE_F32, "dmvae_gemm_grouped_dw: problems must use DMVAE_EPI_STORE_F32");
-        if (dtype == DMVAE_BF16) TRY(gemm_checked(s, dtype, DMVAE_GEMM_DW, pr.M, pr.N, pr.K, pr.A, pr.lda, pr.B, pr.ldb, &pr.epi, 1, &q[i]));
-        else TRY(gemm_checked(s, dtype, DMVAE_GEMM_DW, pr.M, pr.N, pr.K, pr.A, pr.lda, pr.B, pr.ldb, &pr.epi, 1));
+        if (dtype == DMVAE_BF16) TRY(gemm_checked(s, dtype, layout, pr.M, pr.N, pr.K, pr.A, pr.lda, pr.B, pr.ldb, &pr.epi, 1, &q[i]));
+        else TRY(gemm_checked(s, dtype, layout, pr.M, pr.N, pr.K, pr.A, pr.lda, pr.B, pr.ldb, &pr.epi, 1));   // f32: one launch each
     }
-    return dtype == DMVAE_BF16 ? gemm_bf16_grouped_dw(s, q.data(), n) : 0;
+    return dtype == DMVAE_BF16 ? gemm_bf16_grouped(s, layout, q.data(), n) : 0;
+}
+extern "C" int dmvae_gemm_grouped_dw(void* stream, int dtype, const dmvae_gemm_problem* probs, int n) {
+    DMVAE_REQUIRE(probs && n >= 1, "dmvae_gemm_grouped_dw: no problems");
+    for (int i = 0; i < n; ++i)
+        DMVAE_REQUIRE(probs[i].epi.kind == DMVAE_EPI_STORE_F32, "dmvae_gemm_grouped_dw: problems must use DMVAE_EPI_STORE_F32");
+    return dmvae_gemm_grouped(stream, dtype, DMVAE_GEMM_DW, probs, n);
 }
 
 extern "C" int dmvae_latent_nblocks(int B_pad, int D, int K) { return latent_nblocks(B_pad, D, K); }
@@ -643,6 +659,8 @@ extern "C" int dmvae_cast_bf16_to_f32(void* stream, const void* in, float* out, 
     return cast_launch((hipStream_t)stream, in, out, n, 0);
 }
 
+extern "C" int dmvae_debug_spin(void* stream, int microseconds) { return spin_launch((hipStream_t)stream, microseconds); }
+
 extern "C" int dmvae_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;
@@ -687,7 +705,7 @@ extern "C" int dmvae_debug_set_tile(int bm, int bn) {
 }
 
 extern "C" int dmvae_debug_set_knob(int which, int value) {
-    DMVAE_REQUIRE(which >= 0 && which <= 2, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in the grouped dW grid");
+    DMVAE_REQUIRE(which >= 0 && which <= 3, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, 3 = ring depth policy");
     gemm_bf16_set_knob(which, value);
     return 0;
 }

@@ -252,6 +252,21 @@ int gather_launch(hipStream_t s, int act_dtype, const float* data, int64_t n_row
     return check_launch("gather_rows");
 }
 
+// ---------------------------------------------------------------- profiling aid
+// Keeps the stream busy for `us` microseconds (bounded) so that the host can enqueue the
+// launches that follow before the GPU reaches them: HIP-event brackets around those launches
+// then measure kernel time, not host launch latency.  Spins on the constant 100 MHz counter.
+__global__ void spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+int spin_launch(hipStream_t s, int us) {
+    if (us < 0) us = 0;
+    if (us > 20000) us = 20000;
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, s, (unsigned long long)us * 100ull);
+    return check_launch("spin");
+}
+
 // ---------------------------------------------------------------- noise + casts
 __global__ __launch_bounds__(256) void philox_kernel(float* out, int64_t n, uint64_t seed, uint64_t step, uint32_t sid, int gumbel) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)

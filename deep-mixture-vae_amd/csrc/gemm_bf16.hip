@@ -34,6 +34,9 @@
 // on distinct bank groups).
 //
 // Block = 256 threads = 4 waves (2 x 2), BK = 64.
+#include <algorithm>
+#include <cmath>
+
 #include "kernels.h"
 
 namespace dmvae {
@@ -151,7 +154,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // workgroups of the launch when the launch is this single problem (XCD-aware remap), else 0.
 // NW = waves per workgroup: 4 (2 x 2) or 8 (4 x 2: two waves per SIMD share one tile's LDS traffic).
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW>
-__device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_raw, const int nwg, bf16_t* smem) {
+__device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_raw, const int gstart, const int nwg, bf16_t* smem) {
     constexpr bool A_KC = (LAYOUT != DMVAE_GEMM_DW);
     constexpr bool B_KC = (LAYOUT == DMVAE_GEMM_DX);
     constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
@@ -168,10 +171,17 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     // XCD-aware tile order (speed only, never correctness): workgroups are dealt round-robin
     // over the 8 XCDs, so ids b and b+8 share an L2.  Give each XCD a CONTIGUOUS run of tile
     // ids (bijective for any grid size) ...
-    int bid = bid_raw;
-    if (nwg > 0) {          // (grouped launches pass nwg = 0: their tile ids do not start at an XCD boundary)
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    // The problem owns the global workgroup ids [gstart, gstart + nwg) (gstart = 0 for a plain
+    // launch, the problem's first id inside a grouped grid).
+    int bid;
+    {
+        const int gid = gstart + bid_raw, xcd = gid & 7, gend = gstart + nwg;
+        int run0 = 0;                                    // tiles owned by the XCD labels below ours
+        for (int y = 0; y < xcd; ++y) {
+            const int first = gstart + ((y - gstart) & 7);
+            run0 += first < gend ? ((gend - 1 - first) >> 3) + 1 : 0;
+        }
+        bid = run0 + ((gid - (gstart + ((xcd - gstart) & 7))) >> 3);
     }
     // ... and walk the tiles of a run in supertiles of group_m tile-rows (column-major inside a
     // supertile): the ~32 tiles an XCD works on at one time then form a group_m x (32/group_m)
@@ -313,7 +323,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW>
 __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * (BM + BN) * BK];
-    gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW>(a, blockIdx.x, gridDim.x, smem);
+    gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW>(a, blockIdx.x, 0, gridDim.x, smem);
 }
 
 // Grouped launch: several independent GEMM problems of one layout / epilogue / tile shape in ONE
@@ -335,13 +345,26 @@ __global__ __launch_bounds__(256) void gemm_bf16_grouped_kernel(GroupedArgs g) {
     while (i + 1 < g.nprob && (int)blockIdx.x >= g.start[i + 1]) ++i;
     const int bid = (int)blockIdx.x - g.start[i];
     const int kind = g.kind[i];
-    if (kind == 0) gemm_bf16_body<128, 128, LAYOUT, EPI, 2, 4>(g.p[i], bid, 0, smem);
-    else if (kind == 1) gemm_bf16_body<128, 64, LAYOUT, EPI, 3, 4>(g.p[i], bid, 0, smem);
-    else gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, 4>(g.p[i], bid, 0, smem);
+    const int gs = g.start[i], cnt = g.start[i + 1] - gs;
+    if (kind == 0) gemm_bf16_body<128, 128, LAYOUT, EPI, 2, 4>(g.p[i], bid, gs, cnt, smem);
+    else if (kind == 1) gemm_bf16_body<128, 64, LAYOUT, EPI, 3, 4>(g.p[i], bid, gs, cnt, smem);
+    else gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, 4>(g.p[i], bid, gs, cnt, smem);
 }
 
 // ---------------------------------------------------------------- host side
-static int g_group_m = 8;                   // tuning knob (dmvae_debug_set_knob 0): supertile rows
+static int g_group_m = 0;                   // tuning knob (dmvae_debug_set_knob 0): supertile rows, 0 = automatic
+// Supertile height.  An XCD owns a run of R = tiles/8 consecutive tile ids and walks it in
+// supertiles gm tile-rows high, so its L2 sees ~gm A panels (BM x K each) and ~R/gm B panels
+// (BN x K each); fabric traffic ~ gm*BM + (R/gm)*BN is least at gm = sqrt(R*BN/BM).  Measured on
+// the step (tools/knob_ab.py 0 ...): fixed 8 -> 0.3356 ms, 4 (= this rule for N = 512) -> 0.3300 ms.
+static int auto_group_m(int tiles_m, int tiles_n, int bm, int bn) {
+    if (g_group_m > 0) return g_group_m;
+    const double R = std::max(1.0, tiles_m * (double)tiles_n / 8.0);
+    int gm = (int)(std::sqrt(R * bn / bm) + 0.5);
+    const int need = (int)((R + tiles_n - 1) / tiles_n);       // rows a run spans anyway
+    gm = std::max(gm, need);
+    return std::max(1, std::min(gm, tiles_m));
+}
 static int g_grouped_mixed = 1;             // tuning knob (dmvae_debug_set_knob 2): per-problem tiles in the grouped dW grid
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4>
 static const char* kernel_name(bool grouped) {   // the template instantiation, as rocprofv3 prints it
@@ -368,23 +391,32 @@ static int launch(hipStream_t s, const GemmArgs& a, int split) {
     return check_launch("gemm_bf16");
 }
 
-// all problems: DW layout, STORE_F32 epilogue, 64x64 tiles (the only tile every dW shape divides)
-int gemm_bf16_grouped_dw(hipStream_t s, const GemmArgs* probs, int nprob) {
-    if (nprob < 1 || nprob > DMVAE_MAX_GROUP) { set_error("dmvae_gemm_grouped: 1..%d problems", DMVAE_MAX_GROUP); return DMVAE_EINVAL; }
+// Grouped launch of n independent problems that share a layout and an epilogue kind.  Tile per
+// problem = the largest shape it divides, downgraded for the whole group while the grid would
+// not give every CU a workgroup.
+template <int LAYOUT, int EPI>
+static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob) {
+    auto best_kind = [](const GemmArgs& p) { return (p.M % 128 == 0 && p.N % 128 == 0) ? 0 : (p.M % 128 == 0 ? 1 : 2); };
+    auto tiles = [](const GemmArgs& p, int kind) { return (p.M / (kind == 2 ? 64 : 128)) * (p.N / (kind == 0 ? 128 : 64)); };
+    int floor_kind = g_grouped_mixed ? 0 : 2;
+    for (; floor_kind < 2; ++floor_kind) {
+        long total = 0;
+        for (int i = 0; i < nprob; ++i) total += tiles(probs[i], std::max(best_kind(probs[i]), floor_kind));
+        if (total >= 256) break;
+    }
     GroupedArgs g;
     g.nprob = nprob;
     int total = 0, n = 0;
     double flops = 0.0, bytes = 0.0;
     for (int kind = 0; kind < 3; ++kind) {          // large tiles first: the longest workgroups start first
         for (int i = 0; i < nprob; ++i) {
-            const int k = g_grouped_mixed == 0 ? 2 : (probs[i].M % 128 == 0 && probs[i].N % 128 == 0) ? 0 : (probs[i].M % 128 == 0 ? 1 : 2);
-            if (k != kind) continue;
-            const int bm = kind == 2 ? 64 : 128, bn = kind == 0 ? 128 : 64;
+            if (std::max(best_kind(probs[i]), floor_kind) != kind) continue;
             g.start[n] = total;
             g.kind[n] = kind;
             g.p[n] = probs[i];
-            g.p[n].group_m = g_group_m;
-            total += (probs[i].M / bm) * (probs[i].N / bn);
+            g.p[n].group_m = auto_group_m(probs[i].M / (kind == 2 ? 64 : 128), probs[i].N / (kind == 0 ? 128 : 64),
+                                          kind == 2 ? 64 : 128, kind == 0 ? 128 : 64);
+            total += tiles(probs[i], kind);
             flops += 2.0 * probs[i].M * probs[i].N * (double)probs[i].K;
             bytes += gemm_bytes(probs[i]);
             ++n;
@@ -392,18 +424,35 @@ int gemm_bf16_grouped_dw(hipStream_t s, const GemmArgs* probs, int nprob) {
     }
     for (int i = nprob; i < DMVAE_MAX_GROUP; ++i) g.kind[i] = 2;
     for (int i = nprob; i <= DMVAE_MAX_GROUP; ++i) g.start[i] = total;
-    ProfScope ps(s, kernel_name<64, 64, DMVAE_GEMM_DW, DMVAE_EPI_STORE_F32, 4>(true), flops, bytes);
-    hipLaunchKernelGGL((gemm_bf16_grouped_kernel<64, 64, DMVAE_GEMM_DW, DMVAE_EPI_STORE_F32, 4>), dim3(total), dim3(256), 0, s, g);
+    ProfScope ps(s, kernel_name<64, 64, LAYOUT, EPI, 4>(true), flops, bytes);
+    hipLaunchKernelGGL((gemm_bf16_grouped_kernel<64, 64, LAYOUT, EPI, 4>), dim3(total), dim3(256), 0, s, g);
     return check_launch("gemm_bf16_grouped");
 }
+
+// instantiated groups: the nine dW of a step (DW / STORE_F32), the sibling head layers
+// [mean|log_var] + logits (FWD / BIAS_F32) and their two dX (DX / RELU_MASK)
+int gemm_bf16_grouped(hipStream_t s, int layout, const GemmArgs* probs, int nprob) {
+    if (nprob < 1 || nprob > DMVAE_MAX_GROUP) { set_error("dmvae_gemm_grouped: 1..%d problems", DMVAE_MAX_GROUP); return DMVAE_EINVAL; }
+    const int epi = probs[0].epi.kind;
+    for (int i = 1; i < nprob; ++i)
+        if (probs[i].epi.kind != epi) { set_error("dmvae_gemm_grouped: all problems must share the epilogue kind"); return DMVAE_EINVAL; }
+    if (layout == DMVAE_GEMM_DW && epi == DMVAE_EPI_STORE_F32) return grouped_launch<DMVAE_GEMM_DW, DMVAE_EPI_STORE_F32>(s, probs, nprob);
+    if (layout == DMVAE_GEMM_FWD && epi == DMVAE_EPI_BIAS_F32) return grouped_launch<DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_F32>(s, probs, nprob);
+    if (layout == DMVAE_GEMM_DX && epi == DMVAE_EPI_RELU_MASK) return grouped_launch<DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK>(s, probs, nprob);
+    set_error("dmvae_gemm_grouped: layout %d with epilogue %d is not instantiated", layout, epi);
+    return DMVAE_EUNSUPPORTED;
+}
+int gemm_bf16_grouped_dw(hipStream_t s, const GemmArgs* probs, int nprob) { return gemm_bf16_grouped(s, DMVAE_GEMM_DW, probs, nprob); }
 
 static int g_force_tile = 0;   // debug override (dmvae_debug_set_tile): BM*1000+BN, 0 = heuristic
 void gemm_bf16_force_tile(int t) { g_force_tile = t; }
 static int g_nw8 = 1;          // tuning knob (dmvae_debug_set_knob 1): 8-wave workgroups for the 128-row tiles
+static int g_deep = 0;         // tuning knob (dmvae_debug_set_knob 3): -1 deep ring when <= 1 workgroup/CU, 0 never, 1 always
 void gemm_bf16_set_knob(int which, int v) {
-    if (which == 0) g_group_m = v < 1 ? 1 : v;
+    if (which == 0) g_group_m = v < 0 ? 0 : v;
     if (which == 1) g_nw8 = v;
     if (which == 2) g_grouped_mixed = v;
+    if (which == 3) g_deep = v;
 }
 
 // Tile choice, BM*1000+BN.  These GEMMs run at the per-CU L2->LDS streaming rate, so the figure
@@ -434,10 +483,18 @@ int gemm_bf16_tile_m(int M, int N, int split) {
 template <int LAYOUT, int EPI>
 static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split) {
     GemmArgs a = a0;
-    a.group_m = g_group_m;
-    switch (gemm_bf16_tile_m(a.M, a.N, split)) {
-        case 128128: return g_nw8 ? launch<128, 128, LAYOUT, EPI, 2, 8>(s, a, split) : launch<128, 128, LAYOUT, EPI, 2>(s, a, split);
-        case 128064: return g_nw8 ? launch<128, 64, LAYOUT, EPI, 3, 8>(s, a, split) : launch<128, 64, LAYOUT, EPI, 3>(s, a, split);
+    const int t = gemm_bf16_tile_m(a.M, a.N, split);
+    a.group_m = auto_group_m(a.M / (t / 1000), a.N / (t % 1000), t / 1000, t % 1000);
+    const long wgs = (long)(a.M / (t / 1000)) * (a.N / (t % 1000)) * split;
+    // one workgroup per CU at most -> a single deep ring (more bytes in flight); else two shallow ones
+    const bool deep = g_deep < 0 ? wgs <= 320 : g_deep == 1;
+    switch (t) {
+        case 128128:
+            if (deep) return launch<128, 128, LAYOUT, EPI, 4, 8>(s, a, split);
+            return g_nw8 ? launch<128, 128, LAYOUT, EPI, 2, 8>(s, a, split) : launch<128, 128, LAYOUT, EPI, 2>(s, a, split);
+        case 128064:
+            if (deep) return launch<128, 64, LAYOUT, EPI, 6, 8>(s, a, split);
+            return g_nw8 ? launch<128, 64, LAYOUT, EPI, 3, 8>(s, a, split) : launch<128, 64, LAYOUT, EPI, 3>(s, a, split);
         case 64128: return launch<64, 128, LAYOUT, EPI, 3>(s, a, split);
         default: return launch<64, 64, LAYOUT, EPI, 4>(s, a, split);
     }

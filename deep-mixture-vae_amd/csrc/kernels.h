@@ -16,6 +16,7 @@ struct AdamArgs {
 #define DMVAE_MAX_GROUP 16
 int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split);
 int gemm_bf16_grouped_dw(hipStream_t s, const GemmArgs* probs, int nprob);
+int gemm_bf16_grouped(hipStream_t s, int layout, const GemmArgs* probs, int nprob);
 int gemm_bf16_tile_m(int M, int N, int split);
 void gemm_bf16_force_tile(int t);
 void gemm_bf16_set_knob(int which, int v);
@@ -34,5 +35,6 @@ int gather_launch(hipStream_t s, int act_dtype, const float* data, int64_t n_row
                   int n_valid, int B_pad, void* out_act, int64_t ld_act, float* out_f32, int64_t ld_f32, int cols_pad, const void* st);
 int philox_launch(hipStream_t s, float* out, int64_t n, uint64_t seed, uint64_t step, uint32_t sid, int gumbel);
 int cast_launch(hipStream_t s, const void* in, void* out, int64_t n, int to_bf16);
+int spin_launch(hipStream_t s, int us);
 
 }  // namespace dmvae

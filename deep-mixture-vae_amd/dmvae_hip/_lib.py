@@ -22,14 +22,14 @@ GEMM_FWD, GEMM_DX, GEMM_DW = 0, 1, 2
 MAX_LAYERS = 8
 
 EXPORTS = [
-    "dmvae_gemm", "dmvae_gemm_partials", "dmvae_gemm_grouped_dw", "dmvae_latent_nblocks", "dmvae_latent_fwd",
+    "dmvae_gemm", "dmvae_gemm_partials", "dmvae_gemm_grouped_dw", "dmvae_gemm_grouped", "dmvae_latent_nblocks", "dmvae_latent_fwd",
     "dmvae_recon_fwd_bwd", "dmvae_recon_nblocks", "dmvae_colsum", "dmvae_loss_finalize",
     "dmvae_adam_tf", "dmvae_adam_finish", "dmvae_gather_rows", "dmvae_philox_normal",
     "dmvae_philox_gumbel", "dmvae_cast_f32_to_bf16", "dmvae_cast_bf16_to_f32",
     "dmvae_plan_create", "dmvae_plan_destroy", "dmvae_plan_sizes", "dmvae_plan_tensor",
     "dmvae_plan_bind", "dmvae_plan_load_batch", "dmvae_plan_forward_backward",
     "dmvae_plan_update", "dmvae_plan_encode", "dmvae_plan_decode", "dmvae_plan_view",
-    "dmvae_prof_enable", "dmvae_prof_collect", "dmvae_debug_set_tile", "dmvae_debug_set_knob", "dmvae_abi_version", "dmvae_last_error",
+    "dmvae_prof_enable", "dmvae_prof_collect", "dmvae_debug_spin", "dmvae_debug_set_tile", "dmvae_debug_set_knob", "dmvae_abi_version", "dmvae_last_error",
 ]
 
 
@@ -129,6 +129,7 @@ def _load():
         "dmvae_gemm": [vp, i32, i32, i32, i32, i32, vp, i64, vp, i64, P(Epilogue), i32],
         "dmvae_gemm_partials": [i32, i32, i32],
         "dmvae_gemm_grouped_dw": [vp, i32, P(GemmProblem), i32],
+        "dmvae_gemm_grouped": [vp, i32, i32, P(GemmProblem), i32],
         "dmvae_latent_nblocks": [i32, i32, i32],
         "dmvae_latent_fwd": [vp, P(LatentArgs)],
         "dmvae_recon_fwd_bwd": [vp, i32, i32, i32, i32, i32, i32, vp, i64, vp, i64, f32, vp, i64, vp],
@@ -154,6 +155,7 @@ def _load():
         "dmvae_plan_decode": [vp, vp, vp, i64, i32],
         "dmvae_plan_view": [vp, C.c_char_p, P(vp), P(i64), P(C.c_int32)],
         "dmvae_prof_enable": [i32],
+        "dmvae_debug_spin": [vp, i32],
         "dmvae_prof_collect": [P(ProfRow), i32],
         "dmvae_debug_set_tile": [i32, i32],
         "dmvae_debug_set_knob": [i32, i32],

@@ -107,6 +107,9 @@ typedef struct dmvae_gemm_problem {
     dmvae_epilogue epi;
 } dmvae_gemm_problem;
 int dmvae_gemm_grouped_dw(void* stream, int dtype, const dmvae_gemm_problem* probs, int n);
+/* the general form: n independent problems of one layout sharing an epilogue kind.  bf16 groups
+ * exist for (DW, STORE_F32), (FWD, BIAS_F32) and (DX, RELU_MASK); f32 issues one launch each. */
+int dmvae_gemm_grouped(void* stream, int dtype, int layout, const dmvae_gemm_problem* probs, int n);
 
 /* ---- latent kernel: softmax + reparameterisation + mixture KL + all KL gradients
  * replaces priors.py:86-89 (Z), :104-147 (KL_Z exact / relaxed), :170-181
@@ -286,6 +289,9 @@ typedef struct dmvae_prof_row {
     double bytes;   /* algorithmic */
 } dmvae_prof_row;
 int dmvae_prof_enable(int on);
+/* keeps `stream` busy for ~microseconds (<= 20 ms) so the host can run ahead of the GPU and the
+ * event brackets of the following launches contain no host launch latency */
+int dmvae_debug_spin(void* stream, int microseconds);
 int dmvae_prof_collect(dmvae_prof_row* rows, int max_rows);   /* returns number of rows */
 
 /* tuning aid: force the bf16 GEMM tile (64|128 x 64|128); (0,0) restores the heuristic */
