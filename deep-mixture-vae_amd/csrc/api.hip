@@ -660,6 +660,11 @@ extern "C" int dmvae_cast_bf16_to_f32(void* stream, const void* in, float* out, 
 }
 
 extern "C" int dmvae_debug_spin(void* stream, int microseconds) { return spin_launch((hipStream_t)stream, microseconds); }
+extern "C" int dmvae_debug_stamps(void** device_ptr) {
+    if (!device_ptr) return DMVAE_EINVAL;
+    *device_ptr = gemm_bf16_stamps();
+    return *device_ptr ? 0 : DMVAE_ESTATE;
+}
 
 extern "C" int dmvae_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -36,8 +36,18 @@
 // Block = 256 threads = 4 waves (2 x 2), BK = 64.
 #include <algorithm>
 #include <cmath>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <vector>
 
 #include "kernels.h"
+
+// Measurement-only builds (tools/ablate.sh -> a separately named .so, never the product library):
+// 1 = no MFMA, 2 = no LDS fragment reads, 3 = no global->LDS loads in the K loop, 4 = 1 + 2.
+#ifndef DMVAE_ABLATE
+#define DMVAE_ABLATE 0
+#endif
 
 namespace dmvae {
 
@@ -58,10 +68,12 @@ __device__ __forceinline__ int swz_nc(int k, int chunk) {
 // tile; loop invariant, computed once.
 //   KC : tile [R rows][64 k]   : a wave instruction covers 8 rows x 128 B
 //   !KC: tile [64 k][R cols]   : R = 128: 4 k-rows x 256 B;  R = 64: 8 k-rows x 128 B
-template <int R, bool KC, int NW>
-__device__ __forceinline__ void stage_offsets(int64_t ld, int wave, int lane, unsigned (&off)[R / (8 * NW)]) {
+// BKT = K depth of the tile: 64, or 32 for the n-contiguous (dW) operands only (half the k-rows).
+template <int R, bool KC, int NW, int BKT>
+__device__ __forceinline__ void stage_offsets(int64_t ld, int wave, int lane, unsigned (&off)[R * BKT / (512 * NW)]) {
+    static_assert(BKT == 64 || !KC, "a k-contiguous tile row is 64 elements");
 #pragma unroll
-    for (int i = 0; i < R / (8 * NW); ++i) {
+    for (int i = 0; i < R * BKT / (512 * NW); ++i) {
         int row, c;
         if constexpr (KC) {
             row = i * (8 * NW) + wave * 8 + (lane >> 3);
@@ -153,15 +165,17 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // One output tile of one GEMM problem.  bid_raw = tile id within the problem, nwg = number of
 // workgroups of the launch when the launch is this single problem (XCD-aware remap), else 0.
 // NW = waves per workgroup: 4 (2 x 2) or 8 (4 x 2: two waves per SIMD share one tile's LDS traffic).
-template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW>
+// BKT = K depth of one ring slot (64; 32 is available to the dW layout: a 128x128 tile then gets a
+// 4-slot ring in the same 64 KiB, i.e. 48 KiB instead of 32 KiB in flight).
+template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW, int BKT = BK>
 __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_raw, const int gstart, const int nwg, bf16_t* smem) {
     constexpr bool A_KC = (LAYOUT != DMVAE_GEMM_DW);
     constexpr bool B_KC = (LAYOUT == DMVAE_GEMM_DX);
-    constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
+    constexpr int A_ELEMS = BM * BKT, B_ELEMS = BN * BKT, STAGE = A_ELEMS + B_ELEMS;
     constexpr int WM = NW / 2;                       // waves along M (2 along N)
     constexpr int TM = BM / (16 * WM), TN = BN / 32; // 16x16 tiles per wave (wave tile = BM/WM x BN/2)
-    constexpr int LOADS = (BM + BN) / (8 * NW);      // LDS-DMA instructions per lane per K tile
-    static_assert(NSTAGE >= 2 && NSTAGE <= 8 && LOADS * (NSTAGE - 2) <= 63, "ring depth / vmcnt range");
+    constexpr int LOADS = (BM + BN) * BKT / (512 * NW);   // LDS-DMA instructions per lane per K tile
+    static_assert(NSTAGE >= 2 && NSTAGE <= 8 && LOADS * (NSTAGE - 1) <= 63, "ring depth / vmcnt range");
     // smem: NSTAGE * STAGE elements, the kernel's ONLY LDS object (owned by the __global__ wrapper)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -196,14 +210,14 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = blockIdx.y * a.k_split;
-    const int nk = a.k_split / BK;
+    const int nk = a.k_split / BKT;
 
     const bf16_t* Ag = reinterpret_cast<const bf16_t*>(a.A);
     const bf16_t* Bg = reinterpret_cast<const bf16_t*>(a.B);
     Ag += A_KC ? ((int64_t)m0 * a.lda + kbeg) : ((int64_t)kbeg * a.lda + m0);
     Bg += B_KC ? ((int64_t)n0 * a.ldb + kbeg) : ((int64_t)kbeg * a.ldb + n0);
-    const int64_t stepA = A_KC ? (int64_t)BK : (int64_t)BK * a.lda;
-    const int64_t stepB = B_KC ? (int64_t)BK : (int64_t)BK * a.ldb;
+    const int64_t stepA = A_KC ? (int64_t)BKT : (int64_t)BKT * a.lda;
+    const int64_t stepB = B_KC ? (int64_t)BKT : (int64_t)BKT * a.ldb;
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -222,12 +236,12 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_bits);
 
     // loop-invariant per-lane addressing: global source byte offsets and LDS fragment offsets
-    unsigned goA[BM / (8 * NW)], goB[BN / (8 * NW)];
-    stage_offsets<BM, A_KC, NW>(a.lda, wave, lane, goA);
-    stage_offsets<BN, B_KC, NW>(a.ldb, wave, lane, goB);
-    unsigned short foA[BK / 32][TM][2], foB[BK / 32][TN][2];
+    unsigned goA[BM * BKT / (512 * NW)], goB[BN * BKT / (512 * NW)];
+    stage_offsets<BM, A_KC, NW, BKT>(a.lda, wave, lane, goA);
+    stage_offsets<BN, B_KC, NW, BKT>(a.ldb, wave, lane, goB);
+    unsigned short foA[BKT / 32][TM][2], foB[BKT / 32][TN][2];
 #pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
+    for (int ks = 0; ks < BKT / 32; ++ks) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) frag_offsets<BM, A_KC>(wm * (BM / WM) + i * 16, ks, lane, foA[ks][i][0], foA[ks][i][1]);
 #pragma unroll
@@ -245,59 +259,115 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
         glds_tile(Ag + tc * stepA, goA, s, 1024u * NW);
         glds_tile(Bg + tc * stepB, goB, s + 2u * A_ELEMS, 1024u * NW);
     };
-    auto compute = [&](int slot) {
+    // fragments of K sub-step ks (32 deep) of ring slot `slot`
+    auto rd = [&](int slot, int ks, bf16x8 (&af)[TM], bf16x8 (&bfr)[TN]) {
         const bf16_t* As = smem + slot * STAGE;
         const bf16_t* Bs = As + A_ELEMS;
+#if DMVAE_ABLATE == 2 || DMVAE_ABLATE == 4      // tools/ablate.sh: no LDS reads
 #pragma unroll
-        for (int ks = 0; ks < BK / 32; ++ks) {
-            bf16x8 af[TM], bfr[TN];
+        for (int i = 0; i < TM; ++i) af[i] = ones;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = read_frag<A_KC>(As, foA[ks][i][0], foA[ks][i][1]);
+        for (int j = 0; j < TN; ++j) bfr[j] = ones;
+#else
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j] = read_frag<B_KC>(Bs, foB[ks][j][0], foB[ks][j][1]);
+        for (int i = 0; i < TM; ++i) af[i] = read_frag<A_KC>(As, foA[ks][i][0], foA[ks][i][1]);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) bfr[j] = read_frag<B_KC>(Bs, foB[ks][j][0], foB[ks][j][1]);
+#endif
+    };
+    auto mma = [&](const bf16x8 (&af)[TM], const bf16x8 (&bfr)[TN]) {
+#if DMVAE_ABLATE == 1 || DMVAE_ABLATE == 4      // no MFMA (fragments still read)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    // operands swapped: D[row = n][col = m] -> each lane owns 4 consecutive n of one m
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-            if constexpr (DW) {
-                if (do_bias) {
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[i]));
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) bacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], ones, bacc[j], 0, 0, 0);
-                }
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bfr[j]));
+#else
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                // operands swapped: D[row = n][col = m] -> each lane owns 4 consecutive n of one m
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+#endif
+        if constexpr (DW) {
+            if (do_bias) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], ones, bacc[j], 0, 0, 0);
             }
         }
     };
 
+    // Software pipeline over the two 32-deep sub-steps of a K tile, fragments double-buffered in
+    // registers: the LDS reads of the NEXT sub-step are issued before the MFMAs of the current
+    // one, so a wave alone on its SIMD (no second resident workgroup to hide behind) keeps the
+    // matrix core fed.  Per K tile kt (slot s):
+    //     read f1 <- (s, ks 1) | mma f0 | lgkmcnt(0): slot s is now fully in registers
+    //     vmcnt: tile kt+1 landed | barrier: ... for every wave, and every wave is done with slot s
+    //     refill slot s with tile kt+NSTAGE | read f0 <- (s+1, ks 0) | mma f1
+    // NSTAGE tiles are in flight after the prologue, NSTAGE-1 while a tile is multiplied.
+    static_assert(BKT == 64, "the pipelined loop handles two 32-deep sub-steps per ring slot");
+    bf16x8 f0a[TM], f0b[TN], f1a[TM], f1b[TN];
 #pragma unroll
-    for (int t = 0; t < NSTAGE - 1; ++t) issue(t, t);          // prologue: NSTAGE-1 tiles in flight
-
+    for (int t = 0; t < NSTAGE; ++t) issue(t, t);
+    wait_vmcnt<LOADS*(NSTAGE - 1)>();                           // tile 0 has landed (this wave's share)
+    __builtin_amdgcn_s_barrier();
+    rd(0, 0, f0a, f0b);
     for (int kt = 0; kt < nk; kt += NSTAGE) {
 #pragma unroll
         for (int s = 0; s < NSTAGE; ++s) {                      // ring slot s is a compile-time constant here
             if (kt + s < nk) {
-                wait_vmcnt<LOADS*(NSTAGE - 2)>();               // tile kt+s has landed (this wave's share)
-                __builtin_amdgcn_s_barrier();                   // ... every wave's share; all waves are done with the slot refilled next
-                issue(kt + s + NSTAGE - 1, (s + NSTAGE - 1) % NSTAGE);   // refill the slot read in the previous step
-                compute(s);
+                rd(s, 1, f1a, f1b);
+                mma(f0a, f0b);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wait_vmcnt<LOADS*(NSTAGE - 2)>();               // tile kt+s+1 has landed (this wave's share)
+                __builtin_amdgcn_s_barrier();
+#if DMVAE_ABLATE == 3                            // tools/ablate.sh: no global loads in the K loop
+                if (kt + s + NSTAGE >= nk)
+#endif
+                issue(kt + s + NSTAGE, s);
+                if (kt + s + 1 < nk) rd((s + 1) % NSTAGE, 0, f0a, f0b);
+                mma(f1a, f1b);
             }
         }
     }
     wait_vmcnt<0>();                                            // drain the clamped tail loads before LDS is reused / the wave ends
     __builtin_amdgcn_s_barrier();
 
+    // Epilogue through LDS.  The MFMA result map gives a lane 4 consecutive n of ONE row and its 15
+    // neighbours 15 OTHER rows: stored straight from the accumulators a wave instruction touches
+    // 16 rows x 32 B (bf16) -- partial-line writes (and mask / target reads) that ran the
+    // epilogue at ~1.4 TB/s.  The fp32 tile is instead parked in the (now idle) ring, 16-byte
+    // chunk index XOR (row & 7) (conflict-free ds_write_b128 / ds_read_b128), and re-read
+    // row-contiguous: a wave then covers whole 256..512-byte row segments.
     float loss = 0.f;
     const int li = lane & 15, g = lane >> 4;
+    constexpr int CH = BN / 4, NT = 64 * NW;
+    static_assert(BM * BN * 4 <= NSTAGE * STAGE * 2, "fp32 tile must fit in the ring");
+    float* ct = reinterpret_cast<float*>(smem);
+#if DMVAE_ABLATE != 5
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int m = m0 + wm * (BM / WM) + i * 16 + li;
-            const int n = n0 + wn * (BN / 2) + j * 16 + g * 4;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            epilogue_quad<EPI, bf16_t>(a.epi, m, n, v, loss);
+            const int ml = wm * (BM / WM) + i * 16 + li;
+            const int c = (wn * (BN / 2) + j * 16) / 4 + g;
+            *reinterpret_cast<f32x4*>(ct + ml * BN + ((c ^ (ml & 7)) << 2)) = acc[i][j];
         }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < BM * CH / NT; ++q) {
+        const int idx = q * NT + tid;
+        const int ml = idx / CH, c = idx % CH;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(ct + ml * BN + ((c ^ (ml & 7)) << 2));
+        float v[4] = {t[0], t[1], t[2], t[3]};
+        epilogue_quad<EPI, bf16_t>(a.epi, m0 + ml, n0 + c * 4, v, loss);
+    }
+#else
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
+#endif
     if constexpr (DW) {
         if (do_bias && wm == 0 && li == 0) {      // D[row = n][col = any m]: column 0 of the wm == 0 waves writes
             float* db = reinterpret_cast<float*>(a.epi.out2);
@@ -315,6 +385,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     }
     if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
         float* red = reinterpret_cast<float*>(smem);
+        __syncthreads();                                         // every wave is done reading the parked tile
         const float t = block_sum_waves<NW>(loss, red);
         if (tid == 0) a.epi.partials[bid_raw] = t;
     }
@@ -330,6 +401,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmArgs a) {
 // grid (the nine dW = X^T dY products of a training step: each alone fills a fraction of the 256
 // CUs, together they keep every CU at two resident workgroups).  Problem i owns the workgroups
 // [start[i], start[i+1]).
+__device__ unsigned long long g_stamps[2048 * 4];   // written by DMVAE_ABLATE == 6 builds only
+void* gemm_bf16_stamps() {
+    void* p = nullptr;
+    return hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps)) == hipSuccess ? p : nullptr;
+}
 struct GroupedArgs {
     int nprob;
     int kind[DMVAE_MAX_GROUP];
@@ -346,9 +422,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_grouped_kernel(GroupedArgs g) {
     const int bid = (int)blockIdx.x - g.start[i];
     const int kind = g.kind[i];
     const int gs = g.start[i], cnt = g.start[i + 1] - gs;
+#if DMVAE_ABLATE == 6     // placement / timeline stamps of every workgroup (tools/stamps.py)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // (a 4-slot ring of K depth 32 in the same 64 KiB was measured for the 128x128 dW tiles: no gain)
     if (kind == 0) gemm_bf16_body<128, 128, LAYOUT, EPI, 2, 4>(g.p[i], bid, gs, cnt, smem);
     else if (kind == 1) gemm_bf16_body<128, 64, LAYOUT, EPI, 3, 4>(g.p[i], bid, gs, cnt, smem);
     else gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, 4>(g.p[i], bid, gs, cnt, smem);
+#if DMVAE_ABLATE == 6
+    if (threadIdx.x == 0 && blockIdx.x < 2048) {
+        unsigned long long* st = g_stamps + 4 * blockIdx.x;
+        st[0] = t0;
+        st[1] = __builtin_amdgcn_s_memrealtime();
+        st[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_ID | XCC_ID
+        st[3] = ((unsigned long long)LAYOUT << 32) | (unsigned)kind;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- host side
@@ -365,7 +454,7 @@ static int auto_group_m(int tiles_m, int tiles_n, int bm, int bn) {
     gm = std::max(gm, need);
     return std::max(1, std::min(gm, tiles_m));
 }
-static int g_grouped_mixed = 1;             // tuning knob (dmvae_debug_set_knob 2): per-problem tiles in the grouped dW grid
+static int g_grouped_mixed = 1;             // tuning knob (dmvae_debug_set_knob 2): 0 all 64x64, 1 planned per-problem tiles, 2 largest tile each shape divides
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4>
 static const char* kernel_name(bool grouped) {   // the template instantiation, as rocprofv3 prints it
     static char nm[2][64];
@@ -398,29 +487,68 @@ template <int LAYOUT, int EPI>
 static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob) {
     auto best_kind = [](const GemmArgs& p) { return (p.M % 128 == 0 && p.N % 128 == 0) ? 0 : (p.M % 128 == 0 ? 1 : 2); };
     auto tiles = [](const GemmArgs& p, int kind) { return (p.M / (kind == 2 ? 64 : 128)) * (p.N / (kind == 0 ? 128 : 64)); };
-    int floor_kind = g_grouped_mixed ? 0 : 2;
-    for (; floor_kind < 2; ++floor_kind) {
-        long total = 0;
-        for (int i = 0; i < nprob; ++i) total += tiles(probs[i], std::max(best_kind(probs[i]), floor_kind));
-        if (total >= 256) break;
+    // bytes one workgroup of this kind streams into LDS: these kernels run at the per-CU L2->LDS
+    // intake rate (~70 GB/s), so a workgroup's duration is proportional to it
+    auto wg_bytes = [](const GemmArgs& p, int kind) { return 2.0 * ((kind == 2 ? 64 : 128) + (kind == 0 ? 128 : 64)) * (double)p.K; };
+    // Tile plan.  Every workgroup is resident at once (<= 2 per CU) and the dispatcher deals them
+    // breadth-first in launch order (measured, tools/stamps.py): launched longest-first, workgroup
+    // j lands on CU j mod 256, so CU c streams s[c] + s[c+256] + ... bytes.  Every problem may use
+    // the largest tile its shape divides or a smaller one (more, shorter workgroups that pack the
+    // CUs' second slots evenly): take the assignment with the least-loaded busiest CU, ties to
+    // the fewest bytes in total.  <= 3^nprob candidates, searched once per set of shapes.
+    int kinds[DMVAE_MAX_GROUP];
+    for (int i = 0; i < nprob; ++i) kinds[i] = g_grouped_mixed ? best_kind(probs[i]) : 2;
+    if (g_grouped_mixed == 1) {
+        static std::mutex mu;
+        static std::map<std::vector<int>, std::vector<int>> memo;
+        std::vector<int> key;
+        for (int i = 0; i < nprob; ++i) { key.push_back(probs[i].M); key.push_back(probs[i].N); key.push_back(probs[i].K); }
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = memo.find(key);
+        if (it == memo.end()) {
+            std::vector<int> cur(kinds, kinds + nprob), best = cur;
+            double best_max = 1e300, best_sum = 1e300;
+            std::vector<double> s;
+            for (;;) {
+                s.clear();
+                double sum = 0.0;
+                for (int i = 0; i < nprob; ++i) {
+                    const int t = tiles(probs[i], cur[i]);
+                    s.insert(s.end(), (size_t)t, wg_bytes(probs[i], cur[i]));
+                    sum += t * wg_bytes(probs[i], cur[i]);
+                }
+                std::sort(s.begin(), s.end(), std::greater<double>());
+                double load[256] = {0.0}, mx = 0.0;
+                for (size_t j = 0; j < s.size(); ++j) load[j & 255] += s[j];
+                for (double l : load) mx = std::max(mx, l);
+                if (mx < best_max * 0.99 || (mx < best_max * 1.01 && sum < best_sum)) { best_max = std::min(mx, best_max); best_sum = sum; best = cur; }
+                int i = 0;                               // next assignment: odometer over [best_kind, 2]
+                while (i < nprob && cur[i] == 2) { cur[i] = kinds[i]; ++i; }
+                if (i == nprob) break;
+                ++cur[i];
+            }
+            it = memo.emplace(key, best).first;
+        }
+        for (int i = 0; i < nprob; ++i) kinds[i] = it->second[i];
     }
+    int order[DMVAE_MAX_GROUP];                      // longest workgroups first
+    for (int i = 0; i < nprob; ++i) order[i] = i;
+    std::stable_sort(order, order + nprob, [&](int x, int y) { return wg_bytes(probs[x], kinds[x]) > wg_bytes(probs[y], kinds[y]); });
     GroupedArgs g;
     g.nprob = nprob;
     int total = 0, n = 0;
     double flops = 0.0, bytes = 0.0;
-    for (int kind = 0; kind < 3; ++kind) {          // large tiles first: the longest workgroups start first
-        for (int i = 0; i < nprob; ++i) {
-            if (std::max(best_kind(probs[i]), floor_kind) != kind) continue;
-            g.start[n] = total;
-            g.kind[n] = kind;
-            g.p[n] = probs[i];
-            g.p[n].group_m = auto_group_m(probs[i].M / (kind == 2 ? 64 : 128), probs[i].N / (kind == 0 ? 128 : 64),
-                                          kind == 2 ? 64 : 128, kind == 0 ? 128 : 64);
-            total += tiles(probs[i], kind);
-            flops += 2.0 * probs[i].M * probs[i].N * (double)probs[i].K;
-            bytes += gemm_bytes(probs[i]);
-            ++n;
-        }
+    for (int o = 0; o < nprob; ++o) {
+        const int i = order[o], kind = kinds[i];
+        g.start[n] = total;
+        g.kind[n] = kind;
+        g.p[n] = probs[i];
+        g.p[n].group_m = auto_group_m(probs[i].M / (kind == 2 ? 64 : 128), probs[i].N / (kind == 0 ? 128 : 64),
+                                      kind == 2 ? 64 : 128, kind == 0 ? 128 : 64);
+        total += tiles(probs[i], kind);
+        flops += 2.0 * probs[i].M * probs[i].N * (double)probs[i].K;
+        bytes += gemm_bytes(probs[i]);
+        ++n;
     }
     for (int i = nprob; i < DMVAE_MAX_GROUP; ++i) g.kind[i] = 2;
     for (int i = nprob; i <= DMVAE_MAX_GROUP; ++i) g.start[i] = total;

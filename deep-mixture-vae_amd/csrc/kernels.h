@@ -36,5 +36,6 @@ int gather_launch(hipStream_t s, int act_dtype, const float* data, int64_t n_row
 int philox_launch(hipStream_t s, float* out, int64_t n, uint64_t seed, uint64_t step, uint32_t sid, int gumbel);
 int cast_launch(hipStream_t s, const void* in, void* out, int64_t n, int to_bf16);
 int spin_launch(hipStream_t s, int us);
+void* gemm_bf16_stamps();
 
 }  // namespace dmvae

@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401  (import order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdmvae_hip.so")
+# DMVAE_HIP_LIB: another build of the SAME library (e.g. a measurement variant from tools/ablate.sh)
+LIB_PATH = os.environ.get("DMVAE_HIP_LIB") or os.path.join(_HERE, "libdmvae_hip.so")
 
 F32, BF16 = 0, 1
 GEMM_FWD, GEMM_DX, GEMM_DW = 0, 1, 2
@@ -29,7 +30,7 @@ EXPORTS = [
     "dmvae_plan_create", "dmvae_plan_destroy", "dmvae_plan_sizes", "dmvae_plan_tensor",
     "dmvae_plan_bind", "dmvae_plan_load_batch", "dmvae_plan_forward_backward",
     "dmvae_plan_update", "dmvae_plan_encode", "dmvae_plan_decode", "dmvae_plan_view",
-    "dmvae_prof_enable", "dmvae_prof_collect", "dmvae_debug_spin", "dmvae_debug_set_tile", "dmvae_debug_set_knob", "dmvae_abi_version", "dmvae_last_error",
+    "dmvae_prof_enable", "dmvae_prof_collect", "dmvae_debug_spin", "dmvae_debug_stamps", "dmvae_debug_set_tile", "dmvae_debug_set_knob", "dmvae_abi_version", "dmvae_last_error",
 ]
 
 
@@ -156,6 +157,7 @@ def _load():
         "dmvae_plan_view": [vp, C.c_char_p, P(vp), P(i64), P(C.c_int32)],
         "dmvae_prof_enable": [i32],
         "dmvae_debug_spin": [vp, i32],
+        "dmvae_debug_stamps": [P(vp)],
         "dmvae_prof_collect": [P(ProfRow), i32],
         "dmvae_debug_set_tile": [i32, i32],
         "dmvae_debug_set_knob": [i32, i32],

@@ -293,6 +293,10 @@ int dmvae_prof_enable(int on);
  * event brackets of the following launches contain no host launch latency */
 int dmvae_debug_spin(void* stream, int microseconds);
 int dmvae_prof_collect(dmvae_prof_row* rows, int max_rows);   /* returns number of rows */
+/* measurement builds only (tools/ablate.sh 6): device pointer of the per-workgroup stamp table of the
+ * grouped GEMM kernel, 2048 x {start, end (100 MHz ticks), HW_ID<<32 | XCC_ID, layout<<32 | tile kind};
+ * the product library never writes it */
+int dmvae_debug_stamps(void** device_ptr);
 
 /* tuning aid: force the bf16 GEMM tile (64|128 x 64|128); (0,0) restores the heuristic */
 int dmvae_debug_set_tile(int bm, int bn);

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Builds measurement variants of the bf16 GEMM (DMVAE_ABLATE=1..4, see gemm_bf16.hip) into
+# deep-mixture-vae_amd/build/libdmvae_hip_abl<N>.so (git-ignored; select with DMVAE_HIP_LIB).
+# Results of an ablated library are WRONG by construction: timing only.
+set -e
+cd "$(dirname "$0")/../deep-mixture-vae_amd"
+python3 build.py > /dev/null
+for n in "$@"; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DDMVAE_ABLATE=$n -c csrc/gemm_bf16.hip -o build/gemm_bf16_abl$n.o &
+done
+wait
+for n in "$@"; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libdmvae_hip_abl$n.so build/gemm_bf16_abl$n.o build/gemm_f32.o build/latent.o build/elementwise.o build/api.o
+  echo build/libdmvae_hip_abl$n.so
+done
