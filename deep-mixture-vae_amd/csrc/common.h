@@ -25,6 +25,26 @@ __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
     return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
 }
 
+// TF-1.x Adam (base_models.py:95-110), shared by the stand-alone kernel and the dW-epilogue form so
+// that both produce the same bits: every product and sum rounded on its own (no FMA contraction).
+__device__ __forceinline__ float adam_lr_t(float lr, float b1, float b2, uint64_t t) {
+    // pow on the exact integer t; double keeps 1 - b2^t accurate for small t
+    const double b1t = pow((double)b1, (double)t), b2t = pow((double)b2, (double)t);
+    return (float)((double)lr * sqrt(1.0 - b2t) / (1.0 - b1t));
+}
+__device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, float gscale, float b1, float b2, float eps, float lr_t) {
+    // plain operators under contract(off): HIP's __fmul_rn / __fadd_rn are header functions whose * and +
+    // still carry the contract flag, so each caller fused them differently (1-ulp differences in m)
+#pragma clang fp contract(off)
+    const float gj = g * gscale;
+    const float m1 = b1 * m, m2 = (1.f - b1) * gj;
+    m = m1 + m2;
+    const float v1 = b2 * v, v2 = ((1.f - b2) * gj) * gj;
+    v = v1 + v2;
+    const float num = lr_t * m, den = sqrtf(v) + eps;
+    p = p - num / den;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

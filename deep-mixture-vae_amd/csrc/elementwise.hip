@@ -14,9 +14,7 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(AdamArgs a) {
     // state given: t = adam_t + 1, or adam_t itself when the step's loss_finalize already advanced it (t_host == ~0)
     const uint64_t t = a.st ? (a.t_host == ~0ull ? a.st->adam_t : a.st->adam_t + 1) : a.t_host;
     const float lr = a.st ? a.st->lr : a.lr;
-    // powf on the exact integer t; double keeps 1-b2^t accurate for small t
-    const double b1t = pow((double)a.b1, (double)t), b2t = pow((double)a.b2, (double)t);
-    const float lr_t = (float)((double)lr * sqrt(1.0 - b2t) / (1.0 - b1t));
+    const float lr_t = adam_lr_t(lr, a.b1, a.b2, t);
     const int64_t n4 = a.n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -26,12 +24,7 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(AdamArgs a) {
         float4 v = reinterpret_cast<float4*>(a.v)[i];
         float* pp = &p.x; float* gp = &g.x; float* mp = &m.x; float* vp = &v.x;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float gj = gp[j] * a.gscale;
-            mp[j] = a.b1 * mp[j] + (1.f - a.b1) * gj;
-            vp[j] = a.b2 * vp[j] + (1.f - a.b2) * gj * gj;
-            pp[j] = pp[j] - lr_t * mp[j] / (sqrtf(vp[j]) + a.eps);
-        }
+        for (int j = 0; j < 4; ++j) adam_elem(pp[j], mp[j], vp[j], gp[j], a.gscale, a.b1, a.b2, a.eps, lr_t);
         reinterpret_cast<float4*>(a.p)[i] = p;
         reinterpret_cast<float4*>(a.m)[i] = m;
         reinterpret_cast<float4*>(a.v)[i] = v;
@@ -201,6 +194,61 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* rp, int
 int loss_finalize_launch(hipStream_t s, const float* rp, int nr, const float* lp, int nl, float inv_B, void* st, int bump_adam) {
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, rp, nr, lp, nl, inv_B, reinterpret_cast<dmvae_state*>(st), bump_adam);
     return check_launch("loss_finalize");
+}
+
+// ---------------------------------------------------------------- step finalize
+// Everything of a training step that only needs the forward pass's per-block partials, in ONE
+// launch (a kernel boundary costs ~4.6 us on this chip; the plan runs it on a side branch beside
+// the backward GEMMs):  block 0 = the loss scalars (loss_finalize_kernel's work);
+// blocks 1.. = the prior-table gradients, d/d(prior) = sum over the latent kernel's blocks of
+// their partials [nblk][ncol], summed in a FIXED order: 16 row groups x 16 columns per block, each
+// thread adds its rows in ascending order, then the 16 groups are added in ascending order.
+__global__ __launch_bounds__(256) void step_finalize_kernel(const float* rp, int nr, const float* lp, int nl, float inv_B, dmvae_state* st,
+                                                            int bump_adam, float b1, float b2, const float* part, int nblk, int ncol, float* gout) {
+    __shared__ float red[16][17];
+    if (blockIdx.x == 0) {
+        float a = 0.f, z = 0.f, c = 0.f;
+        for (int i = threadIdx.x; i < nr; i += 256) a += rp[i];
+        for (int i = threadIdx.x; i < nl; i += 256) { z += lp[2 * i]; c += lp[2 * i + 1]; }
+        float* r4 = &red[0][0];
+        const float recon = block_sum_256(a, r4) * inv_B;
+        const float klz = block_sum_256(z, r4) * inv_B;
+        const float klc = block_sum_256(c, r4) * inv_B;
+        if (threadIdx.x == 0) {
+            const float loss = recon + st->kl_ratio * (klc + klz);
+            st->last_loss = loss; st->last_recon = recon; st->last_klz = klz; st->last_klc = klc;
+            st->epoch_loss += loss * st->epoch_weight;
+            st->epoch_recon += recon * st->epoch_weight;
+            st->epoch_klz += klz * st->epoch_weight;
+            st->epoch_klc += klc * st->epoch_weight;
+            st->noise_step += 1;
+            if (bump_adam) {     // the update of this step (stand-alone or fused into the dW launch) uses t = adam_t
+                st->adam_t += 1;
+                st->lr_t = adam_lr_t(st->lr, b1, b2, st->adam_t);
+            }
+            st->batch_cursor = (st->batches_per_epoch > 0) ? (st->batch_cursor + 1) % st->batches_per_epoch : 0;
+        }
+        return;
+    }
+    const int col = (blockIdx.x - 1) * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;
+    float s = 0.f;
+    if (col < ncol)
+        for (int r = rg; r < nblk; r += 16) s += part[(int64_t)r * ncol + col];
+    red[rg][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && col < ncol) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
+        gout[col] = t;
+    }
+}
+int step_finalize_launch(hipStream_t s, const float* rp, int nr, const float* lp, int nl, float inv_B, void* st, int bump_adam,
+                         float b1, float b2, const float* part, int nblk, int ncol, float* gout) {
+    ProfScope ps(s, "step_finalize", (double)nblk * ncol, 4.0 * ((double)nblk * ncol + nr + 2.0 * nl));
+    hipLaunchKernelGGL(step_finalize_kernel, dim3(1 + (ncol + 15) / 16), dim3(256), 0, s, rp, nr, lp, nl, inv_B,
+                       reinterpret_cast<dmvae_state*>(st), bump_adam, b1, b2, part, nblk, ncol, gout);
+    return check_launch("step_finalize");
 }
 
 // ---------------------------------------------------------------- batch assembly

@@ -160,6 +160,29 @@ __device__ __forceinline__ bf16x8 read_frag(const bf16_t* s, unsigned lo, unsign
     }
 }
 
+// TF-Adam on four consecutive arena elements whose gradient g[0..3] is in registers
+// (DMVAE_EPI_ADAM, and the extra prior-table segment of the same launch).
+__device__ __forceinline__ void adam_quad(const dmvae_adam_ctx& c, int64_t off, const float (&g)[4]) {
+    const dmvae_state* st = reinterpret_cast<const dmvae_state*>(c.state);
+    const float lr_t = st->lr_t;
+    float4 p = *reinterpret_cast<const float4*>(c.param + off);
+    float4 m = *reinterpret_cast<const float4*>(c.m + off);
+    float4 v = *reinterpret_cast<const float4*>(c.v + off);
+    float* pp = &p.x; float* mp = &m.x; float* vp = &v.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) adam_elem(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);
+    *reinterpret_cast<float4*>(c.param + off) = p;
+    *reinterpret_cast<float4*>(c.m + off) = m;
+    *reinterpret_cast<float4*>(c.v + off) = v;
+    if (c.param_bf16) {
+        uint2 q;
+        q.x = pack2bf(p.x, p.y);
+        q.y = pack2bf(p.z, p.w);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(c.param_bf16) + off) = q;
+    }
+    if (c.store_grad) *reinterpret_cast<float4*>(c.grad + off) = make_float4(g[0], g[1], g[2], g[3]);
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // One output tile of one GEMM problem.  bid_raw = tile id within the problem, nwg = number of
@@ -168,7 +191,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // BKT = K depth of one ring slot (64; 32 is available to the dW layout: a 128x128 tile then gets a
 // 4-slot ring in the same 64 KiB, i.e. 48 KiB instead of 32 KiB in flight).
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW, int BKT = BK>
-__device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_raw, const int gstart, const int nwg, bf16_t* smem) {
+__device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_raw, const int gstart, const int nwg, bf16_t* smem,
+                                               const dmvae_adam_ctx* ac = nullptr) {
     constexpr bool A_KC = (LAYOUT != DMVAE_GEMM_DW);
     constexpr bool B_KC = (LAYOUT == DMVAE_GEMM_DX);
     constexpr int A_ELEMS = BM * BKT, B_ELEMS = BN * BKT, STAGE = A_ELEMS + B_ELEMS;
@@ -360,7 +384,13 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
         const int ml = idx / CH, c = idx % CH;
         const f32x4 t = *reinterpret_cast<const f32x4*>(ct + ml * BN + ((c ^ (ml & 7)) << 2));
         float v[4] = {t[0], t[1], t[2], t[3]};
-        epilogue_quad<EPI, bf16_t>(a.epi, m0 + ml, n0 + c * 4, v, loss);
+        if constexpr (EPI == DMVAE_EPI_ADAM) {
+            // the gradient quad updates the matching parameter / m / v elements (same offset in every arena)
+            const int64_t off = (reinterpret_cast<const float*>(a.epi.out) - ac->grad) + (int64_t)(m0 + ml) * a.epi.ldo + n0 + c * 4;
+            adam_quad(*ac, off, v);
+        } else {
+            epilogue_quad<EPI, bf16_t>(a.epi, m0 + ml, n0 + c * 4, v, loss);
+        }
     }
 #else
 #pragma unroll
@@ -377,6 +407,9 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
                 if constexpr (EPI == DMVAE_EPI_ATOMIC_F32) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) atomicAdd(db + n + e, bacc[j][e]);
+                } else if constexpr (EPI == DMVAE_EPI_ADAM) {
+                    float v[4] = {bacc[j][0], bacc[j][1], bacc[j][2], bacc[j][3]};
+                    adam_quad(*ac, (db - ac->grad) + n, v);
                 } else {
                     *reinterpret_cast<float4*>(db + n) = make_float4(bacc[j][0], bacc[j][1], bacc[j][2], bacc[j][3]);
                 }
@@ -411,12 +444,26 @@ struct GroupedArgs {
     int kind[DMVAE_MAX_GROUP];
     int start[DMVAE_MAX_GROUP + 1];
     GemmArgs p[DMVAE_MAX_GROUP];
+    dmvae_adam_ctx adam;      // DMVAE_EPI_ADAM launches only
 };
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE>
 __global__ __launch_bounds__(256) void gemm_bf16_grouped_kernel(GroupedArgs g) {
     // every problem takes the largest tile its shape divides (traffic per flop ~ (BM+BN)/(BM*BN)):
     // kind 0 = 128x128 / 2 stages, 1 = 128x64 / 3, 2 = 64x64 / 4  -- one LDS array of the largest ring
     __shared__ __attribute__((aligned(16))) bf16_t smem[3 * (128 + 64) * BK];   // 72 KiB >= 2*(128+128)*64, 4*(64+64)*64
+    const dmvae_adam_ctx* ac = EPI == DMVAE_EPI_ADAM ? &g.adam : nullptr;
+    if constexpr (EPI == DMVAE_EPI_ADAM) {
+        if ((int)blockIdx.x >= g.start[g.nprob]) {   // the extra workgroup(s): arena segment whose gradient is already in memory
+            const int64_t n4 = g.adam.seg_n >> 2;
+            for (int64_t q = (int64_t)((int)blockIdx.x - g.start[g.nprob]) * 256 + threadIdx.x; q < n4; q += (int64_t)((int)gridDim.x - g.start[g.nprob]) * 256) {
+                const int64_t off = g.adam.seg_off + 4 * q;
+                const float4 gq = *reinterpret_cast<const float4*>(g.adam.grad + off);
+                const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
+                adam_quad(g.adam, off, gv);
+            }
+            return;
+        }
+    }
     int i = 0;
     while (i + 1 < g.nprob && (int)blockIdx.x >= g.start[i + 1]) ++i;
     const int bid = (int)blockIdx.x - g.start[i];
@@ -426,9 +473,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_grouped_kernel(GroupedArgs g) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // (a 4-slot ring of K depth 32 in the same 64 KiB was measured for the 128x128 dW tiles: no gain)
-    if (kind == 0) gemm_bf16_body<128, 128, LAYOUT, EPI, 2, 4>(g.p[i], bid, gs, cnt, smem);
-    else if (kind == 1) gemm_bf16_body<128, 64, LAYOUT, EPI, 3, 4>(g.p[i], bid, gs, cnt, smem);
-    else gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, 4>(g.p[i], bid, gs, cnt, smem);
+    if (kind == 0) gemm_bf16_body<128, 128, LAYOUT, EPI, 2, 4>(g.p[i], bid, gs, cnt, smem, ac);
+    else if (kind == 1) gemm_bf16_body<128, 64, LAYOUT, EPI, 3, 4>(g.p[i], bid, gs, cnt, smem, ac);
+    else gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, 4>(g.p[i], bid, gs, cnt, smem, ac);
 #if DMVAE_ABLATE == 6
     if (threadIdx.x == 0 && blockIdx.x < 2048) {
         unsigned long long* st = g_stamps + 4 * blockIdx.x;
@@ -468,6 +515,7 @@ static const char* kernel_name(bool grouped) {   // the template instantiation, 
 }
 static double gemm_bytes(const GemmArgs& a) {    // algorithmic: each operand once + the output once
     const int k = a.epi.kind;
+    if (k == DMVAE_EPI_ADAM) return 2.0 * ((double)a.M * a.K + (double)a.K * a.N);   // the update's bytes are added per launch
     const double osz = (k == DMVAE_EPI_STORE_F32 || k == DMVAE_EPI_ATOMIC_F32 || k == DMVAE_EPI_BIAS_F32 || k == DMVAE_EPI_BIAS_SIGMOID) ? 4.0 : 2.0;
     return 2.0 * ((double)a.M * a.K + (double)a.K * a.N) + osz * a.M * a.N;
 }
@@ -484,7 +532,7 @@ static int launch(hipStream_t s, const GemmArgs& a, int split) {
 // problem = the largest shape it divides, downgraded for the whole group while the grid would
 // not give every CU a workgroup.
 template <int LAYOUT, int EPI>
-static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob) {
+static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const dmvae_adam_ctx* ctx = nullptr) {
     auto best_kind = [](const GemmArgs& p) { return (p.M % 128 == 0 && p.N % 128 == 0) ? 0 : (p.M % 128 == 0 ? 1 : 2); };
     auto tiles = [](const GemmArgs& p, int kind) { return (p.M / (kind == 2 ? 64 : 128)) * (p.N / (kind == 0 ? 128 : 64)); };
     // bytes one workgroup of this kind streams into LDS: these kernels run at the per-CU L2->LDS
@@ -552,8 +600,18 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob) {
     }
     for (int i = nprob; i < DMVAE_MAX_GROUP; ++i) g.kind[i] = 2;
     for (int i = nprob; i <= DMVAE_MAX_GROUP; ++i) g.start[i] = total;
+    int extra = 0;
+    g.adam = dmvae_adam_ctx{};
+    if (ctx) {
+        g.adam = *ctx;
+        // the update's traffic: p, m, v read + written, the bf16 shadow written (the gradient stays in registers)
+        double elems = (double)ctx->seg_n;
+        for (int i = 0; i < nprob; ++i) elems += (double)probs[i].M * probs[i].N + (probs[i].epi.out2 ? probs[i].N : 0);
+        bytes += elems * (24.0 + (ctx->param_bf16 ? 2.0 : 0.0) + (ctx->store_grad ? 4.0 : 0.0)) + 4.0 * ctx->seg_n;
+        if (ctx->seg_n > 0) extra = (int)std::min<int64_t>(4, (ctx->seg_n / 4 + 255) / 256);
+    }
     ProfScope ps(s, kernel_name<64, 64, LAYOUT, EPI, 4>(true), flops, bytes);
-    hipLaunchKernelGGL((gemm_bf16_grouped_kernel<64, 64, LAYOUT, EPI, 4>), dim3(total), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_bf16_grouped_kernel<64, 64, LAYOUT, EPI, 4>), dim3(total + extra), dim3(256), 0, s, g);
     return check_launch("gemm_bf16_grouped");
 }
 
@@ -571,6 +629,17 @@ int gemm_bf16_grouped(hipStream_t s, int layout, const GemmArgs* probs, int npro
     return DMVAE_EUNSUPPORTED;
 }
 int gemm_bf16_grouped_dw(hipStream_t s, const GemmArgs* probs, int nprob) { return gemm_bf16_grouped(s, DMVAE_GEMM_DW, probs, nprob); }
+// the dW group with the Adam update in the epilogue (every problem's epilogue kind = DMVAE_EPI_ADAM)
+int gemm_bf16_grouped_dw_adam(hipStream_t s, const GemmArgs* probs, int nprob, const dmvae_adam_ctx& ctx) {
+    if (nprob < 1 || nprob > DMVAE_MAX_GROUP) { set_error("dmvae_gemm_grouped_dw_adam: 1..%d problems", DMVAE_MAX_GROUP); return DMVAE_EINVAL; }
+    for (int i = 0; i < nprob; ++i)
+        if (probs[i].epi.kind != DMVAE_EPI_ADAM || !probs[i].epi.out) { set_error("dmvae_gemm_grouped_dw_adam: every problem needs epilogue kind ADAM and out = its gradient address"); return DMVAE_EINVAL; }
+    if (!ctx.param || !ctx.grad || !ctx.m || !ctx.v || !ctx.state || (ctx.seg_off & 3) || (ctx.seg_n & 3) || ctx.seg_n < 0) {
+        set_error("dmvae_gemm_grouped_dw_adam: null arena / state, or a segment that is not a multiple of 4 elements");
+        return DMVAE_EINVAL;
+    }
+    return grouped_launch<DMVAE_GEMM_DW, DMVAE_EPI_ADAM>(s, probs, nprob, &ctx);
+}
 
 static int g_force_tile = 0;   // debug override (dmvae_debug_set_tile): BM*1000+BN, 0 = heuristic
 void gemm_bf16_force_tile(int t) { g_force_tile = t; }

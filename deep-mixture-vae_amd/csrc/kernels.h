@@ -31,6 +31,9 @@ int recon_nblocks(int B_pad, int I_pad);
 int recon_launch(hipStream_t s, int act_dtype, int recon_kind, int B, int B_pad, int I, int I_pad, const float* logits, int64_t ldl,
                  const float* x, int64_t ldx, float inv_B, void* dl, int64_t ldd, float* partials);
 int loss_finalize_launch(hipStream_t s, const float* rp, int nr, const float* lp, int nl, float inv_B, void* st, int bump_adam);
+int step_finalize_launch(hipStream_t s, const float* rp, int nr, const float* lp, int nl, float inv_B, void* st, int bump_adam,
+                         float b1, float b2, const float* part, int nblk, int ncol, float* gout);
+int gemm_bf16_grouped_dw_adam(hipStream_t s, const GemmArgs* probs, int nprob, const dmvae_adam_ctx& ctx);
 int gather_launch(hipStream_t s, int act_dtype, const float* data, int64_t n_rows, int dim, const int32_t* perm, int64_t first, int batch,
                   int n_valid, int B_pad, void* out_act, int64_t ld_act, float* out_f32, int64_t ld_f32, int cols_pad, const void* st);
 int philox_launch(hipStream_t s, float* out, int64_t n, uint64_t seed, uint64_t step, uint32_t sid, int gumbel);

@@ -19,11 +19,12 @@ LIB_PATH = os.environ.get("DMVAE_HIP_LIB") or os.path.join(_HERE, "libdmvae_hip.
 F32, BF16 = 0, 1
 GEMM_FWD, GEMM_DX, GEMM_DW = 0, 1, 2
 (EPI_BIAS_RELU, EPI_BIAS_F32, EPI_BIAS_RECON, EPI_RELU_MASK, EPI_LATENT,
- EPI_STORE_F32, EPI_ATOMIC_F32, EPI_BIAS_SIGMOID) = range(8)
+ EPI_STORE_F32, EPI_ATOMIC_F32, EPI_BIAS_SIGMOID, EPI_ADAM) = range(9)
 MAX_LAYERS = 8
 
 EXPORTS = [
-    "dmvae_gemm", "dmvae_gemm_partials", "dmvae_gemm_grouped_dw", "dmvae_gemm_grouped", "dmvae_latent_nblocks", "dmvae_latent_fwd",
+    "dmvae_gemm", "dmvae_gemm_partials", "dmvae_gemm_grouped_dw", "dmvae_gemm_grouped", "dmvae_gemm_grouped_dw_adam", "dmvae_plan_train_step",
+"dmvae_latent_nblocks", "dmvae_latent_fwd",
     "dmvae_recon_fwd_bwd", "dmvae_recon_nblocks", "dmvae_colsum", "dmvae_loss_finalize",
     "dmvae_adam_tf", "dmvae_adam_finish", "dmvae_gather_rows", "dmvae_philox_normal",
     "dmvae_philox_gumbel", "dmvae_cast_f32_to_bf16", "dmvae_cast_bf16_to_f32",
@@ -54,6 +55,13 @@ class GemmProblem(C.Structure):
                 ("epi", Epilogue)]
 
 
+class AdamCtx(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
+                ("param_bf16", C.c_void_p), ("state", C.c_void_p),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("epsilon", C.c_float), ("grad_scale", C.c_float),
+                ("store_grad", C.c_int32), ("reserved", C.c_int32), ("seg_off", C.c_int64), ("seg_n", C.c_int64)]
+
+
 class LatentArgs(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("B_pad", C.c_int32), ("D", C.c_int32), ("K", C.c_int32),
@@ -80,7 +88,7 @@ class State(C.Structure):
     _fields_ = [
         ("adam_t", C.c_uint64), ("noise_step", C.c_uint64),
         ("batch_cursor", C.c_uint32), ("batches_per_epoch", C.c_uint32),
-        ("kl_ratio", C.c_float), ("lr", C.c_float), ("epoch_weight", C.c_float), ("pad0", C.c_float),
+        ("kl_ratio", C.c_float), ("lr", C.c_float), ("epoch_weight", C.c_float), ("lr_t", C.c_float),
         ("epoch_loss", C.c_float), ("epoch_recon", C.c_float), ("epoch_klz", C.c_float), ("epoch_klc", C.c_float),
         ("last_loss", C.c_float), ("last_recon", C.c_float), ("last_klz", C.c_float), ("last_klc", C.c_float),
     ]
@@ -131,6 +139,8 @@ def _load():
         "dmvae_gemm_partials": [i32, i32, i32],
         "dmvae_gemm_grouped_dw": [vp, i32, P(GemmProblem), i32],
         "dmvae_gemm_grouped": [vp, i32, i32, P(GemmProblem), i32],
+        "dmvae_gemm_grouped_dw_adam": [vp, P(GemmProblem), i32, P(AdamCtx)],
+        "dmvae_plan_train_step": [vp, vp, i32, vp, i64, vp, i64, f32],
         "dmvae_latent_nblocks": [i32, i32, i32],
         "dmvae_latent_fwd": [vp, P(LatentArgs)],
         "dmvae_recon_fwd_bwd": [vp, i32, i32, i32, i32, i32, i32, vp, i64, vp, i64, f32, vp, i64, vp],

@@ -252,6 +252,18 @@ class StepEngine:
     def update(self, grad_scale=1.0):
         check(lib.dmvae_plan_update(self._plan, self._stream(), float(grad_scale)), "dmvae_plan_update")
 
+    def forward_backward_update(self, n_valid=None, eps=None, gumbel=None, inv_B=None):
+        """forward + loss + backward + Adam with the update fused into the dW launch
+        (dmvae_plan_train_step): single-process training, the gradient arena is not written."""
+        n_valid = self.max_batch if n_valid is None else int(n_valid)
+        if eps is not None:
+            assert eps.dtype == torch.float32 and eps.is_contiguous() and eps.shape == (n_valid, self.latent_dim)
+        if gumbel is not None:
+            assert gumbel.dtype == torch.float32 and gumbel.is_contiguous() and gumbel.shape == (n_valid, self.n_classes)
+        inv_B = 1.0 / n_valid if inv_B is None else float(inv_B)
+        check(lib.dmvae_plan_train_step(self._plan, self._stream(), n_valid, ptr(eps), self.latent_dim,
+                                        ptr(gumbel), self.n_classes, inv_B), "dmvae_plan_train_step")
+
     def encode(self, n_valid=None):
         n_valid = self.max_batch if n_valid is None else int(n_valid)
         check(lib.dmvae_plan_encode(self._plan, self._stream(), n_valid), "dmvae_plan_encode")
@@ -291,9 +303,17 @@ class StepEngine:
 
     # ------------------------------------------------------------ whole step, HIP graph
     def train_step(self, data, perm, n_valid=None, eps=None, gumbel=None, first=0, use_state_cursor=False,
-                   grad_sync=None, grad_scale=1.0, inv_B=None):
-        """load batch -> forward/loss/backward -> (gradient exchange) -> Adam."""
+                   grad_sync=None, grad_scale=1.0, inv_B=None, fused=None):
+        """load batch -> forward/loss/backward -> (gradient exchange) -> Adam.
+        fused (default: whenever there is no gradient exchange and grad_scale == 1): the update
+        rides in the epilogue of the dW launch; the gradient arena is then not written."""
         self.load_batch(data, perm, first, n_valid, use_state_cursor)
+        if fused is None:
+            fused = grad_sync is None and float(grad_scale) == 1.0
+        if fused:
+            assert grad_sync is None and float(grad_scale) == 1.0
+            self.forward_backward_update(n_valid, eps, gumbel, inv_B)
+            return
         self.forward_backward(n_valid, eps, gumbel, inv_B)
         if grad_sync is not None:
             grad_sync(self.grad)

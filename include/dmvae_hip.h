@@ -60,7 +60,12 @@ enum {
     DMVAE_EPI_LATENT = 4,    /* dZ = acc: out[m][n] = dZ + aux0, out[m][d_off+n] = dZ*aux2 + aux1   priors.py:86-89 backward */
     DMVAE_EPI_STORE_F32 = 5, /* out(f32) = acc            (dW, split_k == 1)                                    */
     DMVAE_EPI_ATOMIC_F32 = 6,/* out(f32) += acc via atomics (dW, split_k > 1; out pre-zeroed)                   */
-    DMVAE_EPI_BIAS_SIGMOID = 7 /* out(f32) = sigmoid(acc + bias)  reconstructed_X  base_models.py:295-296      */
+    DMVAE_EPI_BIAS_SIGMOID = 7,/* out(f32) = sigmoid(acc + bias)  reconstructed_X  base_models.py:295-296      */
+    DMVAE_EPI_ADAM = 8       /* dW only, grouped bf16 launch with a dmvae_adam_ctx: the gradient tile never
+                              * leaves the registers -- the TF-Adam update of the matching parameter / m / v
+                              * elements (same offset in every arena) is applied in the epilogue; out = the
+                              * tile's address in the GRADIENT arena (locates the offset; written only when
+                              * ctx->store_grad), out2 = the bias gradient's address there (updated likewise) */
 };
 
 typedef struct dmvae_epilogue {
@@ -110,6 +115,23 @@ int dmvae_gemm_grouped_dw(void* stream, int dtype, const dmvae_gemm_problem* pro
 /* the general form: n independent problems of one layout sharing an epilogue kind.  bf16 groups
  * exist for (DW, STORE_F32), (FWD, BIAS_F32) and (DX, RELU_MASK); f32 issues one launch each. */
 int dmvae_gemm_grouped(void* stream, int dtype, int layout, const dmvae_gemm_problem* probs, int n);
+
+/* dW GEMMs with the optimizer step fused into their epilogue (DMVAE_EPI_ADAM; bf16): replaces the
+ * tf.gradients + AdamOptimizer.apply_gradients pair of base_models.py:95-110 for every weight and
+ * bias in one launch.  The four arenas (param, grad, m, v) share one layout; t = state->adam_t
+ * (already advanced for this step).  [seg_off, seg_off + seg_n) is an extra element range of the
+ * arenas (multiple of 4 elements) whose gradient is already in `grad` -- the prior tables -- updated
+ * by one more workgroup of the same launch. */
+typedef struct dmvae_adam_ctx {
+    float* param; float* grad; float* m; float* v;
+    void* param_bf16;          /* bf16 shadow refreshed with the new parameters (may be NULL) */
+    const void* state;         /* dmvae_state: lr and adam_t                                  */
+    float beta1, beta2, epsilon, grad_scale;
+    int32_t store_grad;        /* also write the gradients to `grad`                          */
+    int32_t reserved;
+    int64_t seg_off, seg_n;
+} dmvae_adam_ctx;
+int dmvae_gemm_grouped_dw_adam(void* stream, const dmvae_gemm_problem* probs, int n, const dmvae_adam_ctx* ctx);
 
 /* ---- latent kernel: softmax + reparameterisation + mixture KL + all KL gradients
  * replaces priors.py:86-89 (Z), :104-147 (KL_Z exact / relaxed), :170-181
@@ -165,7 +187,8 @@ typedef struct dmvae_state {
     float kl_ratio;
     float lr;
     float epoch_weight;     /* 1/epoch_len: loss += batch_loss * epoch_weight  (base_models.py:130) */
-    float pad0;
+    float lr_t;             /* lr*sqrt(1-b2^t)/(1-b1^t) for t = adam_t, written when a plan step advances adam_t
+                             * (read by the fused dW + Adam epilogue; the stand-alone Adam kernel recomputes it) */
     float epoch_loss, epoch_recon, epoch_klz, epoch_klc;   /* running epoch means   */
     float last_loss, last_recon, last_klz, last_klc;       /* last batch            */
 } dmvae_state;
@@ -268,6 +291,13 @@ int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_valid,
  * dmvae_plan_forward_backward has already advanced state->adam_t for this step: every
  * forward_backward is to be followed by exactly one update. */
 int dmvae_plan_update(dmvae_plan* p, void* stream, float grad_scale);
+/* forward + loss + backward + Adam as ONE sequence with the update fused into the dW launch
+ * (single-process training on a bf16 plan: no gradient exchange between backward and update).
+ * Equivalent to dmvae_plan_forward_backward followed by dmvae_plan_update(grad_scale = 1), except
+ * that the gradient arena is not written.  f32 plans run exactly that pair. */
+int dmvae_plan_train_step(dmvae_plan* p, void* stream, int n_valid,
+                          const float* eps, int64_t ld_eps, const float* gumbel, int64_t ld_gumbel,
+                          float inv_B);
 /* inference pieces used by get_accuracy / reconstruction / sampling:
  * encode: X (loaded batch) -> mean, log_var, logits (f32, in the workspace)
  * decode: Z (f32 [n][latent_dim], caller) -> sigmoid/identity reconstruction (f32, workspace) */

@@ -138,6 +138,35 @@ def test_bf16_step_close_to_oracle(deterministic):
     assert torch.equal(eng.param_bf16, eng.param.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("mode", ["exact", "relaxed"])
+def test_fused_update_equals_backward_then_adam(mode):
+    """dmvae_plan_train_step (Adam in the epilogue of the dW launch, gradients never stored) must
+    leave exactly the bits that forward_backward + update leave: parameters, m, v, bf16 shadow,
+    step state -- over several steps, with a ragged batch among them."""
+    kw, B = dict(input_dim=784, latent_dim=64, n_classes=10), 256
+    rng = np.random.RandomState(11)
+    X = O.synthetic_images(B, 784, seed=5)
+    Xd = torch.as_tensor(X).cuda()
+    engs = [make(kw, "bf16", B, deterministic=True, seed=9, mode=mode) for _ in range(2)]
+    for step, n in enumerate((B, B, 200, B)):
+        ed = torch.as_tensor(rng.randn(n, 64).astype(np.float32)).cuda()
+        gd = torch.as_tensor(rng.gumbel(size=(n, 10)).astype(np.float32)).cuda() if mode == "relaxed" else None
+        for fused, eng in zip((False, True), engs):
+            eng.load_batch(Xd, None, 0, n)
+            if fused:
+                eng.forward_backward_update(n, ed, gd)
+            else:
+                eng.forward_backward(n, ed, gd)
+                eng.update(1.0)
+        torch.cuda.synchronize()
+        a, b = engs
+        assert a.read_state().adam_t == b.read_state().adam_t == step + 1
+        assert a.read_state().last_loss == b.read_state().last_loss
+        for name in ("param", "m", "v", "param_bf16"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (step, name)
+    assert engs[0].param.abs().sum().item() > 0
+
+
 def test_ragged_batch_and_determinism():
     """n_valid < max_batch (the short last batch of an epoch, utils.py:462-463):
     same result as an engine sized exactly; deterministic mode is bit-reproducible."""
