@@ -213,11 +213,14 @@ def main():
                           "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 2) if r["total_ms"] > 0 else 0.0,
                           "gbs": round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1) if r["total_ms"] > 0 else 0.0})
         dom = max(rows, key=lambda r: r["total_ms"])
-        is_gemm = dom["name"].startswith("gemm")
+        # which roof bounds the dominant kernel: its algorithmic intensity against the ridge point
+        # (dense MFMA peak / HBM peak = 312 flop/B for bf16).  The fused dW + Adam launch moves
+        # ~300 MB for 41 GFLOP = 137 flop/B: HBM side of the ridge.
+        peak_fl = 157.3 if args.dtype == "fp32" else PEAK_BF16_TFLOPS
+        ai = dom["flops"] / max(dom["bytes"], 1.0)
+        is_gemm = dom["name"].startswith("gemm") and ai >= peak_fl * 1e12 / (PEAK_HBM_GBS * 1e9)
         ach = (dom["flops"] if is_gemm else dom["bytes"]) / (dom["total_ms"] * 1e-3) / (1e12 if is_gemm else 1e9)
-        peak = PEAK_BF16_TFLOPS if is_gemm else PEAK_HBM_GBS
-        if is_gemm and args.dtype == "fp32":
-            peak = 157.3
+        peak = peak_fl if is_gemm else PEAK_HBM_GBS
         traffic = None      # HBM bytes per launch from PMC counters: a separate rocprofv3 --pmc run (tools/pmc_traffic.sh)
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
@@ -231,6 +234,10 @@ def main():
                            "launches_per_step": dom["launches"] / ps,
                            "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 3),
                            "algorithmic_per_launch": (dom["flops"] if is_gemm else dom["bytes"]) / dom["launches"],
+                           "flops_per_launch": dom["flops"] / dom["launches"], "bytes_per_launch": dom["bytes"] / dom["launches"],
+                           "flop_per_byte": round(ai, 1),
+                           "mfma_frac": round(dom["flops"] / (dom["total_ms"] * 1e-3) / (peak_fl * 1e12), 4),
+                           "hbm_frac": round(dom["bytes"] / (dom["total_ms"] * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
                            "method": "hipEvent pair around every launch, %d eager steps after the timed region" % args.profile_steps}
         out["kernels"] = table
         out["kernel_ms_per_step_sum"] = round(sum(t["ms_per_step"] for t in table), 4)

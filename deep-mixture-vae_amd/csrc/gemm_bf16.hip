@@ -331,6 +331,29 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     // NSTAGE tiles are in flight after the prologue, NSTAGE-1 while a tile is multiplied.
     static_assert(BKT == 64, "the pipelined loop handles two 32-deep sub-steps per ring slot");
     bf16x8 f0a[TM], f0b[TN], f1a[TM], f1b[TN];
+    // RELU_MASK (every dX GEMM): the forward activations that gate this tile are fetched NOW, in the
+    // epilogue's row-contiguous quad order, so their latency hides behind the K loop instead of
+    // standing between the last MFMA and the stores.  Issued before the first tile load: they are
+    // the oldest vector-memory operations, so the counted vmcnt waits below stay exact.
+    constexpr int NQ = BM * (BN / 4) / (64 * NW);
+    float4 target[EPI == DMVAE_EPI_BIAS_RECON ? NQ : 1];       // BIAS_RECON: likewise the f32 reconstruction targets
+    if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = q * (64 * NW) + tid;
+            const int ml = idx / (BN / 4), c = idx % (BN / 4);
+            target[q] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.epi.aux0) + (int64_t)(m0 + ml) * a.epi.ld0 + n0 + c * 4);
+        }
+    }
+    uint2 gate[EPI == DMVAE_EPI_RELU_MASK ? NQ : 1];
+    if constexpr (EPI == DMVAE_EPI_RELU_MASK) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = q * (64 * NW) + tid;
+            const int ml = idx / (BN / 4), c = idx % (BN / 4);
+            gate[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.epi.aux0) + (int64_t)(m0 + ml) * a.epi.ld0 + n0 + c * 4);
+        }
+    }
 #pragma unroll
     for (int t = 0; t < NSTAGE; ++t) issue(t, t);
     wait_vmcnt<LOADS*(NSTAGE - 1)>();                           // tile 0 has landed (this wave's share)
@@ -388,6 +411,16 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
             // the gradient quad updates the matching parameter / m / v elements (same offset in every arena)
             const int64_t off = (reinterpret_cast<const float*>(a.epi.out) - ac->grad) + (int64_t)(m0 + ml) * a.epi.ldo + n0 + c * 4;
             adam_quad(*ac, off, v);
+        } else if constexpr (EPI == DMVAE_EPI_RELU_MASK) {
+            const uint2 y = gate[q];                 // prefetched before the K loop
+            v[0] = __uint_as_float(y.x << 16) > 0.f ? v[0] : 0.f;
+            v[1] = __uint_as_float(y.x & 0xffff0000u) > 0.f ? v[1] : 0.f;
+            v[2] = __uint_as_float(y.y << 16) > 0.f ? v[2] : 0.f;
+            v[3] = __uint_as_float(y.y & 0xffff0000u) > 0.f ? v[3] : 0.f;
+            ActIO<bf16_t>::store4(a.epi.out, (int64_t)(m0 + ml) * a.epi.ldo + n0 + c * 4, v);
+        } else if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
+            const float xq[4] = {target[q].x, target[q].y, target[q].z, target[q].w};
+            epilogue_quad<EPI, bf16_t>(a.epi, m0 + ml, n0 + c * 4, v, loss, xq);
         } else {
             epilogue_quad<EPI, bf16_t>(a.epi, m0 + ml, n0 + c * 4, v, loss);
         }

@@ -66,8 +66,9 @@ __device__ __forceinline__ void xent_sigmoid(float l, float x, float& xent, floa
 }
 
 // One quad of the epilogue.  `loss` accumulates the RECON contribution.
+// xpre: RECON only, the target quad x[m][n..n+3] when the caller fetched it ahead of time.
 template <int EPI, typename ACT>
-__device__ __forceinline__ void epilogue_quad(const dmvae_epilogue& e, int m, int n, float v[4], float& loss) {
+__device__ __forceinline__ void epilogue_quad(const dmvae_epilogue& e, int m, int n, float v[4], float& loss, const float* xpre = nullptr) {
     if constexpr (EPI == DMVAE_EPI_BIAS_RELU) {
         float b[4];
         loadf4(e.bias, n, b);
@@ -89,7 +90,8 @@ __device__ __forceinline__ void epilogue_quad(const dmvae_epilogue& e, int m, in
     } else if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
         float b[4], x[4], d[4];
         loadf4(e.bias, n, b);
-        loadf4(e.aux0, (int64_t)m * e.ld0 + n, x);
+        if (xpre) { x[0] = xpre[0]; x[1] = xpre[1]; x[2] = xpre[2]; x[3] = xpre[3]; }
+        else loadf4(e.aux0, (int64_t)m * e.ld0 + n, x);
         const bool rowok = m < e.m_valid;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
