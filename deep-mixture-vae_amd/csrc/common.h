@@ -45,6 +45,13 @@ __device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g,
     p = p - num / den;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global
+// store the wave has in flight (vmcnt(0): the write acknowledgement, 2-3 us from HBM) -- wasted
+// when the stores are write-only outputs nobody in the workgroup reads back.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -451,7 +451,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     }
     if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
         float* red = reinterpret_cast<float*>(smem);
-        __syncthreads();                                         // every wave is done reading the parked tile
+        lds_barrier();                                           // every wave is done reading the parked tile (no wait for the global stores)
         const float t = block_sum_waves<NW>(loss, red);
         if (tid == 0) a.epi.partials[bid_raw] = t;
     }

@@ -8,18 +8,29 @@
 // (DMVAE_EPI_LATENT).  The [B,K,D] broadcast tensor TensorFlow materialises is
 // never formed.
 //
-// Work decomposition (HBM-bound; algorithmic bytes in DESIGN.md):
+// Work decomposition (algorithmic bytes in DESIGN.md):
 //   block = 256 threads = 4 waves, owns RB consecutive rows of the batch;
 //   prior tables (mu_k, and exp(-logvar_k) or logvar_k) are staged in LDS in
-//   D-chunks of DC columns (KL is separable in d);
-//   phase 1: SIXTEEN lanes per row (four rows per wave): lane l of a row owns
-//            columns d = l, l+16, ...; loop over k with the table row read from
-//            LDS; reductions run over 16 lanes only (4 DPP-width shuffle steps,
-//            no 64-lane ds_bpermute chains);
+//   D-chunks of DC columns (KL is separable in d); SIXTEEN lanes per row.
+//   Everything a thread needs from global memory for its first row and the
+//   first chunk is requested at the top of the kernel, before any dependent
+//   work: one memory latency instead of four in sequence (at cfg2 the kernel is
+//   pure latency: 9.7 MB in 18 us before).
+//   Barriers are lds_barrier() (LDS traffic only): __syncthreads() also drains the
+//   wave's global stores, and with five write-only output arrays per row that
+//   was 2-3 us of write-acknowledgement wait at each of four barriers
+//   (tools/latent_time.py with the DMVAE_ABLATE=7 phase stamps).
+//   phase 1a: lane l of a row owns columns d = l, l+16, ...: Z, the reparam
+//            coefficient, and the sums over k (dKL/dmean, dKL/dlog_var) -- a
+//            loop over k with private accumulators, no cross-lane traffic;
+//   phase 1b: lane l of a row owns clusters k = l, l+16, ...: the sums over d
+//            (per-(row,k) KL terms), again private accumulators reading the
+//            row's mu / e^lv from LDS -- this replaced a 16-lane shuffle
+//            reduction per (row, k, chunk), which dominated at K*D = 50*256;
 //   phase 2: threads over (k, d) pairs, loop over the block's rows held in
 //            LDS -> per-block partial of the prior-table gradients, written
-//            to [nblocks][2][K][D] and summed by dmvae_colsum in a fixed
-//            order (deterministic; no float atomics).
+//            to [nblocks][2][K][D] and summed in a fixed order by
+//            step_finalize (deterministic; no float atomics).
 #include "kernels.h"
 
 namespace dmvae {
@@ -42,21 +53,31 @@ __device__ __forceinline__ float row_max16(float v) {
     return v;
 }
 
+#ifndef DMVAE_ABLATE
+#define DMVAE_ABLATE 0
+#endif
+#if DMVAE_ABLATE == 7   // tools/latent_time.py --stamps: phase timeline of block 0 behind the loss partials (100 MHz ticks)
+#define LAT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(L.a.loss_partials + 2 * gridDim.x)[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LAT_STAMP(i) do { } while (0)
+#endif
+
 template <int MODE, int DSL>   // MODE 0 exact, 1 relaxed; DSL = columns per lane per chunk (DC = 16*DSL)
 __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
     const dmvae_latent_args& a = L.a;
+    LAT_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int K = a.K, D = a.D, RB = L.RB;
-    constexpr int DC = 16 * DSL;
-    float* t1 = lds;                  // [K][DC] prior means
-    float* t2 = t1 + K * DC;          // [K][DC] exp(-prior_log_var) (exact) | prior_log_var (relaxed)
-    float* ck = t2 + K * DC;          // [K]     sum_d prior_log_var
-    float* ws = ck + K;               // [RB][K] mixture weights (softmax or zeta); 0 for pad rows
-    float* qs = ws + RB * K;          // [RB][K] softmax(logits)
-    float* sk = qs + RB * K;          // [RB][K] exact: sum_d (e+(mu-pm)^2)*ip ; relaxed: dLoss/dzeta
-    float* r1 = sk + RB * K;          // [RB][DC] exact: mu   | relaxed: dLoss/d(bar mean)
-    float* r2 = r1 + RB * DC;         // [RB][DC] exact: e^lv | relaxed: dLoss/d(bar log_var)
-    float* rowlv = r2 + RB * DC;      // [RB] sum_d log_var (exact) | sum_d relaxed KL integrand
+    constexpr int DC = 16 * DSL, DCP = DC + 1;   // +1: rows of one column land on distinct banks (phase 1b / 2)
+    float* t1 = lds;                  // [K][DCP] prior means
+    float* t2 = t1 + K * DCP;         // [K][DCP] exp(-prior_log_var) (exact) | prior_log_var (relaxed)
+    float* ck = t2 + K * DCP;         // [K]      sum_d prior_log_var
+    float* ws = ck + K;               // [RB][K]  mixture weights (softmax or zeta); 0 for pad rows
+    float* qs = ws + RB * K;          // [RB][K]  softmax(logits)
+    float* sk = qs + RB * K;          // [RB][K]  exact: sum_d (e+(mu-pm)^2)*ip ; relaxed: dLoss/dzeta
+    float* r1 = sk + RB * K;          // [RB][DCP] exact: mu   | relaxed: dLoss/d(bar mean)
+    float* r2 = r1 + RB * DCP;        // [RB][DCP] exact: e^lv | relaxed: dLoss/d(bar log_var)
+    float* rowlv = r2 + RB * DCP;     // [RB] sum_d log_var (exact) | sum_d relaxed KL integrand
     float* red = rowlv + RB;          // [32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -69,46 +90,110 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
     const float rB = klr * a.inv_B;          // r / B
     const float rB2 = 0.5f * rB;             // r / (2B)
     const float logK = __logf((float)K);
+    const int dc0 = min(DC, D);
 
-    // ---- prologue: c_k, per-row softmax / zeta, KL_C ----
+    // ---- early global loads: tables of chunk 0, and this group's first row (logits, mean, log_var, eps)
+    constexpr int TPF = 4, KF = 4;
+    float pm_pre[TPF], plv_pre[TPF];
+#pragma unroll
+    for (int j = 0; j < TPF; ++j) {
+        const int idx = tid + 256 * j;
+        pm_pre[j] = 0.f; plv_pre[j] = 0.f;
+        if (idx < K * dc0) {
+            const int k = idx / dc0, d = idx - k * dc0;
+            pm_pre[j] = a.prior_means[(int64_t)k * D + d];
+            plv_pre[j] = a.prior_log_vars[(int64_t)k * D + d];
+        }
+    }
+    const int b0 = row0 + rsub;
+    const bool valid0 = b0 < a.B;
+    float lg_pre[KF], mu_pre[DSL], lv_pre[DSL], ep_pre[DSL];
+#pragma unroll
+    for (int i = 0; i < KF; ++i) {
+        const int k = lr + 16 * i;
+        lg_pre[i] = (valid0 && k < K) ? a.logits[(int64_t)b0 * a.ld_logits + k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < DSL; ++i) {
+        const int d = lr + 16 * i;
+        mu_pre[i] = 0.f; lv_pre[i] = 0.f; ep_pre[i] = 0.f;
+        if (valid0 && d < dc0) {
+            mu_pre[i] = a.mean[(int64_t)b0 * a.ld_mean + d];
+            lv_pre[i] = a.log_var[(int64_t)b0 * a.ld_log_var + d];
+            if (a.eps) ep_pre[i] = a.eps[(int64_t)b0 * a.ld_eps + d];
+        }
+    }
+
+    LAT_STAMP(1);
+    // ---- prologue: c_k, tables of chunk 0 into LDS, per-row softmax / zeta, KL_C ----
     for (int k = tid >> 4; k < K; k += 16) {
         float s = 0.f;
         for (int d = lr; d < D; d += 16) s += a.prior_log_vars[(int64_t)k * D + d];
         s = row_sum16(s);
         if (lr == 0) ck[k] = s;
     }
+#pragma unroll
+    for (int j = 0; j < TPF; ++j) {
+        const int idx = tid + 256 * j;
+        if (idx < K * dc0) {
+            const int k = idx / dc0, d = idx - k * dc0;
+            t1[k * DCP + d] = pm_pre[j];
+            t2[k * DCP + d] = (MODE == 0) ? __expf(-plv_pre[j]) : plv_pre[j];
+        }
+    }
+    for (int idx = tid + 256 * TPF; idx < K * dc0; idx += 256) {
+        const int k = idx / dc0, d = idx - k * dc0;
+        const float plv = a.prior_log_vars[(int64_t)k * D + d];
+        t1[k * DCP + d] = a.prior_means[(int64_t)k * D + d];
+        t2[k * DCP + d] = (MODE == 0) ? __expf(-plv) : plv;
+    }
     float klc_acc = 0.f, klz_acc = 0.f;   // per 16-lane group (all lanes of the group hold the same value)
     for (int r = rsub; r < RB; r += 16) {
+        const bool first = r == rsub;
         const int b = row0 + r;
         const bool valid = b < a.B;
-        float mx = -INFINITY, mz = -INFINITY;
-        for (int k = lr; k < K; k += 16) {
-            const float lg = valid ? a.logits[(int64_t)b * a.ld_logits + k] : 0.f;
-            mx = fmaxf(mx, lg);
-            if (MODE == 1) {
-                const float gk = !valid ? 0.f
-                    : (a.gumbel ? a.gumbel[(int64_t)b * a.ld_gumbel + k]
-                                : philox_gumbel_at(a.seed, nstep, 1u, (uint64_t)b * K + k));
-                mz = fmaxf(mz, (lg + gk) / a.temperature);
-            }
+        // this lane's clusters k = lr + 16 i: the first KF logits (and Gumbel draws) live in registers
+        float lg[KF], gk[KF];
+#pragma unroll
+        for (int i = 0; i < KF; ++i) {
+            const int k = lr + 16 * i;
+            lg[i] = first ? lg_pre[i] : ((valid && k < K) ? a.logits[(int64_t)b * a.ld_logits + k] : 0.f);
+            gk[i] = 0.f;
+            if (MODE == 1 && valid && k < K)
+                gk[i] = a.gumbel ? a.gumbel[(int64_t)b * a.ld_gumbel + k] : philox_gumbel_at(a.seed, nstep, 1u, (uint64_t)b * K + k);
         }
+        auto for_k = [&](auto&& fn) {     // fn(k, logit, gumbel) over this lane's clusters
+#pragma unroll
+            for (int i = 0; i < KF; ++i) {
+                const int k = lr + 16 * i;
+                if (k < K) fn(k, lg[i], gk[i]);
+            }
+            for (int k = lr + 16 * KF; k < K; k += 16) {
+                const float l = valid ? a.logits[(int64_t)b * a.ld_logits + k] : 0.f;
+                float g = 0.f;
+                if (MODE == 1 && valid)
+                    g = a.gumbel ? a.gumbel[(int64_t)b * a.ld_gumbel + k] : philox_gumbel_at(a.seed, nstep, 1u, (uint64_t)b * K + k);
+                fn(k, l, g);
+            }
+        };
+        float mx = -INFINITY, mz = -INFINITY;
+        for_k([&](int, float l, float g) {
+            mx = fmaxf(mx, l);
+            if (MODE == 1) mz = fmaxf(mz, (l + g) / a.temperature);
+        });
         mx = row_max16(mx);
         if (MODE == 1) mz = row_max16(mz);
         float se = 0.f, sz = 0.f;
-        for (int k = lr; k < K; k += 16) {
-            const float lg = valid ? a.logits[(int64_t)b * a.ld_logits + k] : 0.f;
-            const float ex = __expf(lg - mx);
+        for_k([&](int k, float l, float g) {
+            const float ex = __expf(l - mx);
             qs[r * K + k] = ex;
             se += ex;
             if (MODE == 1) {
-                const float gk = !valid ? 0.f
-                    : (a.gumbel ? a.gumbel[(int64_t)b * a.ld_gumbel + k]
-                                : philox_gumbel_at(a.seed, nstep, 1u, (uint64_t)b * K + k));
-                const float ez = __expf((lg + gk) / a.temperature - mz);
+                const float ez = __expf((l + g) / a.temperature - mz);
                 ws[r * K + k] = ez;
                 sz += ez;
             }
-        }
+        });
         se = row_sum16(se);
         if (MODE == 1) sz = row_sum16(sz);
         float kc = 0.f;
@@ -129,23 +214,27 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
             else reinterpret_cast<float*>(a.Z_act)[(int64_t)b * a.ld_Z + d] = 0.f;
         }
     }
-    __syncthreads();
+    lds_barrier();
+    LAT_STAMP(2);
 
     // ---- D-chunk loop ----
     for (int c = 0; c < L.nchunks; ++c) {
         const int d0 = c * DC;
         const int dc = min(DC, D - d0);
-        for (int idx = tid; idx < K * dc; idx += 256) {
-            const int k = idx / dc, d = idx - k * dc;
-            const float pmv = a.prior_means[(int64_t)k * D + d0 + d];
-            const float plv = a.prior_log_vars[(int64_t)k * D + d0 + d];
-            t1[k * DC + d] = pmv;
-            t2[k * DC + d] = (MODE == 0) ? __expf(-plv) : plv;
+        if (c > 0) {                  // chunk 0 was staged in the prologue
+            for (int idx = tid; idx < K * dc; idx += 256) {
+                const int k = idx / dc, d = idx - k * dc;
+                const float pmv = a.prior_means[(int64_t)k * D + d0 + d];
+                const float plv = a.prior_log_vars[(int64_t)k * D + d0 + d];
+                t1[k * DCP + d] = pmv;
+                t2[k * DCP + d] = (MODE == 0) ? __expf(-plv) : plv;
+            }
+            lds_barrier();
         }
-        __syncthreads();
 
-        // phase 1: sixteen lanes per row, column d = lr + 16*i
+        // phase 1a: sixteen lanes per row, column d = lr + 16*i; sums over k in private accumulators
         for (int r = rsub; r < RB; r += 16) {
+            const bool first = r == rsub && c == 0;
             const int b = row0 + r;
             const bool valid = b < a.B;
             float mu[DSL], e[DSL], lvv[DSL];
@@ -160,11 +249,11 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                     const int dg = d0 + d;
                     float z = 0.f, cl = 0.f;
                     if (valid) {
-                        mu[i] = a.mean[(int64_t)b * a.ld_mean + dg];
-                        lvv[i] = a.log_var[(int64_t)b * a.ld_log_var + dg];
+                        mu[i] = first ? mu_pre[i] : a.mean[(int64_t)b * a.ld_mean + dg];
+                        lvv[i] = first ? lv_pre[i] : a.log_var[(int64_t)b * a.ld_log_var + dg];
                         e[i] = __expf(lvv[i]);
                         const float sd = __expf(0.5f * lvv[i]);
-                        const float ep = a.eps ? a.eps[(int64_t)b * a.ld_eps + dg]
+                        const float ep = a.eps ? (first ? ep_pre[i] : a.eps[(int64_t)b * a.ld_eps + dg])
                                                : philox_normal_at(a.seed, nstep, 0u, (uint64_t)b * D + dg);
                         z = mu[i] + sd * ep;
                         cl = ep * 0.5f * sd;
@@ -180,22 +269,20 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                 float gm[DSL], A[DSL];
 #pragma unroll
                 for (int i = 0; i < DSL; ++i) { gm[i] = 0.f; A[i] = 0.f; }
+                // one wave per SIMD: nothing hides an LDS round trip, so every loop below is unrolled
+                // to keep a batch of independent reads in flight
+#pragma unroll 5
                 for (int k = 0; k < K; ++k) {
                     const float wk = ws[r * K + k];
-                    float part = 0.f;
 #pragma unroll
                     for (int i = 0; i < DSL; ++i) {
                         if (ok[i]) {
                             const int d = lr + 16 * i;
-                            const float ipk = t2[k * DC + d];
-                            const float diff = mu[i] - t1[k * DC + d];
-                            part += (e[i] + diff * diff) * ipk;
-                            gm[i] += wk * diff * ipk;
+                            const float ipk = t2[k * DCP + d];
+                            gm[i] += wk * (mu[i] - t1[k * DCP + d]) * ipk;
                             A[i] += wk * ipk;
                         }
                     }
-                    part = row_sum16(part);
-                    if (lr == 0) sk[r * K + k] += part;
                 }
                 lvsum = row_sum16(lvsum);
                 if (lr == 0) rowlv[r] += lvsum;
@@ -205,89 +292,115 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                         const int d = lr + 16 * i, dg = d0 + d;
                         a.gmu[(int64_t)b * a.ld_g + dg] = valid ? rB * gm[i] : 0.f;
                         a.glv[(int64_t)b * a.ld_g + dg] = valid ? rB2 * (e[i] * A[i] - 1.f) : 0.f;
-                        r1[r * DC + d] = mu[i];
-                        r2[r * DC + d] = e[i];
+                        r1[r * DCP + d] = mu[i];
+                        r2[r * DCP + d] = e[i];
                     }
                 }
             } else {
                 float bm[DSL], bl[DSL];
 #pragma unroll
                 for (int i = 0; i < DSL; ++i) { bm[i] = 0.f; bl[i] = 0.f; }
+#pragma unroll 5
                 for (int k = 0; k < K; ++k) {
                     const float wk = ws[r * K + k];
 #pragma unroll
                     for (int i = 0; i < DSL; ++i) {
                         if (ok[i]) {
                             const int d = lr + 16 * i;
-                            bm[i] += wk * t1[k * DC + d];
-                            bl[i] += wk * t2[k * DC + d];
+                            bm[i] += wk * t1[k * DCP + d];
+                            bl[i] += wk * t2[k * DCP + d];
                         }
                     }
                 }
-                float dbm[DSL], dbl[DSL], integ = 0.f;
+                float integ = 0.f;
 #pragma unroll
                 for (int i = 0; i < DSL; ++i) {
-                    dbm[i] = 0.f; dbl[i] = 0.f;
                     if (ok[i]) {
                         const int d = lr + 16 * i, dg = d0 + d;
                         const float ib = __expf(-bl[i]);
                         const float diff = mu[i] - bm[i];
                         const float gmu = rB * diff * ib;
+                        float dbm = 0.f, dbl = 0.f;
                         if (valid) {
                             integ += bl[i] - lvv[i] - 1.f + (e[i] + diff * diff) * ib;
-                            dbm[i] = -gmu;
-                            dbl[i] = rB2 * (1.f - (e[i] + diff * diff) * ib);
+                            dbm = -gmu;
+                            dbl = rB2 * (1.f - (e[i] + diff * diff) * ib);
                         }
                         a.gmu[(int64_t)b * a.ld_g + dg] = valid ? gmu : 0.f;
                         a.glv[(int64_t)b * a.ld_g + dg] = valid ? rB2 * (e[i] * ib - 1.f) : 0.f;
-                        r1[r * DC + d] = dbm[i];
-                        r2[r * DC + d] = dbl[i];
+                        r1[r * DCP + d] = dbm;
+                        r2[r * DCP + d] = dbl;
                     }
                 }
                 integ = row_sum16(integ);
                 if (lr == 0) rowlv[r] += integ;
-                for (int k = 0; k < K; ++k) {
-                    float part = 0.f;
-#pragma unroll
-                    for (int i = 0; i < DSL; ++i) {
-                        if (ok[i]) {
-                            const int d = lr + 16 * i;
-                            part += dbm[i] * t1[k * DC + d] + dbl[i] * t2[k * DC + d];
-                        }
-                    }
-                    part = row_sum16(part);
-                    if (lr == 0) sk[r * K + k] += part;
-                }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        LAT_STAMP(3);
 
+        // phase 1b: sixteen lanes per row, cluster k = lr + 16*j; sums over d in private accumulators
+        for (int r = rsub; r < RB; r += 16) {
+            const float* x1 = r1 + r * DCP;
+            const float* x2 = r2 + r * DCP;
+            for (int k = lr; k < K; k += 16) {
+                const float* p1 = t1 + k * DCP;
+                const float* p2 = t2 + k * DCP;
+                float s[4] = {0.f, 0.f, 0.f, 0.f};
+                int d = 0;
+                for (; d + 7 < dc; d += 8) {      // 32 independent LDS reads per trip
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (MODE == 0) {
+                            const float f = x1[d + u] - p1[d + u];
+                            s[u & 3] += (x2[d + u] + f * f) * p2[d + u];
+                        } else {
+                            s[u & 3] += x1[d + u] * p1[d + u] + x2[d + u] * p2[d + u];
+                        }
+                    }
+                }
+                for (; d < dc; ++d) {
+                    if (MODE == 0) {
+                        const float f = x1[d] - p1[d];
+                        s[0] += (x2[d] + f * f) * p2[d];
+                    } else {
+                        s[0] += x1[d] * p1[d] + x2[d] * p2[d];
+                    }
+                }
+                sk[r * K + k] += (s[0] + s[1]) + (s[2] + s[3]);     // (r, k) belongs to this lane alone
+            }
+        }
+
+        LAT_STAMP(4);
         // phase 2: prior-table gradient partials of this block, threads over (k, d)
         for (int idx = tid; idx < K * dc; idx += 256) {
             const int k = idx / dc, d = idx - k * dc;
             float a1 = 0.f, a2 = 0.f;
             if (MODE == 0) {
-                const float pmv = t1[k * DC + d], ipv = t2[k * DC + d];
+                const float pmv = t1[k * DCP + d], ipv = t2[k * DCP + d];
+#pragma unroll 8
                 for (int r = 0; r < RB; ++r) {
                     const float wk = ws[r * K + k];
-                    const float diff = r1[r * DC + d] - pmv;
+                    const float diff = r1[r * DCP + d] - pmv;
                     a1 += wk * diff;
-                    a2 += wk * (1.f - (r2[r * DC + d] + diff * diff) * ipv);
+                    a2 += wk * (1.f - (r2[r * DCP + d] + diff * diff) * ipv);
                 }
                 a1 = -rB * ipv * a1;
                 a2 = rB2 * a2;
             } else {
+#pragma unroll 8
                 for (int r = 0; r < RB; ++r) {
                     const float wk = ws[r * K + k];
-                    a1 += wk * r1[r * DC + d];
-                    a2 += wk * r2[r * DC + d];
+                    a1 += wk * r1[r * DCP + d];
+                    a2 += wk * r2[r * DCP + d];
                 }
             }
             float* o = a.dprior_partials + (int64_t)blockIdx.x * 2 * K * D;
             o[(int64_t)k * D + d0 + d] = a1;
             o[(int64_t)K * D + (int64_t)k * D + d0 + d] = a2;
         }
-        __syncthreads();
+        lds_barrier();
+        LAT_STAMP(5);
     }
 
     // ---- finalize rows: KL_Z, dlogits ----
@@ -333,7 +446,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
     }
     // block loss partials, fixed order over the 16 row groups
     if (lr == 0) { red[rsub] = klz_acc; red[16 + rsub] = klc_acc; }
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
         float z = 0.f, c = 0.f;
 #pragma unroll
@@ -341,6 +454,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
         a.loss_partials[2 * blockIdx.x + 0] = z;
         a.loss_partials[2 * blockIdx.x + 1] = c;
     }
+    LAT_STAMP(6);
 }
 
 static void latent_geometry(int B_pad, int D, int K, int& RB, int& DC, int& nchunks, size_t& lds_bytes) {
@@ -350,7 +464,7 @@ static void latent_geometry(int B_pad, int D, int K, int& RB, int& DC, int& nchu
     DC = 256;
     while (DC > 16 && DC / 2 >= D) DC /= 2;     // no wider than D rounded up to a power of two >= 16
     auto bytes = [&](int dc) {
-        return sizeof(float) * ((size_t)2 * K * dc + K + (size_t)3 * RB * K + (size_t)2 * RB * dc + RB + 32);
+        return sizeof(float) * ((size_t)2 * K * (dc + 1) + K + (size_t)3 * RB * K + (size_t)2 * RB * (dc + 1) + RB + 32);
     };
     while (DC > 16 && bytes(DC) > 60 * 1024) DC /= 2;
     nchunks = (D + DC - 1) / DC;
