@@ -21,6 +21,7 @@ dtype ("bf16" throughput / "fp32" parity), enc_layers / head_dim / dec_layers
 noise ("device" Philox | "host" NumPy stream of the reference), seed.
 """
 import math
+import os
 
 import numpy as np
 
@@ -291,12 +292,130 @@ class DeepMixtureVAE(VAE):
         _, _, logits = self.encode(data._rows[order])
         return get_clustering_accuracy(logits, data._cls[order])
 
-    # ------------------------------------------------------------------ pretraining (next row)
+    # ------------------------------------------------------------------ pretraining (base_models.py:304-423)
+    # the variables tf.get_collection(TRAINABLE_VARIABLES, scope=name + "/encoder_network/c") returns (:313-315)
+    PRIOR_VAR_LIST = ("W_ch", "b_ch", "W_logits", "b_logits")
+
     def define_pretrain_step(self, vae_lr, prior_lr):
-        raise NotImplementedError("pretraining stages (base_models.py:304-423) are a 'next' row of SURVEY.md 8f")
+        """base_models.py:304-320: two more Adam optimizers, each with its own slots --
+        vae_train_step = Adam(vae_lr).minimize(recon_loss) over every variable the
+        reconstruction depends on, prior_train_step = Adam(prior_lr).minimize(latent_loss,
+        var_list = the c-head)."""
+        self.define_train_loss()
+        self.vae_loss = "recon"
+        self._vae_lr, self._prior_lr = float(vae_lr), float(prior_lr)
+        self.vae_train_step = "adam_tf(recon_loss)"
+        self.prior_train_step = "adam_tf(latent_loss, var_list=encoder_network/c)"
+
+    def _ckpt(self, stage):
+        return os.path.join(self.path, stage, "parameters.npz") if self.path else None
+
+    def _restore(self, stage):
+        path = self._ckpt(stage)
+        if path and os.path.exists(path):
+            self.load_state_dict(dict(np.load(path)))
+            return True
+        return False
+
+    def _save(self, stage):
+        path = self._ckpt(stage)
+        if path:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            np.savez(path, **self.state_dict())
+
+    def _pretrain_epoch(self, sess, data, stage):
+        """one epoch of a pretraining stage: epsilon = 0 (so Z = mean), the stage's loss and
+        variable list; returns sum(batch_loss) / epoch_len like the reference's loops (:331-350, :395-414)."""
+        import torch
+        from dmvae_hip import GradExchange
+        eng = self._engine
+        world = sess.world_size
+        b = data.batch_size // world
+        if data.batch_size % world or b != eng.max_batch:
+            raise ValueError("batch_size %d does not match the model (%d per rank x %d ranks)" % (data.batch_size, eng.max_batch, world))
+        rows = data.device_rows(sess.device)
+        perm = self._epoch_perm(data, sess)
+        n_local = perm.numel()
+        n_full, tail = n_local // b, (n_local % b if world == 1 else 0)
+        ex = GradExchange()
+        sync = ex if ex.enabled else None
+        # recon-only objective = the full loss at kl_ratio 0: every KL gradient carries the factor r
+        eng.reset_epoch(n_full + (1 if tail else 0), kl_ratio=0.0 if stage == "vae" else 1.0, epoch_weight=1.0 / data.epoch_len)
+        zeros = {}
+
+        def noise(n):
+            if n not in zeros:
+                zeros[n] = (torch.zeros((n, self.latent_dim), dtype=torch.float32, device=sess.device),
+                            torch.zeros((n, self.n_classes), dtype=torch.float32, device=sess.device) if self.gumbel else None)
+            return zeros[n]
+        frozen = [k for k in eng.parameter_names() if k not in self.PRIOR_VAR_LIST]
+        for i in range(n_full + (1 if tail else 0)):
+            n = b if i < n_full else tail
+            inv_B = (world / float(data.batch_size)) if i < n_full else 1.0 / n
+            eps, g = noise(n)
+            if stage == "vae":
+                eng.train_step(rows, perm, n, eps, g, first=i * b, grad_sync=sync, grad_scale=ex.grad_scale, inv_B=inv_B)
+            else:
+                eng.load_batch(rows, perm, i * b, n)
+                eng.forward_backward(n, eps, g, inv_B)
+                if sync is not None:
+                    sync(eng.grad)
+                for k in frozen:                      # minimize(..., var_list=c-head): nothing else moves
+                    eng.grad_view(k).zero_()
+                eng.update(ex.grad_scale)
+        torch.cuda.synchronize(sess.device)
+        st = eng.read_state()
+        loss = float(st.epoch_recon) if stage == "vae" else float(st.epoch_klz) + float(st.epoch_klc)
+        if world > 1:
+            loss = ex.mean_scalars([loss])[0]
+        self._replay = None        # the step graph was captured for the main optimizer's state; recapture after pretraining
+        return loss
+
+    def pretrain_vae(self, session, data, n_epochs):
+        """base_models.py:322-350."""
+        sess = session or self._session
+        if not self._restore("vae"):
+            print("Could not load trained ae parameters")
+        self._engine.reset_optimizer(self._vae_lr)
+        min_loss = float("inf")
+        for _ in range(n_epochs):
+            loss = self._pretrain_epoch(sess, data, "vae")
+            if loss <= min_loss:
+                min_loss = loss
+                self._save("vae")
+        return min_loss
+
+    def pretrain_prior(self, session, data, n_epochs):
+        """base_models.py:352-414: prior tables from a diagonal GMM on the encoder means, then
+        Adam on the latent loss over the c-head only."""
+        sess = session or self._session
+        if not self._restore("prior"):
+            print("Could not load trained prior parameters")
+            if n_epochs > 0:
+                from sklearn.mixture import GaussianMixture
+                Z = self.encode(data.data)[0]
+                gmm_model = GaussianMixture(n_components=self.n_classes, covariance_type="diag", max_iter=n_epochs,
+                                            n_init=20, weights_init=np.ones(self.n_classes) / self.n_classes)
+                gmm_model.fit(Z)
+                self._engine.set_parameters({"prior_means": gmm_model.means_,
+                                             "prior_log_vars": np.log(gmm_model.covariances_ + 1e-20)})
+                self._save("prior")
+        self._engine.reset_optimizer(self._prior_lr)
+        min_loss = float("inf")
+        for _ in range(n_epochs):
+            loss = self._pretrain_epoch(sess, data, "prior")
+            if loss <= min_loss:
+                min_loss = loss
+                self._save("prior")
+        return min_loss
 
     def pretrain(self, session, data, n_epochs_vae, n_epochs_gmm):
-        raise NotImplementedError("pretraining stages (base_models.py:304-423) are a 'next' row of SURVEY.md 8f")
+        """base_models.py:416-423."""
+        assert(self.vae_train_step is not None and self.prior_train_step is not None)
+        self.pretrain_vae(session, data, n_epochs_vae)
+        self.pretrain_prior(session, data, n_epochs_gmm)
+        # the main optimizer (define_train_step) is its own AdamOptimizer: fresh slots, its own learning rate
+        self._engine.reset_optimizer(getattr(self, "_lr", None))
 
     # ------------------------------------------------------------------ checkpoint (trainables only, like tf.train.Saver)
     def state_dict(self):

@@ -218,6 +218,16 @@ class StepEngine:
         host = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8)
         self.state_t.copy_(host)
 
+    def reset_optimizer(self, lr=None):
+        """A fresh tf.train.AdamOptimizer instance (base_models.py:102, :307-320 create one per
+        training stage): zero m and v, t back to 0, optionally a new learning rate."""
+        self.m.zero_()
+        self.v.zero_()
+        kw = dict(adam_t=0, lr_t=0.0)
+        if lr is not None:
+            kw["lr"] = float(lr)
+        self.write_state(**kw)
+
     def reset_epoch(self, batches_per_epoch, kl_ratio=None, epoch_weight=None):
         kw = dict(batch_cursor=0, batches_per_epoch=int(batches_per_epoch), epoch_loss=0.0, epoch_recon=0.0,
                   epoch_klz=0.0, epoch_klc=0.0,

@@ -4,8 +4,10 @@ per-batch path on MI355X.  Run from this directory:  python train.py [flags]
 Multi-GPU (one process per GPU, RCCL gradient all-reduce):
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py --batch_size 65536
 Flags that the reference accepts but that address models outside the DMVAE hot
-path (--model vade/dmoe/dvmoe/vademoe, --pretrain, --plotting, --visdom) are
-parsed and rejected / ignored with a message, see SURVEY.md 2.1.
+path (--model vade/dmoe/dvmoe/vademoe, --plotting, --visdom) are parsed and
+rejected / ignored with a message, see SURVEY.md 2.1.  --pretrain runs the two
+pretraining stages of base_models.py:304-423 (recon-only Adam at epsilon = 0,
+GMM-initialised prior tables, latent-loss Adam over the c-head).
 New flags (defaults = reference behaviour): --batch_size, --dtype, --seed,
 --host_noise, --gumbel, --temperature, --enc_layers, --head_dim, --dec_layers.
 """
@@ -88,8 +90,6 @@ def main(argv):
         raise NotImplementedError("--model %s: only the DMVAE ELBO path is built (SURVEY.md 2.1, 8)" % model_str)
     if model_str != "dmvae":
         raise NotImplementedError
-    if argv.pretrain:
-        raise NotImplementedError("--pretrain: pretraining stages are a 'next' row (SURVEY.md 8f)")
     if argv.plotting and rank == 0:
         print("--plotting: PNG plots are out of scope of this build; ignored")
     if argv.visdom and rank == 0:
@@ -131,6 +131,9 @@ def main(argv):
         for path in [model.path + "/" + x for x in ["model", "vae", "prior"]]:
             if not os.path.exists(path):
                 os.makedirs(path)
+    if argv.pretrain:     # train.py:222-231, :241-249
+        model.define_pretrain_step(argv.pretrain_vae_lr, argv.pretrain_prior_lr)
+        model.pretrain(sess, train_data, argv.pretrain_epochs_vae, argv.pretrain_epochs_prior)
     ckpt_path = model.path + "/model/parameters.ckpt"
     try:
         model.load_state_dict(torch.load(ckpt_path, weights_only=False))

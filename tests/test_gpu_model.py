@@ -127,15 +127,89 @@ def test_latent_variable_classes_against_reference_golden_vectors(golden):
         assert nf.kl_from_prior({"mean": g("mean"), "log_var": g("log_var")}) == pytest.approx(float(g("kl_normal")), rel=5e-5)
 
 
+def test_pretraining_stages_match_reference_semantics(tmp_path):
+    """base_models.py:304-423.  Stage 1: Adam(vae_lr) on the reconstruction loss at epsilon = 0;
+    stage 2: prior tables from a diagonal GMM on the encoder means, then Adam(prior_lr) on the
+    latent loss over the c-head variables only.  Each stage is its own optimizer (fresh slots)."""
+    from includes.utils import Dataset
+    from sklearn.mixture import GaussianMixture
+    rng = np.random.RandomState(4)
+    N, B = 16 * 3 + 6, 16
+    X = (rng.rand(N, 40) * (rng.rand(N, 40) < 0.4)).astype(np.float32)
+    cls = rng.randint(0, 5, N)
+    m = build()
+    m.path = str(tmp_path / "ckpt")
+    m.define_pretrain_step(0.003, 0.004)
+    cfg = O.Config(40, 6, 5, SMALL["enc_layers"], SMALL["head_dim"], SMALL["dec_layers"])
+    p0 = m.engine.get_parameters()
+    p = {k: v.astype(np.float64) for k, v in p0.items()}
+    data = Dataset((X, cls), batch_size=B, shuffle=False)
+    batches = [X[i:i + B].astype(np.float64) for i in range(0, N, B)]
+    epoch_len = len(batches)
+
+    # ---- stage 1
+    loss_vae = m.pretrain_vae(None, data, 2)
+    mo, vo = O.adam_tf_init(p)
+    t, ref = 0, []
+    for ep in range(2):
+        acc = 0.0
+        for xb in batches:
+            t += 1
+            a = O.forward(p, cfg, xb, np.zeros((len(xb), 6)), 0.0)
+            g = O.backward(p, cfg, a)
+            O.adam_tf(p, g, mo, vo, t, 0.003)
+            acc += a["recon"] / epoch_len
+        ref.append(acc)
+    assert loss_vae == pytest.approx(min(ref), abs=2e-3)
+    pg = m.engine.get_parameters()
+    for k in p:
+        assert np.percentile(np.abs(pg[k] - p[k]), 99) <= 5e-4, ("vae stage", k)
+    for k in ("W_ch", "b_ch", "W_logits", "b_logits", "prior_means", "prior_log_vars"):   # no gradient from recon: untouched
+        np.testing.assert_array_equal(pg[k], p0[k])
+    assert os.path.exists(os.path.join(m.path, "vae", "parameters.npz"))
+
+    # ---- stage 2: GMM initialisation (same global NumPy stream on both sides), then the c-head
+    for k in p:        # continue from the GPU's parameters so that the GMM sees identical means
+        p[k] = pg[k].astype(np.float64)
+    Z = m.encode(data.data)[0]
+    np.random.seed(7)
+    gmm = GaussianMixture(n_components=5, covariance_type="diag", max_iter=2, n_init=20, weights_init=np.ones(5) / 5).fit(Z)
+    np.random.seed(7)
+    loss_prior = m.pretrain_prior(None, data, 2)
+    p["prior_means"] = gmm.means_.astype(np.float32).astype(np.float64)
+    p["prior_log_vars"] = np.log(gmm.covariances_ + 1e-20).astype(np.float32).astype(np.float64)
+    mo, vo = O.adam_tf_init(p)
+    t, ref = 0, []
+    for ep in range(2):
+        acc = 0.0
+        for xb in batches:
+            t += 1
+            a = O.forward(p, cfg, xb, np.zeros((len(xb), 6)), 1.0)
+            g = O.backward(p, cfg, a)
+            for k in g:
+                if k not in m.PRIOR_VAR_LIST:
+                    g[k] = np.zeros_like(g[k])
+            O.adam_tf(p, g, mo, vo, t, 0.004)
+            acc += (a["kl_z"] + a["kl_c"]) / epoch_len
+        ref.append(acc)
+    assert loss_prior == pytest.approx(min(ref), rel=2e-3, abs=2e-3)
+    pg2 = m.engine.get_parameters()
+    for k in p:
+        if k in m.PRIOR_VAR_LIST:
+            assert np.percentile(np.abs(pg2[k] - p[k]), 99) <= 5e-4, ("prior stage", k)
+        else:
+            np.testing.assert_allclose(pg2[k], p[k], rtol=0, atol=1e-6, err_msg=k)     # frozen
+    # the full pretrain() hands the main optimizer fresh slots
+    m.pretrain(None, data, 0, 0)
+    assert m.engine.read_state().adam_t == 0 and float(m.engine.m.abs().sum()) == 0.0
+
+
 def test_unsupported_surfaces_fail_loudly():
     import base_models
     with pytest.raises(NotImplementedError):
         base_models.DeepMixtureVAE("m", "binary", 784, 10, 10, cnn=True)
     with pytest.raises(NotImplementedError):
         base_models.VaDE("v", "binary", 784, 10, 10)
-    m = build()
-    with pytest.raises(NotImplementedError):
-        m.define_pretrain_step(1e-3, 1e-3)
 
 
 def test_train_cli_one_epoch(tmp_path, monkeypatch):

@@ -44,13 +44,19 @@ def test_init_matches_reference_rules_and_oracle_stream():
     assert eng.param.numel() >= oracle_cfg(REF).n_params()
 
 
-@pytest.mark.parametrize("cfg_kw,B", [(SMALL, 37), (REF, 100)])
+# cfg4's latent geometry (D=256, K=50: the prior tables go through LDS in four D-chunks) on small layers
+WIDE = dict(input_dim=100, latent_dim=256, n_classes=50, enc_layers=(70, 50), head_dim=90, dec_layers=(90, 50, 30))
+
+
+@pytest.mark.parametrize("cfg_kw,B", [(SMALL, 37), (REF, 100), (WIDE, 48)])
 @pytest.mark.parametrize("mode", ["exact", "relaxed"])
 @pytest.mark.parametrize("input_type", ["binary", "real"])
 def test_fp32_step_matches_oracle(cfg_kw, B, mode, input_type):
     kw = dict(cfg_kw, input_type=input_type)
     if cfg_kw is REF and (mode == "relaxed" or input_type == "real"):
         pytest.skip("reference-size case runs once (exact, binary)")
+    if cfg_kw is WIDE and input_type == "real":
+        pytest.skip("wide-latent case runs with the binary loss only")
     eng = make(kw, "fp32", B, mode)
     cfg = oracle_cfg(kw)
     rng = np.random.RandomState(1)
