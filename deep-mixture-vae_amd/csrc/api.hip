@@ -131,6 +131,7 @@ struct dmvae_plan {
     hipEvent_t ev_fork[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join = nullptr;   // [3] = step_finalize fork
     bool side_busy = false;
     bool fused_update = false;        // set for the duration of dmvae_plan_train_step on a bf16 plan
+    bool staged = false;              // dmvae_plan_forward_backward_stage: every segment launches its own dW group
     bool overlap_dw = true;
 };
 
@@ -405,9 +406,9 @@ static int grad_dense(dmvae_plan* p, hipStream_t s, const void* X, int64_t ldx, 
 // re-enables the side-stream form for re-measurement on other shapes.
 static int flush_dw(dmvae_plan* p, hipStream_t s, int group) {
     if (p->dw_queue.empty()) return 0;
-    if (!p->overlap_dw && group != 2) return 0;
+    if (!p->overlap_dw && !p->staged && group != 2) return 0;
     hipStream_t target = s;
-    if (p->side && p->overlap_dw) {
+    if (p->side && p->overlap_dw && !p->staged) {
         hipError_t e = hipEventRecord(p->ev_fork[group], s);
         if (e == hipSuccess) e = hipStreamWaitEvent(p->side, p->ev_fork[group], 0);
         if (e != hipSuccess) { set_error("dW side stream fork: %s", hipGetErrorString(e)); return (int)e; }
@@ -439,13 +440,23 @@ static int dx_dense(dmvae_plan* p, hipStream_t s, const void* dY, int64_t ldy, i
     return gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_DX, p->Bp, N, Kdim, dY, ldy, Wp(p, w_off), ldw, &e, 1, deferred);
 }
 
-extern "C" int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_valid, const float* eps, int64_t ld_eps,
-                                           const float* gumbel, int64_t ld_gumbel, float inv_B) {
+// stage < 0: the whole forward + backward.  stage 0 / 1 / 2: the three segments after which one
+// contiguous BUCKET of the gradient arena is complete (dmvae_plan_grad_buckets): 0 = forward, loss,
+// decoder backward -> [dec0 .. out, prior tables]; 1 = heads -> [zh|ch, mean|log_var, logits];
+// 2 = trunk -> [enc*].  Each segment launches its own dW group, so a data-parallel caller can start
+// the bucket's all-reduce while the next segment runs.
+static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const float* eps, int64_t ld_eps,
+                                 const float* gumbel, int64_t ld_gumbel, float inv_B, int stage) {
     DMVAE_REQUIRE(p && p->bound, "dmvae_plan_forward_backward: plan not bound");
     DMVAE_REQUIRE(n_valid > 0 && n_valid <= p->cfg.max_batch, "dmvae_plan_forward_backward: n_valid=%d out of range", n_valid);
+    DMVAE_REQUIRE(stage >= -1 && stage <= 2, "dmvae_plan_forward_backward_stage: stage %d (0, 1, 2)", stage);
     hipStream_t s = (hipStream_t)stream;
     const dmvae_config& c = p->cfg;
     const int dt = c.dtype;
+    const bool all = stage < 0;
+    p->staged = !all;
+    const int nd = (int)p->dec.size(), ne = (int)p->enc.size();
+  if (all || stage == 0) {
     p->dw_queue.clear();
     TRY(encode_impl(p, s));
 
@@ -471,7 +482,6 @@ extern "C" int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_va
     TRY(latent_launch(s, &la));
 
     TRY(decode_hidden(p, s));
-    const int nd = (int)p->dec.size(), ne = (int)p->enc.size();
     {   // output layer + reconstruction loss + dLoss/dlogits in one epilogue
         const PLayer& L = p->out;
         dmvae_epilogue e;
@@ -512,7 +522,9 @@ extern "C" int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_va
             TRY(gemm_checked(s, dt, DMVAE_GEMM_DX, p->Bp, p->Dp, L.out_pad, WS(p, p->o_ddec[0]), L.out_pad, Wp(p, L.w_off), L.ldw, &e, 1));
         }
     }
-    TRY(flush_dw(p, s, 0));   // decoder dW group: overlaps the rest of the dX chain on the side stream
+    TRY(flush_dw(p, s, 0));   // decoder dW group (launched here only when staged / DMVAE_DW_OVERLAP)
+  }
+  if (all || stage == 1) {
     // ---- backward: heads
     TRY(grad_dense(p, s, WS(p, p->o_hzc), 2 * p->Hp, p->Hp, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->mv.b_off));
     TRY(grad_dense(p, s, act_off(p, p->o_hzc, p->Hp), 2 * p->Hp, p->Hp, WS(p, p->o_dlg), p->Kp, p->Kp, p->lg.w_off, p->lg.ldw, p->lg.b_off));
@@ -528,6 +540,8 @@ extern "C" int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_va
     // ---- backward: trunk
     TRY(grad_dense(p, s, WS(p, p->o_enc[ne - 1]), p->Tp, p->Tp, WS(p, p->o_dhzc), 2 * p->Hp, 2 * p->Hp, p->zc.w_off, p->zc.ldw, p->zc.b_off));
     TRY(flush_dw(p, s, 1));   // heads dW group ([mean|log_var], logits, [zh|ch])
+  }
+  if (all || stage == 2) {
     TRY(dx_dense(p, s, WS(p, p->o_dhzc), 2 * p->Hp, 2 * p->Hp, p->zc.w_off, p->zc.ldw, p->Tp, WS(p, p->o_enc[ne - 1]), p->Tp,
                  WS(p, p->o_denc[ne - 1]), p->Tp));
     for (int i = ne - 1; i >= 0; --i) {
@@ -539,13 +553,32 @@ extern "C" int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_va
             TRY(dx_dense(p, s, WS(p, p->o_denc[i]), L.out_pad, L.out_pad, L.w_off, L.ldw, L.in_pad,
                          WS(p, p->o_enc[i - 1]), p->enc[i - 1].out_pad, WS(p, p->o_denc[i - 1]), p->enc[i - 1].out_pad));
     }
-    TRY(flush_dw(p, s, 2));   // trunk dW group
+    TRY(flush_dw(p, s, 2));   // trunk dW group (everything queued so far when not staged)
+  }
     if (p->side_busy) {       // join: Adam / the gradient exchange / the next step must see the side stream's work
         hipError_t e = hipEventRecord(p->ev_join, p->side);
         if (e == hipSuccess) e = hipStreamWaitEvent(s, p->ev_join, 0);
         p->side_busy = false;
         if (e != hipSuccess) { set_error("side stream join: %s", hipGetErrorString(e)); return (int)e; }
     }
+    return 0;
+}
+
+extern "C" int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_valid, const float* eps, int64_t ld_eps,
+                                           const float* gumbel, int64_t ld_gumbel, float inv_B) {
+    return forward_backward_impl(p, stream, n_valid, eps, ld_eps, gumbel, ld_gumbel, inv_B, -1);
+}
+extern "C" int dmvae_plan_forward_backward_stage(dmvae_plan* p, void* stream, int stage, int n_valid, const float* eps, int64_t ld_eps,
+                                                 const float* gumbel, int64_t ld_gumbel, float inv_B) {
+    DMVAE_REQUIRE(stage >= 0 && stage <= 2, "dmvae_plan_forward_backward_stage: stage %d (0, 1, 2)", stage);
+    return forward_backward_impl(p, stream, n_valid, eps, ld_eps, gumbel, ld_gumbel, inv_B, stage);
+}
+extern "C" int dmvae_plan_grad_buckets(const dmvae_plan* p, int64_t bounds[4]) {
+    DMVAE_REQUIRE(p && bounds, "dmvae_plan_grad_buckets: null pointer");
+    bounds[0] = 0;                                   // stage 2 completes [bounds[0], bounds[1])  (trunk)
+    bounds[1] = p->zc.w_off;                         // stage 1 completes [bounds[1], bounds[2])  (heads)
+    bounds[2] = p->dec.empty() ? p->out.w_off : p->dec[0].w_off;   // stage 0 completes [bounds[2], bounds[3])  (decoder, prior tables)
+    bounds[3] = p->param_elems;
     return 0;
 }
 

@@ -259,6 +259,32 @@ class StepEngine:
         check(lib.dmvae_plan_forward_backward(self._plan, self._stream(), n_valid, ptr(eps), self.latent_dim,
                                               ptr(gumbel), self.n_classes, inv_B), "dmvae_plan_forward_backward")
 
+    def forward_backward_stage(self, stage, n_valid=None, eps=None, gumbel=None, inv_B=None):
+        """segment `stage` (0, 1, 2) of forward_backward; after it grad_buckets()[stage] is final."""
+        n_valid = self.max_batch if n_valid is None else int(n_valid)
+        inv_B = 1.0 / n_valid if inv_B is None else float(inv_B)
+        check(lib.dmvae_plan_forward_backward_stage(self._plan, self._stream(), int(stage), n_valid, ptr(eps), self.latent_dim,
+                                                    ptr(gumbel), self.n_classes, inv_B), "dmvae_plan_forward_backward_stage")
+
+    def grad_buckets(self):
+        """[(lo, hi)] element ranges of the gradient arena in the order the segments complete them."""
+        b = (C.c_int64 * 4)()
+        check(lib.dmvae_plan_grad_buckets(self._plan, b), "dmvae_plan_grad_buckets")
+        return [(b[2], b[3]), (b[1], b[2]), (b[0], b[1])]
+
+    def _backward_with_exchange(self, grad_sync, n_valid=None, eps=None, gumbel=None, inv_B=None):
+        """forward + backward with the gradient exchange: bucketed and overlapped when the exchange
+        offers start()/finish(), else one collective on the whole arena."""
+        if getattr(grad_sync, "overlap", False):
+            handles = []
+            for stage, (lo, hi) in enumerate(self.grad_buckets()):
+                self.forward_backward_stage(stage, n_valid, eps, gumbel, inv_B)
+                handles.append(grad_sync.start(self.grad[lo:hi]))
+            grad_sync.finish(handles)
+        else:
+            self.forward_backward(n_valid, eps, gumbel, inv_B)
+            grad_sync(self.grad)
+
     def update(self, grad_scale=1.0):
         check(lib.dmvae_plan_update(self._plan, self._stream(), float(grad_scale)), "dmvae_plan_update")
 
@@ -324,9 +350,10 @@ class StepEngine:
             assert grad_sync is None and float(grad_scale) == 1.0
             self.forward_backward_update(n_valid, eps, gumbel, inv_B)
             return
-        self.forward_backward(n_valid, eps, gumbel, inv_B)
         if grad_sync is not None:
-            grad_sync(self.grad)
+            self._backward_with_exchange(grad_sync, n_valid, eps, gumbel, inv_B)
+        else:
+            self.forward_backward(n_valid, eps, gumbel, inv_B)
         self.update(grad_scale)
 
     def capture_step(self, data, perm, grad_sync=None, grad_scale=1.0, inv_B=None):
@@ -350,8 +377,30 @@ class StepEngine:
                 self.train_step(data, perm, None, None, None, 0, True, None, grad_scale, inv_B)
             self._graph = (g,)
             return g.replay
-        # data parallel: two graphs with the collective issued eagerly between them on the
-        # same stream (keeps RCCL out of stream capture)
+        # data parallel: graphs with the collectives issued eagerly between them (keeps RCCL out of
+        # stream capture).  Overlapped form: one graph per backward segment; each bucket's
+        # all-reduce starts behind its segment and runs beside the next one.
+        if getattr(grad_sync, "overlap", False):
+            buckets = self.grad_buckets()
+            segs = [torch.cuda.CUDAGraph() for _ in range(3)]
+            gu = torch.cuda.CUDAGraph()
+            for stage, g in enumerate(segs):
+                with torch.cuda.graph(g, stream=side):
+                    if stage == 0:
+                        self.load_batch(data, perm, 0, None, True)
+                    self.forward_backward_stage(stage, None, None, None, inv_B)
+            with torch.cuda.graph(gu, stream=side):
+                self.update(grad_scale)
+            self._graph = (*segs, gu)
+
+            def replay_overlapped():
+                handles = []
+                for g, (lo, hi) in zip(segs, buckets):
+                    g.replay()
+                    handles.append(grad_sync.start(self.grad[lo:hi]))
+                grad_sync.finish(handles)
+                gu.replay()
+            return replay_overlapped
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(ga, stream=side):
             self.load_batch(data, perm, 0, None, True)

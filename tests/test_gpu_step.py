@@ -173,6 +173,36 @@ def test_fused_update_equals_backward_then_adam(mode):
     assert engs[0].param.abs().sum().item() > 0
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_staged_backward_equals_whole_and_buckets_cover_the_arena(dtype):
+    """dmvae_plan_forward_backward_stage 0, 1, 2 (the data-parallel form: one dW launch and one
+    finished gradient bucket per segment) leaves the bits dmvae_plan_forward_backward leaves, and
+    after segment k its bucket no longer changes."""
+    kw, B = dict(input_dim=784, latent_dim=64, n_classes=10), 256
+    rng = np.random.RandomState(13)
+    Xd = torch.as_tensor(O.synthetic_images(B, 784, seed=6)).cuda()
+    ed = torch.as_tensor(rng.randn(B, 64).astype(np.float32)).cuda()
+    whole, staged = make(kw, dtype, B, seed=2), make(kw, dtype, B, seed=2)
+    whole.load_batch(Xd, None, 0, B)
+    whole.forward_backward(B, ed)
+    buckets = staged.grad_buckets()
+    assert buckets[2][0] == 0 and buckets[0][1] == staged.grad.numel()          # trunk first in the arena, decoder + priors last
+    assert buckets[2][1] == buckets[1][0] and buckets[1][1] == buckets[0][0]    # contiguous, no gap
+    staged.load_batch(Xd, None, 0, B)
+    done = []
+    for stage, (lo, hi) in enumerate(buckets):
+        staged.forward_backward_stage(stage, B, ed)
+        torch.cuda.synchronize()
+        done.append((lo, hi))
+        for dlo, dhi in done:      # finished buckets equal the whole-pass gradient already
+            assert torch.equal(staged.grad[dlo:dhi], whole.grad[dlo:dhi]), (stage, dlo, dhi)
+    assert staged.read_state().last_loss == whole.read_state().last_loss
+    whole.update(0.5)
+    staged.update(0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(whole.param, staged.param)
+
+
 def test_ragged_batch_and_determinism():
     """n_valid < max_batch (the short last batch of an epoch, utils.py:462-463):
     same result as an engine sized exactly; deterministic mode is bit-reproducible."""

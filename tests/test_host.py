@@ -186,8 +186,15 @@ def _dp_worker(rank, world, port, out):
     flat = torch.cat([torch.as_tensor(g[k]).reshape(-1) for k in names])     # the flat gradient arena
     ex = GradExchange()
     assert ex.enabled and ex.world == world and ex.grad_scale == 1.0 / world
+    bucketed = flat.clone()
     ex(flat)                                                                 # ONE all-reduce(SUM) per step
     flat = flat * ex.grad_scale                                              # folded into the Adam kernel on the GPU
+    # the overlapped form: three contiguous buckets, last part of the arena first (decoder, heads, trunk)
+    assert ex.overlap
+    n = bucketed.numel()
+    handles = [ex.start(bucketed[lo_:hi_]) for lo_, hi_ in ((2 * n // 3, n), (n // 3, 2 * n // 3), (0, n // 3))]
+    ex.finish(handles)
+    assert torch.equal(bucketed * ex.grad_scale, flat)
     full = O.backward(p, cfg, O.forward(p, cfg, X, eps))
     ref = torch.cat([torch.as_tensor(full[k]).reshape(-1) for k in names])
     err = (flat - ref).abs().max().item()
