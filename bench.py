@@ -35,6 +35,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch (cfg2: 4096)")
+    ap.add_argument("--lr", type=float, default=0.002, help="Adam learning rate (train.py default 0.002; the 4096-wide cfg5 "
+                    "stack overflows exp(log_var) after one step at that rate in fp32 and bf16 alike: use 1e-4 there)")
+    ap.add_argument("--input_dim", type=int, default=784)
+    ap.add_argument("--enc_layers", default="500,500")
+    ap.add_argument("--head_dim", type=int, default=2000)
+    ap.add_argument("--dec_layers", default="2000,500,500")
     ap.add_argument("--latent_dim", type=int, default=64)
     ap.add_argument("--n_clusters", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -78,10 +84,11 @@ def cpu_baseline(args, seconds):
         cores = os.cpu_count() or 1
     out = {}
     for B in (args.batch, 100):
-        cfg = O.Config(784, args.latent_dim, args.n_clusters)
+        cfg = O.Config(args.input_dim, args.latent_dim, args.n_clusters, tuple(int(v) for v in args.enc_layers.split(",")),
+                       args.head_dim, tuple(int(v) for v in args.dec_layers.split(",")))
         p = O.init_params(cfg, 0, np.float32)
         m, v = O.adam_tf_init(p)
-        X = O.synthetic_images(B, 784, seed=1)
+        X = O.synthetic_images(B, args.input_dim, seed=1)
         rng = np.random.RandomState(0)
         eps = rng.randn(B, args.latent_dim).astype(np.float32)
         budget = seconds * (0.75 if B == args.batch else 0.25)
@@ -126,9 +133,13 @@ def main():
 
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    I, D, K, B = 784, args.latent_dim, args.n_clusters, args.batch
-    eng = StepEngine(I, D, K, dtype=args.dtype, max_batch=B, seed=1234 + rank, deterministic=args.deterministic)
+    I, D, K, B = args.input_dim, args.latent_dim, args.n_clusters, args.batch
+    enc = tuple(int(v) for v in args.enc_layers.split(","))
+    dec = tuple(int(v) for v in args.dec_layers.split(","))
+    eng = StepEngine(I, D, K, enc_layers=enc, head_dim=args.head_dim, dec_layers=dec, dtype=args.dtype, max_batch=B,
+                     seed=1234 + rank, deterministic=args.deterministic)
     eng.init_parameters(0)
+    eng.write_state(lr=args.lr)
     ex = GradExchange()
     ex.broadcast_(eng.param)
     eng.refresh_shadow()
@@ -196,16 +207,20 @@ def main():
 
     ms_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
-    fpi = flops_per_image(I, D, K)
+    fpi = flops_per_image(I, D, K, enc, args.head_dim, dec)
+    is_cfg2 = (I, D, K, B, enc, args.head_dim, dec, args.dtype) == (784, 64, 10, 4096, (500, 500), 2000, (2000, 500, 500), "bf16")
+    arch = "%d-%s-(%d|%d)-z%d/K%d-%s-%d" % (I, "-".join(map(str, enc)), args.head_dim, args.head_dim, D, K, "-".join(map(str, dec)), I)
     out = {
-        "metric": "images/sec (train), MNIST K=10 z=64 batch=4096/GPU bf16",
+        "metric": "images/sec (train), MNIST K=10 z=64 batch=4096/GPU bf16" if is_cfg2
+                  else "images/sec (train), DMVAE %s batch=%d/GPU %s" % (arch, B, args.dtype),
         "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "configs[1]: DMVAE MLP 784-500-500-(2000|2000)-z%d/K%d-2000-500-500-784, one ELBO training step "
-                               "(gather+fwd+loss+bwd+Adam), synthetic 28x28 rows resident in HBM" % (D, K),
+        "config": {"workload": "%sDMVAE MLP %s, one ELBO training step (gather+fwd+loss+bwd+Adam), synthetic rows resident in HBM"
+                               % ("configs[1]: " if is_cfg2 else "", arch),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                   "hip_graph": not args.no_graph, "deterministic": bool(args.deterministic)},
+                   "hip_graph": not args.no_graph, "float_atomics": False,
+                   "update": "adam fused into the dW launch" if world == 1 else "bucketed all-reduce overlapped with backward, then adam"},
         "step_flops_algorithmic": fpi * B,
         "step_mfma_frac_of_peak": round(fpi * B / (ms_step * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4),
         "last_loss": round(float(st.last_loss), 4),
