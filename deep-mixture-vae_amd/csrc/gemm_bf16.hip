@@ -43,6 +43,7 @@
 
 #include "kernels.h"
 
+__device__ unsigned long long g_mid[2048];           // DMVAE_ABLATE == 6 builds only: end of each workgroup's K loop
 // Measurement-only builds (tools/ablate.sh -> a separately named .so, never the product library):
 // 1 = no MFMA, 2 = no LDS fragment reads, 3 = no global->LDS loads in the K loop, 4 = 1 + 2.
 #ifndef DMVAE_ABLATE
@@ -379,6 +380,9 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     }
     wait_vmcnt<0>();                                            // drain the clamped tail loads before LDS is reused / the wave ends
     __builtin_amdgcn_s_barrier();
+#if DMVAE_ABLATE == 6     // tools/stamps.py: when the K loop of this workgroup ended
+    if (threadIdx.x == 0 && blockIdx.x < 2048) g_mid[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // Epilogue through LDS.  The MFMA result map gives a lane 4 consecutive n of ONE row and its 15
     // neighbours 15 OTHER rows: stored straight from the accumulators a wave instruction touches
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_grouped_kernel(GroupedArgs g) {
         st[0] = t0;
         st[1] = __builtin_amdgcn_s_memrealtime();
         st[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_ID | XCC_ID
-        st[3] = ((unsigned long long)LAYOUT << 32) | (unsigned)kind;
+        st[3] = ((g_mid[blockIdx.x] - t0) << 16) | ((unsigned long long)LAYOUT << 8) | (unsigned)kind;   // K-loop ticks | layout | kind
     }
 #endif
 }

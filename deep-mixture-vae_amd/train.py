@@ -4,8 +4,9 @@ per-batch path on MI355X.  Run from this directory:  python train.py [flags]
 Multi-GPU (one process per GPU, RCCL gradient all-reduce):
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py --batch_size 65536
 Flags that the reference accepts but that address models outside the DMVAE hot
-path (--model vade/dmoe/dvmoe/vademoe, --plotting, --visdom) are parsed and
-rejected / ignored with a message, see SURVEY.md 2.1.  --pretrain runs the two
+path (--model vade/dmoe/dvmoe/vademoe, --visdom) are parsed and rejected /
+ignored with a message, see SURVEY.md 2.1.  --plotting writes the reference's
+two figures (regenerated.png, sampled.png) as PNG grids.  --pretrain runs the two
 pretraining stages of base_models.py:304-423 (recon-only Adam at epsilon = 0,
 GMM-initialised prior tables, latent-loss Adam over the c-head).
 New flags (defaults = reference behaviour): --batch_size, --dtype, --seed,
@@ -74,6 +75,7 @@ def main(argv):
     import torch
     import base_models
     from includes.utils import load_data, Dataset
+    from includes import visualization
     from dmvae_hip import Session
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,8 +92,7 @@ def main(argv):
         raise NotImplementedError("--model %s: only the DMVAE ELBO path is built (SURVEY.md 2.1, 8)" % model_str)
     if model_str != "dmvae":
         raise NotImplementedError
-    if argv.plotting and rank == 0:
-        print("--plotting: PNG plots are out of scope of this build; ignored")
+    plotting = argv.plotting and rank == 0 and argv.dataset == "mnist"   # train.py:157-163: plots exist for the image sets
     if argv.visdom and rank == 0:
         print("--visdom: accepted, not used")
 
@@ -154,6 +155,9 @@ def main(argv):
         for epoch in bar:
             if epoch % argv.save_epochs == 0 and argv.debug:
                 model.debug(sess, train_data)
+            if plotting and epoch % argv.plot_epochs == 0:      # train.py:281-286
+                visualization.mnist_sample_plot(model, sess)
+                visualization.mnist_regeneration_plot(model, test_data, sess)
             if argv.kl_annealing and (epoch + 1) % argv.anneal_epochs == 0:
                 anneal_term = min(anneal_term + argv.anneal_step, 1.0)
             loss = model.train_op(sess, train_data, anneal_term)
@@ -167,6 +171,9 @@ def main(argv):
                 raise FloatingPointError("loss is NaN at epoch %d (the reference drops into pdb here, train.py:320-321)" % epoch)
             bar.set_postfix({"loss": "%.4f" % loss, "accTrain": "%.4f" % accTrain, "accTest": "%.4f" % accTest,
                              "maxAcc": "%.4f" % maxAcc, "accClusteringTest": "%.4f" % accTest})
+    if plotting:                                                  # train.py:332-334
+        visualization.mnist_sample_plot(model, sess)
+        visualization.mnist_regeneration_plot(model, test_data, sess)
     if rank == 0:
         with open(argv.model + "_logs.txt", "a+") as fl:
             fl.write("\n" + str(argv) + "\n------\n")

@@ -204,6 +204,41 @@ def test_pretraining_stages_match_reference_semantics(tmp_path):
     assert m.engine.read_state().adam_t == 0 and float(m.engine.m.abs().sum()) == 0.0
 
 
+def test_regeneration_and_cluster_samples_match_reference_definitions(tmp_path, monkeypatch):
+    """visualization.py:20-129: a reconstruction is sigmoid(decode(mean)) (every epsilon fed as
+    zeros); a sample of cluster c is sigmoid(decode(mu_c + sigma_c * n)), n from the NumPy stream."""
+    from includes import visualization as V
+    from includes.utils import Dataset
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.RandomState(9)
+    m = build(input_dim=49, latent_dim=6, n_classes=5)          # 7 x 7 "images"
+    X = (rng.rand(120, 49) * (rng.rand(120, 49) < 0.4)).astype(np.float32)
+    data = Dataset((X, rng.randint(0, 5, 120)), batch_size=16, shuffle=False)
+    cfg = O.Config(49, 6, 5, SMALL["enc_layers"], SMALL["head_dim"], SMALL["dec_layers"])
+    p = {k: v.astype(np.float64) for k, v in m.engine.get_parameters().items()}
+    orig, recn = V.regenerate(m, data)
+    a = O.forward(p, cfg, X[:100].astype(np.float64), np.zeros((100, 6)))
+    np.testing.assert_array_equal(orig, X[:100])
+    np.testing.assert_allclose(recn, 1.0 / (1.0 + np.exp(-a["xlogits"])), atol=2e-5)
+    left, right = V.mnist_regeneration_plot(m, data)
+    assert left.shape == right.shape == (70, 70)
+    np.testing.assert_allclose(left[7:14, 14:21], X[12].reshape(7, 7) * 255.0)      # panel (row 1, col 2) = image 12
+    np.random.seed(3)
+    Zs, dec = V.sample_clusters(m, n=200)
+    np.random.seed(3)
+    for c in range(5):
+        O.sample_gumbel((200, 1, 5))      # sample_generative_feed walks C first (its one-hot draw, unused), then Z: base_models.py:58-64
+        z = p["prior_means"][c] + np.random.randn(200, 6) * np.exp(p["prior_log_vars"][c] / 2.0)
+        np.testing.assert_allclose(Zs[c], z, atol=1e-6)
+        xl = O.decode(p, cfg, z[:100])["xlogits"]
+        np.testing.assert_allclose(dec[c], 1.0 / (1.0 + np.exp(-xl)), atol=2e-5)
+    fig = V.mnist_sample_plot(m)
+    assert fig.shape == (35, 70)
+    for name in ("regenerated.png", "sampled.png"):
+        blob = open(os.path.join("plots", m.name, "mnist", name), "rb").read()
+        assert blob[:8] == b"\x89PNG\r\n\x1a\n" and blob[-8:-4] == b"IEND"
+
+
 def test_unsupported_surfaces_fail_loudly():
     import base_models
     with pytest.raises(NotImplementedError):

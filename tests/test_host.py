@@ -223,3 +223,29 @@ def test_data_parallel_exchange_world2_gloo():
         assert err < 1e-12, (rank, err)
         assert bc_ok
         assert m == pytest.approx([0.5, 2.0])
+
+
+def test_png_writer_roundtrip(tmp_path):
+    """includes/visualization.py writes its figures with its own PNG encoder: decode it by hand."""
+    import struct, zlib
+    sys.path.insert(0, os.path.join(ROOT, "deep-mixture-vae_amd"))
+    from includes import visualization as V
+    img = (np.arange(6 * 5).reshape(6, 5) * 8).astype(np.float64)
+    path = str(tmp_path / "a" / "t.png")
+    V._write_png(path, img)
+    blob = open(path, "rb").read()
+    assert blob[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, {}
+    while pos < len(blob):
+        n, tag = struct.unpack(">I4s", blob[pos:pos + 8])
+        data = blob[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", blob[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + data) & 0xffffffff
+        chunks[tag] = data
+        pos += 12 + n
+    w, h, depth, ctype = struct.unpack(">IIBB", chunks[b"IHDR"][:10])
+    assert (w, h, depth, ctype) == (5, 6, 8, 0)
+    raw = zlib.decompress(chunks[b"IDAT"])
+    rows = np.frombuffer(raw, dtype=np.uint8).reshape(6, 6)
+    assert (rows[:, 0] == 0).all() and (rows[:, 1:] == img.astype(np.uint8)).all()
+    g = V._grid(np.arange(100 * 4).reshape(100, 4), side=2)
+    assert g.shape == (20, 20) and g[0, 0] == 0 and g[0, 2] == 4 and g[2, 0] == 40      # image 1 to the right, image 10 below

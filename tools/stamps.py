@@ -17,8 +17,9 @@ buf = torch.empty(2048 * 4, dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
 C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(buf.data_ptr()), p, C.c_size_t(2048 * 32), 3)
 st = buf.cpu().view(2048, 4).numpy()
-rows = [(i, int(r[0]), int(r[1]), int(r[2]) >> 32 & 0xffffffff, int(r[2]) & 0xf, int(r[3]) >> 32, int(r[3]) & 0xff)
-        for i, r in enumerate(st) if r[1] != 0 and (int(r[3]) >> 32) == 2]
+rows = [(i, int(r[0]), int(r[1]), int(r[2]) >> 32 & 0xffffffff, int(r[2]) & 0xf, int(r[3]) >> 8 & 0xff, int(r[3]) & 0xff)
+        for i, r in enumerate(st) if r[1] != 0 and (int(r[3]) >> 8 & 0xff) == 2]
+kloop = {i: (int(r[3]) >> 16) / 100.0 for i, r in enumerate(st) if r[1] != 0}
 t_min = min(r[1] for r in rows); t_max = max(r[2] for r in rows)
 print("dW workgroups %d, span %.2f us" % (len(rows), (t_max - t_min) / 100.0))
 cus = collections.defaultdict(list)
@@ -34,6 +35,10 @@ ends = sorted(max(x[2] for x in l) for l in cus.values())
 print("CU finish time us: min %.1f  p25 %.1f  median %.1f  p75 %.1f  max %.1f" % (ends[0], ends[len(ends) // 4], ends[len(ends) // 2], ends[3 * len(ends) // 4], ends[-1]))
 for kind in (0, 1, 2):
     d = sorted(t1 - t0 for i, t0, t1, hw, xcc, lay, k in rows if k == kind)
-    if d: print("kind %d: n %d  duration us min %.1f median %.1f max %.1f" % (kind, len(d), d[0] / 100.0, d[len(d) // 2] / 100.0, d[-1] / 100.0))
+    if d:
+        kl = sorted(kloop[i] for i, t0, t1, hw, xcc, lay, k in rows if k == kind)
+        ep = sorted((t1 - t0) / 100.0 - kloop[i] for i, t0, t1, hw, xcc, lay, k in rows if k == kind)
+        print("kind %d: n %d  duration us min %.1f median %.1f max %.1f | K loop median %.1f max %.1f | epilogue median %.1f max %.1f"
+              % (kind, len(d), d[0] / 100.0, d[len(d) // 2] / 100.0, d[-1] / 100.0, kl[len(kl) // 2], kl[-1], ep[len(ep) // 2], ep[-1]))
 late = sorted(rows, key=lambda r: -r[2])[:8]
 print("last finishers:", [(r[0], r[6], round((r[1] - t_min) / 100.0, 1), round((r[2] - t_min) / 100.0, 1)) for r in late])
