@@ -16,5 +16,5 @@ cp gpurun_out/r01_pmc_traffic.txt $OUT/${TAG}_pmc_traffic.txt
 python3 bench.py --steps 200 --warmup 20 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o $TAG -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null
 cp $(ls gpurun_out/prof_$TAG/*/*kernel_stats.csv gpurun_out/prof_$TAG/*kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_kernel_stats.csv
-python3 tools/showbench.py $OUT/${TAG}_bench.json | head -8
+python3 tools/showbench.py $OUT/${TAG}_bench.json > $OUT/.show.txt 2>/dev/null; sed -n 1,8p $OUT/.show.txt; rm -f $OUT/.show.txt
 head -12 $OUT/${TAG}_kernel_stats.csv
