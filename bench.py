@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dp-dry-run", default="", choices=["", "overlap", "single"],
+                    help="N = 1 only: issue the data-parallel launch sequence (staged backward + stand-alone Adam, or whole "
+                         "backward + Adam) with a no-op exchange, to price the N > 1 path's compute")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on one GPU)")
     return ap.parse_args()
@@ -153,6 +156,14 @@ def main():
     bpe = args.rows // B
     eng.reset_epoch(bpe, kl_ratio=1.0)
     sync = ex if ex.enabled else None
+    if args.dp_dry_run and world == 1:
+        # the data-parallel launch sequence without a communicator: what the N > 1 path costs in compute alone
+        class _NoComm:
+            overlap = args.dp_dry_run == "overlap"
+            def __call__(self, g): return g
+            def start(self, g): return None
+            def finish(self, hs): pass
+        sync = _NoComm()
 
     if args.no_graph:
         def step():
