@@ -162,7 +162,7 @@ def main():
             overlap = args.dp_dry_run == "overlap"
             def __call__(self, g): return g
             def start(self, g): return None
-            def finish(self, hs): pass
+            def wait(self, h): pass
         sync = _NoComm()
 
     if args.no_graph:

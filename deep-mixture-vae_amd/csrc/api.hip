@@ -597,10 +597,16 @@ extern "C" int dmvae_plan_train_step(dmvae_plan* p, void* stream, int n_valid, c
 
 extern "C" int dmvae_plan_update(dmvae_plan* p, void* stream, float grad_scale) {
     DMVAE_REQUIRE(p && p->bound, "dmvae_plan_update: plan not bound");
+    return dmvae_plan_update_range(p, stream, grad_scale, 0, p->param_elems);
+}
+extern "C" int dmvae_plan_update_range(dmvae_plan* p, void* stream, float grad_scale, int64_t lo, int64_t hi) {
+    DMVAE_REQUIRE(p && p->bound, "dmvae_plan_update_range: plan not bound");
+    DMVAE_REQUIRE(lo >= 0 && hi > lo && hi <= p->param_elems && lo % 4 == 0 && hi % 4 == 0,
+                  "dmvae_plan_update_range: [%lld, %lld) must be a 4-aligned range of the %lld-element arena", (long long)lo, (long long)hi, (long long)p->param_elems);
     hipStream_t s = (hipStream_t)stream;
     AdamArgs a;
-    a.n = p->param_elems; a.p = p->buf.param; a.g = p->buf.grad; a.m = p->buf.m; a.v = p->buf.v;
-    a.pb = reinterpret_cast<bf16_t*>(p->cfg.dtype == DMVAE_BF16 ? p->buf.param_bf16 : nullptr);
+    a.n = hi - lo; a.p = p->buf.param + lo; a.g = p->buf.grad + lo; a.m = p->buf.m + lo; a.v = p->buf.v + lo;
+    a.pb = p->cfg.dtype == DMVAE_BF16 ? reinterpret_cast<bf16_t*>(p->buf.param_bf16) + lo : nullptr;
     a.lr = 0.f; a.b1 = p->cfg.beta1; a.b2 = p->cfg.beta2; a.eps = p->cfg.adam_eps; a.gscale = grad_scale;
     a.zero_grad = 0;    // every gradient element is overwritten each step (no atomic accumulation)
     a.t_host = ~0ull;    // t = state->adam_t, already advanced by this step's loss_finalize (saves a launch)

@@ -24,7 +24,7 @@ MAX_LAYERS = 8
 
 EXPORTS = [
     "dmvae_gemm", "dmvae_gemm_partials", "dmvae_gemm_grouped_dw", "dmvae_gemm_grouped", "dmvae_gemm_grouped_dw_adam", "dmvae_plan_train_step",
-    "dmvae_plan_forward_backward_stage", "dmvae_plan_grad_buckets",
+    "dmvae_plan_forward_backward_stage", "dmvae_plan_grad_buckets", "dmvae_plan_update_range",
 "dmvae_latent_nblocks", "dmvae_latent_fwd",
     "dmvae_recon_fwd_bwd", "dmvae_recon_nblocks", "dmvae_colsum", "dmvae_loss_finalize",
     "dmvae_adam_tf", "dmvae_adam_finish", "dmvae_gather_rows", "dmvae_philox_normal",
@@ -144,6 +144,7 @@ def _load():
         "dmvae_plan_train_step": [vp, vp, i32, vp, i64, vp, i64, f32],
         "dmvae_plan_forward_backward_stage": [vp, vp, i32, i32, vp, i64, vp, i64, f32],
         "dmvae_plan_grad_buckets": [vp, P(i64)],
+        "dmvae_plan_update_range": [vp, vp, f32, i64, i64],
         "dmvae_latent_nblocks": [i32, i32, i32],
         "dmvae_latent_fwd": [vp, P(LatentArgs)],
         "dmvae_recon_fwd_bwd": [vp, i32, i32, i32, i32, i32, i32, vp, i64, vp, i64, f32, vp, i64, vp],

@@ -54,9 +54,15 @@ class GradExchange:
     def start(self, grad_slice):
         return dist.all_reduce(grad_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def wait(self, handle):
+        """the current stream waits for one bucket's all-reduce (its Adam can then run while later
+        buckets are still on the wire)"""
+        if handle is not None:
+            handle.wait()
+
     def finish(self, handles):
         for h in handles:
-            h.wait()
+            self.wait(h)
 
     def broadcast_(self, tensor, src=0):
         if self.enabled:

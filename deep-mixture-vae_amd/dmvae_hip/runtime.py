@@ -272,18 +272,26 @@ class StepEngine:
         check(lib.dmvae_plan_grad_buckets(self._plan, b), "dmvae_plan_grad_buckets")
         return [(b[2], b[3]), (b[1], b[2]), (b[0], b[1])]
 
-    def _backward_with_exchange(self, grad_sync, n_valid=None, eps=None, gumbel=None, inv_B=None):
-        """forward + backward with the gradient exchange: bucketed and overlapped when the exchange
-        offers start()/finish(), else one collective on the whole arena."""
+    def update_range(self, lo, hi, grad_scale=1.0):
+        check(lib.dmvae_plan_update_range(self._plan, self._stream(), float(grad_scale), int(lo), int(hi)), "dmvae_plan_update_range")
+
+    def _step_with_exchange(self, grad_sync, grad_scale, n_valid=None, eps=None, gumbel=None, inv_B=None):
+        """forward + backward + gradient exchange + Adam.  Bucketed and overlapped when the exchange
+        offers start()/wait(): each bucket is updated as soon as its all-reduce has landed, while the
+        later ones are still in flight; else one collective on the whole arena, then one Adam."""
         if getattr(grad_sync, "overlap", False):
+            buckets = self.grad_buckets()
             handles = []
-            for stage, (lo, hi) in enumerate(self.grad_buckets()):
+            for stage, (lo, hi) in enumerate(buckets):
                 self.forward_backward_stage(stage, n_valid, eps, gumbel, inv_B)
                 handles.append(grad_sync.start(self.grad[lo:hi]))
-            grad_sync.finish(handles)
+            for h, (lo, hi) in zip(handles, buckets):
+                grad_sync.wait(h)
+                self.update_range(lo, hi, grad_scale)
         else:
             self.forward_backward(n_valid, eps, gumbel, inv_B)
             grad_sync(self.grad)
+            self.update(grad_scale)
 
     def update(self, grad_scale=1.0):
         check(lib.dmvae_plan_update(self._plan, self._stream(), float(grad_scale)), "dmvae_plan_update")
@@ -351,9 +359,9 @@ class StepEngine:
             self.forward_backward_update(n_valid, eps, gumbel, inv_B)
             return
         if grad_sync is not None:
-            self._backward_with_exchange(grad_sync, n_valid, eps, gumbel, inv_B)
-        else:
-            self.forward_backward(n_valid, eps, gumbel, inv_B)
+            self._step_with_exchange(grad_sync, grad_scale, n_valid, eps, gumbel, inv_B)
+            return
+        self.forward_backward(n_valid, eps, gumbel, inv_B)
         self.update(grad_scale)
 
     def capture_step(self, data, perm, grad_sync=None, grad_scale=1.0, inv_B=None):
@@ -383,23 +391,25 @@ class StepEngine:
         if getattr(grad_sync, "overlap", False):
             buckets = self.grad_buckets()
             segs = [torch.cuda.CUDAGraph() for _ in range(3)]
-            gu = torch.cuda.CUDAGraph()
+            upds = [torch.cuda.CUDAGraph() for _ in range(3)]
             for stage, g in enumerate(segs):
                 with torch.cuda.graph(g, stream=side):
                     if stage == 0:
                         self.load_batch(data, perm, 0, None, True)
                     self.forward_backward_stage(stage, None, None, None, inv_B)
-            with torch.cuda.graph(gu, stream=side):
-                self.update(grad_scale)
-            self._graph = (*segs, gu)
+            for g, (lo, hi) in zip(upds, buckets):
+                with torch.cuda.graph(g, stream=side):
+                    self.update_range(lo, hi, grad_scale)
+            self._graph = (*segs, *upds)
 
             def replay_overlapped():
                 handles = []
                 for g, (lo, hi) in zip(segs, buckets):
                     g.replay()
                     handles.append(grad_sync.start(self.grad[lo:hi]))
-                grad_sync.finish(handles)
-                gu.replay()
+                for h, g in zip(handles, upds):      # Adam of a bucket as soon as its sum has landed
+                    grad_sync.wait(h)
+                    g.replay()
             return replay_overlapped
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(ga, stream=side):

@@ -302,6 +302,9 @@ int dmvae_plan_grad_buckets(const dmvae_plan* p, int64_t bounds[4]);
  * dmvae_plan_forward_backward has already advanced state->adam_t for this step: every
  * forward_backward is to be followed by exactly one update. */
 int dmvae_plan_update(dmvae_plan* p, void* stream, float grad_scale);
+/* the same on the arena elements [lo, hi) only (4-aligned): with the bucketed gradient exchange each
+ * bucket is updated as soon as its all-reduce has landed, while later buckets are still in flight */
+int dmvae_plan_update_range(dmvae_plan* p, void* stream, float grad_scale, int64_t lo, int64_t hi);
 /* forward + loss + backward + Adam as ONE sequence with the update fused into the dW launch
  * (single-process training on a bf16 plan: no gradient exchange between backward and update).
  * Equivalent to dmvae_plan_forward_backward followed by dmvae_plan_update(grad_scale = 1), except
