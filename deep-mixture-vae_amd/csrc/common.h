@@ -123,6 +123,16 @@ __device__ __forceinline__ float philox_normal_at(uint64_t seed, uint64_t step, 
     const float ang = 6.283185307179586f * u01(r[1]);
     return (idx & 1) ? rad * __sinf(ang) : rad * __cosf(ang);
 }
+// four independent N(0,1) draws from ONE Philox block (two Box-Muller pairs): the latent kernel's
+// lanes own four columns each, so this replaces four blocks of ten rounds by one
+__device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t step, uint32_t stream_id, uint64_t blk, float (&n)[4]) {
+    uint32_t r[4];
+    philox_block(seed, step, stream_id, blk, r);
+    const float rad0 = sqrtf(-2.0f * __logf(u01(r[0]))), ang0 = 6.283185307179586f * u01(r[1]);
+    const float rad1 = sqrtf(-2.0f * __logf(u01(r[2]))), ang1 = 6.283185307179586f * u01(r[3]);
+    n[0] = rad0 * __cosf(ang0); n[1] = rad0 * __sinf(ang0);
+    n[2] = rad1 * __cosf(ang1); n[3] = rad1 * __sinf(ang1);
+}
 __device__ __forceinline__ float philox_gumbel_at(uint64_t seed, uint64_t step, uint32_t stream_id, uint64_t idx) {
     uint32_t r[4];
     philox_block(seed, step, stream_id, idx >> 2, r);

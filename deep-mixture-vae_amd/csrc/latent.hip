@@ -240,6 +240,17 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
             float mu[DSL], e[DSL], lvv[DSL];
             bool ok[DSL];
             float lvsum = 0.f;
+            // device noise: one Philox block per four of this lane's columns, keyed by (row, chunk, lane, group)
+            float nz[DSL < 4 ? 4 : DSL];
+            if (!a.eps && valid) {
+#pragma unroll
+                for (int j = 0; j < (DSL + 3) / 4; ++j) {
+                    float q4[4];
+                    philox_normal4(a.seed, nstep, 0u, ((((uint64_t)b * L.nchunks + c) * 16 + lr) * ((DSL + 3) / 4)) + j, q4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) nz[4 * j + u] = q4[u];
+                }
+            }
 #pragma unroll
             for (int i = 0; i < DSL; ++i) {
                 const int d = lr + 16 * i;
@@ -253,8 +264,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                         lvv[i] = first ? lv_pre[i] : a.log_var[(int64_t)b * a.ld_log_var + dg];
                         e[i] = __expf(lvv[i]);
                         const float sd = __expf(0.5f * lvv[i]);
-                        const float ep = a.eps ? (first ? ep_pre[i] : a.eps[(int64_t)b * a.ld_eps + dg])
-                                               : philox_normal_at(a.seed, nstep, 0u, (uint64_t)b * D + dg);
+                        const float ep = a.eps ? (first ? ep_pre[i] : a.eps[(int64_t)b * a.ld_eps + dg]) : nz[i];
                         z = mu[i] + sd * ep;
                         cl = ep * 0.5f * sd;
                         lvsum += lvv[i];

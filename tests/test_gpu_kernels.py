@@ -386,6 +386,14 @@ def test_latent_bf16_outputs_and_device_noise(hip):
     np.testing.assert_array_equal(g1["Z"], g2["Z"])            # same (seed, step) -> same noise
     epsd = (g1["Zf"][:B] - mean) / np.exp(lv / 2)              # recover the Philox normals
     assert abs(epsd.mean()) < 0.02 and abs(epsd.std() - 1.0) < 0.02
+    # four draws share one Philox block (two Box-Muller pairs): still i.i.d. N(0,1)
+    z0 = run_latent(L, np.zeros((2048, 64)), np.zeros((2048, 64)), rng.randn(2048, K), None, None, pm, plv, 0, 1.0, 1.0, 0)["Zf"][:2048]
+    assert abs(z0.mean()) < 0.01 and abs(z0.std() - 1.0) < 0.01
+    assert abs((z0 ** 3).mean()) < 0.03 and abs((z0 ** 4).mean() - 3.0) < 0.1
+    assert len(np.unique(z0.round(6))) > 0.95 * z0.size > 0                     # no block reused across rows / lanes
+    cc = np.corrcoef(z0.T)                                                        # columns (incl. the 4 of one lane: d, d+16, d+32, d+48)
+    assert np.abs(cc - np.eye(64)).max() < 0.12
+    assert abs(np.corrcoef(z0[:-1].ravel(), z0[1:].ravel())[0, 1]) < 0.01         # consecutive rows
     np.testing.assert_allclose(g1["Z"][:B, :D], g1["Zf"][:B], rtol=1e-2, atol=1e-2)   # bf16 copy of the f32 Z
 
 
