@@ -307,12 +307,16 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bfr[j]));
 #else
+        // the wave that has its fragments goes first: two waves share a SIMD, the other one is waiting on
+        // LDS or the barrier anyway (measured on the step, tools/ab_libs.sh: 0.3136 -> 0.3110 ms)
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 // operands swapped: D[row = n][col = m] -> each lane owns 4 consecutive n of one m
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
 #endif
         if constexpr (DW) {
             if (do_bias) {
