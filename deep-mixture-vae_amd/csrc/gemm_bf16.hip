@@ -466,7 +466,10 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
 }
 
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW>
-__global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmArgs a) {
+// second bound = waves per SIMD the register budget must allow: two resident workgroups per CU (the
+// rings are sized for that); without it the 128x128 dX instantiation took 130 VGPRs = one workgroup per CU
+// (the recon epilogue with its prefetched targets would spill under that budget: left unconstrained)
+__global__ __launch_bounds__(64 * NW, (EPI == DMVAE_EPI_BIAS_RECON ? 1 : NW / 2)) void gemm_bf16_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * (BM + BN) * BK];
     gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW>(a, blockIdx.x, 0, gridDim.x, smem);
 }
