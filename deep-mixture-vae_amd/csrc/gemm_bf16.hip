@@ -490,8 +490,8 @@ struct GroupedArgs {
     GemmArgs p[DMVAE_MAX_GROUP];
     dmvae_adam_ctx adam;      // DMVAE_EPI_ADAM launches only
 };
-template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE>
-__global__ __launch_bounds__(256) void gemm_bf16_grouped_kernel(GroupedArgs g) {
+template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_bf16_grouped_kernel(GroupedArgs g) {
     // every problem takes the largest tile its shape divides (traffic per flop ~ (BM+BN)/(BM*BN)):
     // kind 0 = 128x128 / 2 stages, 1 = 128x64 / 3, 2 = 64x64 / 4  -- one LDS array of the largest ring
     __shared__ __attribute__((aligned(16))) bf16_t smem[3 * (128 + 64) * BK];   // 72 KiB >= 2*(128+128)*64, 4*(64+64)*64
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_grouped_kernel(GroupedArgs g) {
     if constexpr (EPI == DMVAE_EPI_ADAM) {
         if ((int)blockIdx.x >= g.start[g.nprob]) {   // the extra workgroup(s): arena segment whose gradient is already in memory
             const int64_t n4 = g.adam.seg_n >> 2;
-            for (int64_t q = (int64_t)((int)blockIdx.x - g.start[g.nprob]) * 256 + threadIdx.x; q < n4; q += (int64_t)((int)gridDim.x - g.start[g.nprob]) * 256) {
+            for (int64_t q = (int64_t)((int)blockIdx.x - g.start[g.nprob]) * (64 * NW) + threadIdx.x; q < n4; q += (int64_t)((int)gridDim.x - g.start[g.nprob]) * (64 * NW)) {
                 const int64_t off = g.adam.seg_off + 4 * q;
                 const float4 gq = *reinterpret_cast<const float4*>(g.adam.grad + off);
                 const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
@@ -517,9 +517,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_grouped_kernel(GroupedArgs g) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // (a 4-slot ring of K depth 32 in the same 64 KiB was measured for the 128x128 dW tiles: no gain)
-    if (kind == 0) gemm_bf16_body<128, 128, LAYOUT, EPI, 2, 4>(g.p[i], bid, gs, cnt, smem, ac);
-    else if (kind == 1) gemm_bf16_body<128, 64, LAYOUT, EPI, 3, 4>(g.p[i], bid, gs, cnt, smem, ac);
-    else gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, 4>(g.p[i], bid, gs, cnt, smem, ac);
+    if (kind == 0) gemm_bf16_body<128, 128, LAYOUT, EPI, 2, NW>(g.p[i], bid, gs, cnt, smem, ac);
+    else if (kind == 1) gemm_bf16_body<128, 64, LAYOUT, EPI, 3, NW>(g.p[i], bid, gs, cnt, smem, ac);
+    else gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW>(g.p[i], bid, gs, cnt, smem, ac);
 #if DMVAE_ABLATE == 6
     if (threadIdx.x == 0 && blockIdx.x < 2048) {
         unsigned long long* st = g_stamps + 4 * blockIdx.x;
@@ -655,7 +655,8 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
         if (ctx->seg_n > 0) extra = (int)std::min<int64_t>(4, (ctx->seg_n / 4 + 255) / 256);
     }
     ProfScope ps(s, kernel_name<64, 64, LAYOUT, EPI, 4>(true), flops, bytes);
-    hipLaunchKernelGGL((gemm_bf16_grouped_kernel<64, 64, LAYOUT, EPI, 4>), dim3(total + extra), dim3(256), 0, s, g);
+    // (8-wave workgroups in the grouped grids were measured too: 0.3071 vs 0.3014 ms/step, not kept)
+    hipLaunchKernelGGL((gemm_bf16_grouped_kernel<64, 64, LAYOUT, EPI, 4, 4>), dim3(total + extra), dim3(256), 0, s, g);
     return check_launch("gemm_bf16_grouped");
 }
 
