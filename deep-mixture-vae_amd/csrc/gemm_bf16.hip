@@ -726,14 +726,16 @@ template <int LAYOUT, int EPI>
 static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split) {
     GemmArgs a = a0;
     const int t = gemm_bf16_tile_m(a.M, a.N, split);
+    // (256x128 tiles -- one 8-wave workgroup per CU, 3 x 48 KiB ring, 25 % fewer bytes per flop -- were
+    //  measured three times and not kept: at M = 4096 the 2048-wide forward layer 16.7 vs 15.9 us, its dX
+    //  17.1 vs 19.0 us; whole step at B = 16384: 1.0753 vs 1.0706 ms, at B = 8192 / D 256 / K 50: 0.8079 vs
+    //  0.7922 ms.  Two resident workgroups overlapping their load / compute / store phases beat the
+    //  smaller intake of one.)
     a.group_m = auto_group_m(a.M / (t / 1000), a.N / (t % 1000), t / 1000, t % 1000);
     const long wgs = (long)(a.M / (t / 1000)) * (a.N / (t % 1000)) * split;
     // one workgroup per CU at most -> a single deep ring (more bytes in flight); else two shallow ones
     const bool deep = g_deep < 0 ? wgs <= 320 : g_deep == 1;
     switch (t) {
-        // (256x128, one 8-wave workgroup per CU with a 3 x 48 KiB ring, was measured: 4096x2048x512 forward
-        //  16.7 vs 15.9 us, its dX 17.1 vs 19.0 us -- 25 % less intake, but no second workgroup to overlap
-        //  load / compute / store phases with; not kept)
         case 128128:
             if (deep) return launch<128, 128, LAYOUT, EPI, 4, 8>(s, a, split);
             return g_nw8 ? launch<128, 128, LAYOUT, EPI, 2, 8>(s, a, split) : launch<128, 128, LAYOUT, EPI, 2>(s, a, split);

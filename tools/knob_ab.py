@@ -12,7 +12,8 @@ res = {v: [] for v in values}
 engs = {}
 for v in values:
     L.check(L.lib.dmvae_debug_set_knob(which, v))
-    e = StepEngine(784, 64, 10, dtype="bf16", max_batch=4096); e.init_parameters(0); e.reset_epoch(16)
+    e = StepEngine(784, int(os.environ.get("AB_D", 64)), int(os.environ.get("AB_K", 10)), dtype="bf16", max_batch=int(os.environ.get("AB_B", 4096)))
+    e.init_parameters(0); e.reset_epoch(65536 // int(os.environ.get("AB_B", 4096)))
     engs[v] = (e, e.capture_step(data, perm))        # the knob is baked into the captured graph
 for rnd in range(5):
     for v in values:
