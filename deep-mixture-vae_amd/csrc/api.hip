@@ -392,18 +392,15 @@ static int grad_dense(dmvae_plan* p, hipStream_t s, const void* X, int64_t ldx, 
     return gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_DW, Mdim, N, p->Bp, X, ldx, dY, ldy, &e, split);
 }
 
-// Launch the queued weight-gradient problems as ONE grouped grid.  They depend only on tensors
-// that already exist (X_l from the forward pass, dY_l just produced) and nothing on the dX chain
-// depends on them, so they go to the plan's side stream (fork: event on `s`, awaited by `side`;
-// the join is at the end of forward_backward) and share the CUs with the chain's GEMMs, which
-// leave half of each CU's LDS and wave slots free.  The fork/join is plain event record/wait, so
-// it is captured into the same HIP graph as the rest of the step.
-//
-// MEASURED (cfg2, MI355X, round 1): overlapping is SLOWER -- 0.4235 vs 0.391 ms/step.  The dW grid
-// and the dX chain are bound by the same per-CU L2->LDS path, and three small groups are less
-// efficient than one large one (164 vs 109 us).  So by default everything queues until the last
-// call (group 2) and goes out as ONE grouped launch on the main stream; DMVAE_DW_OVERLAP=1
-// re-enables the side-stream form for re-measurement on other shapes.
+// Launch the queued weight-gradient problems as ONE grouped grid (with the Adam update in its
+// epilogue under dmvae_plan_train_step).  Three forms:
+//   default   everything queues until the last call (group 2): one launch, on the main stream;
+//   staged    (dmvae_plan_forward_backward_stage, data parallel) every group is launched where it
+//             is flushed, so that its gradient bucket is final when the segment ends;
+//   DMVAE_DW_OVERLAP=1   every group goes to the plan's side stream beside the dX chain (fork /
+//             join by events, capturable).  MEASURED (cfg2, round 1): SLOWER, 0.4235 vs 0.391
+//             ms/step -- the dW grid and the dX chain are bound by the same per-CU intake, and
+//             three small groups fill the chip worse than one large one.  Kept for re-measurement.
 static int flush_dw(dmvae_plan* p, hipStream_t s, int group) {
     if (p->dw_queue.empty()) return 0;
     if (!p->overlap_dw && !p->staged && group != 2) return 0;

@@ -13,8 +13,14 @@
 //
 // Data movement: tiles go global -> LDS directly (global_load_lds_dwordx4,
 // 16 B per lane, no VGPR staging) into an NSTAGE-deep LDS ring; NSTAGE-1 K
-// tiles are in flight while one is multiplied, retired by a COUNTED
-// s_waitcnt vmcnt(N) and one raw s_barrier per K step.  The LDS-DMA is issued
+// tiles are in flight while one is multiplied (its fragments double-buffered in
+// registers, so a slot is refilled as soon as its second half has been read),
+// retired by a COUNTED s_waitcnt vmcnt(N) and one raw s_barrier per K step.
+// What bounds these kernels is the CU's intake (L2 -> LDS, ~70 GB/s per CU,
+// DESIGN.md section 6), so: as few bytes per flop as the grid size allows, TWO
+// resident workgroups per CU whose load / compute / store phases overlap (rings
+// <= 72 KiB, register budget for 4 waves per SIMD), and the epilogue's global
+// reads issued before the K loop.  The LDS-DMA is issued
 // from inline asm: through __builtin_amdgcn_global_load_lds hipcc (ROCm 7.2)
 // treats it as a may-alias LDS store and drains the ring with vmcnt(0) before
 // the first ds_read of every K step (measured: ring depth then buys nothing).
@@ -33,7 +39,8 @@
 // (the last two keep each transposing read's 8 rows x 32 B of a 32-lane half
 // on distinct bank groups).
 //
-// Block = 256 threads = 4 waves (2 x 2), BK = 64.
+// Block = 4 waves (2 x 2) or 8 waves (4 x 2), BK = 64.  Epilogue: the fp32 tile is parked in the
+// idle ring and re-read row-contiguous (see the body), then the fused op of include/dmvae_hip.h.
 #include <algorithm>
 #include <cmath>
 #include <functional>
