@@ -559,7 +559,7 @@ static const char* kernel_name(bool grouped) {   // the template instantiation, 
     static bool init = false;
     if (!init) {
         snprintf(nm[0], 64, "gemm_bf16_kernel<%d, %d, %d, %d, %d, %d>", BM, BN, LAYOUT, EPI, NSTAGE, NW);
-        snprintf(nm[1], 64, "gemm_bf16_grouped_kernel<%d, %d, %d, %d, %d>", BM, BN, LAYOUT, EPI, NSTAGE);
+        snprintf(nm[1], 64, "gemm_bf16_grouped_kernel<%d, %d, %d, %d, %d, %d>", BM, BN, LAYOUT, EPI, NSTAGE, NW);
         init = true;
     }
     return nm[grouped ? 1 : 0];
