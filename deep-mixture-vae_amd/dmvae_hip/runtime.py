@@ -385,9 +385,18 @@ class StepEngine:
                 self.train_step(data, perm, None, None, None, 0, True, None, grad_scale, inv_B)
             self._graph = (g,)
             return g.replay
-        # data parallel: graphs with the collectives issued eagerly between them (keeps RCCL out of
-        # stream capture).  Overlapped form: one graph per backward segment; each bucket's
-        # all-reduce starts behind its segment and runs beside the next one.
+        # data parallel.  MEASURED (one GPU, no-op exchange, `bench.py --dp-dry-run`): issuing the
+        # sequence eagerly is faster than replaying it as several small graphs with the collectives
+        # between them (three segments + three bucket updates: 0.362 vs 0.396 ms; one backward +
+        # Adam: 0.313 vs 0.326 ms) -- the host stays ahead of a 0.3 ms step and every graph launch
+        # has its own cost.  So the data-parallel step is issued eagerly; DMVAE_DP_GRAPHS=1 keeps the
+        # graph form (collectives outside capture) for re-measurement.
+        import os
+        if os.environ.get("DMVAE_DP_GRAPHS", "0") != "1":
+            def eager_step():
+                self.train_step(data, perm, None, None, None, 0, True, grad_sync, grad_scale, inv_B)
+            self._graph = None
+            return eager_step
         if getattr(grad_sync, "overlap", False):
             buckets = self.grad_buckets()
             segs = [torch.cuda.CUDAGraph() for _ in range(3)]
