@@ -9,7 +9,10 @@ Pinning status (see DESIGN.md "Oracle"):
   * prior / latent-variable math (rows A2, A6, A6b, A9, A10 of SURVEY.md 8a) is
     pinned by golden vectors produced by executing the reference's own
     code/priors.py (oracle/make_golden.py, fixtures in tests/golden/).
-  * dense layers, sigmoid cross-entropy, autodiff backward and Adam live in
+  * the decoder's hidden FullyConnected stack (row A7, base_models.py:279-289) is pinned by
+    executing the reference's own includes/layers.py + includes/network.py
+    (oracle/make_network_golden.py).
+  * tf.layers.dense layers, sigmoid cross-entropy, autodiff backward and Adam live in
     TensorFlow 1.x (third party, not vendored, not installed): for those rows
     this file restates the documented TF semantics; PARITY UNPINNED by any
     reference run -- checked instead against closed forms and torch-autograd

@@ -66,3 +66,38 @@ initializers = types.SimpleNamespace(random_normal=_random_normal, zeros=_zeros)
 
 def get_variable(name, shape=None, dtype=None, initializer=None, trainable=True):
     return initializer(tuple(shape))
+
+
+# ---- additions for code/includes/layers.py + network.py (FullyConnected / DeepNetwork, the decoder
+# of base_models.py:279-289): eager NumPy meaning of the ops their class bodies and _call use.
+def _relu(x):
+    return np.maximum(x, 0.0)
+
+
+nn.relu = _relu
+
+
+@contextlib.contextmanager
+def name_scope(name, *a, **k):
+    yield name
+
+
+def _flatten(x):
+    x = np.asarray(x)
+    return x.reshape(x.shape[0], -1)
+
+
+layers = types.SimpleNamespace(flatten=_flatten)
+
+
+def _xavier_initializer():
+    """tf.contrib.layers.xavier_initializer(): uniform, limit sqrt(6 / (fan_in + fan_out)) -- TensorFlow's
+    documented rule restated (the golden generator overwrites the variables anyway; only shapes matter)."""
+    def init(shape, dtype=np.float64):
+        fan_in, fan_out = (shape[0], shape[1]) if len(shape) == 2 else (int(np.prod(shape[:-1])), shape[-1])
+        lim = np.sqrt(6.0 / (fan_in + fan_out))
+        return np.random.uniform(-lim, lim, size=shape).astype(np.float64)
+    return init
+
+
+contrib = types.SimpleNamespace(layers=types.SimpleNamespace(xavier_initializer=_xavier_initializer))
