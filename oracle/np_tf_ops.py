@@ -101,3 +101,21 @@ def _xavier_initializer():
 
 
 contrib = types.SimpleNamespace(layers=types.SimpleNamespace(xavier_initializer=_xavier_initializer))
+
+
+# ---- additions for code/base_models.py's VAE base class (constructor placeholders only): a placeholder is
+# an opaque hashable token that the mocked session of oracle/make_trainop_golden.py finds in its feed dict.
+class _Token:
+    def __init__(self, name):
+        self.name = name
+
+    def __repr__(self):
+        return "<placeholder %s>" % self.name
+
+
+def placeholder_with_default(value, shape=None, name=None):
+    return _Token(name)
+
+
+def placeholder(dtype=None, shape=None, name=None):
+    return _Token(name)
