@@ -337,3 +337,33 @@ def test_two_ranks_equal_one_rank_to_fp32_roundoff(overlap):
     # can flip a sign of m/sqrt(v) only where |g| ~ 1e-9, so compare the bulk tightly and the tail loosely
     assert np.percentile(d, 99.9) <= 2e-6, np.percentile(d, 99.9)
     assert d.max() <= 4.1e-3
+
+
+def test_deep_stack_more_than_sixteen_weight_gradients():
+    """8 + 8 layers give 20 dW problems: more than one grouped launch holds (16).  The queue is then
+    launched early; fused, plain and staged backward must still agree bit for bit, and the bf16
+    gradients must track the fp32 engine."""
+    kw = dict(input_dim=96, latent_dim=8, n_classes=4, enc_layers=(64,) * 8, head_dim=64, dec_layers=(64,) * 8)
+    B = 128
+    rng = np.random.RandomState(31)
+    Xd = torch.as_tensor((rng.rand(B, 96) * (rng.rand(B, 96) < 0.4)).astype(np.float32)).cuda()
+    ed = torch.as_tensor(rng.randn(B, 8).astype(np.float32)).cuda()
+    plain, fused, staged, ref = (make(kw, dt, B, seed=5) for dt in ("bf16", "bf16", "bf16", "fp32"))
+    for eng in (plain, staged, ref, fused):
+        eng.load_batch(Xd, None, 0, B)
+    plain.forward_backward(B, ed)
+    ref.forward_backward(B, ed)
+    for stage in range(3):
+        staged.forward_backward_stage(stage, B, ed)
+    torch.cuda.synchronize()
+    assert torch.equal(plain.grad, staged.grad)
+    gp, gr = plain.get_gradients(), ref.get_gradients()
+    assert len([k for k in gp if k.startswith("W_")]) == 8 + 5 + 8 + 1     # 20 GEMM problems: [zh|ch] and [mean|log_var] are fused pairs
+    for k in gp:
+        rel = np.linalg.norm(gp[k] - gr[k]) / (np.linalg.norm(gr[k]) + 1e-30)
+        assert rel <= 0.15, (k, rel)          # bf16 through 18 layers
+    plain.update(1.0)
+    fused.forward_backward_update(B, ed)
+    torch.cuda.synchronize()
+    for name in ("param", "m", "v", "param_bf16"):
+        assert torch.equal(getattr(plain, name), getattr(fused, name)), name
