@@ -193,6 +193,20 @@ __device__ __forceinline__ void adam_quad(const dmvae_adam_ctx& c, int64_t off, 
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// XCD-aware order (speed only, never correctness): workgroups are dealt round-robin over the 8
+// XCDs, so ids b and b+8 share an L2.  Of the workgroup ids [gstart, gend), XCD x owns those with
+// id & 7 == x; give each XCD a CONTIGUOUS run of work items: returns the item index in
+// [0, gend - gstart) of workgroup gid (a bijection for any range).
+__device__ __forceinline__ int xcd_run_index(const int gid, const int gstart, const int gend) {
+    const int xcd = gid & 7;
+    int run0 = 0;                                        // items owned by the XCD labels below ours
+    for (int y = 0; y < xcd; ++y) {
+        const int first = gstart + ((y - gstart) & 7);
+        run0 += first < gend ? ((gend - 1 - first) >> 3) + 1 : 0;
+    }
+    return run0 + ((gid - (gstart + ((xcd - gstart) & 7))) >> 3);
+}
+
 // One output tile of one GEMM problem.  bid_raw = tile id within the problem, nwg = number of
 // workgroups of the launch when the launch is this single problem (XCD-aware remap), else 0.
 // NW = waves per workgroup: 4 (2 x 2) or 8 (4 x 2: two waves per SIMD share one tile's LDS traffic).
@@ -219,16 +233,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     // ids (bijective for any grid size) ...
     // The problem owns the global workgroup ids [gstart, gstart + nwg) (gstart = 0 for a plain
     // launch, the problem's first id inside a grouped grid).
-    int bid;
-    {
-        const int gid = gstart + bid_raw, xcd = gid & 7, gend = gstart + nwg;
-        int run0 = 0;                                    // tiles owned by the XCD labels below ours
-        for (int y = 0; y < xcd; ++y) {
-            const int first = gstart + ((y - gstart) & 7);
-            run0 += first < gend ? ((gend - 1 - first) >> 3) + 1 : 0;
-        }
-        bid = run0 + ((gid - (gstart + ((xcd - gstart) & 7))) >> 3);
-    }
+    const int bid = nwg < 0 ? bid_raw : xcd_run_index(gstart + bid_raw, gstart, gstart + nwg);   // nwg < 0: the caller did the remap
     // ... and walk the tiles of a run in supertiles of group_m tile-rows (column-major inside a
     // supertile): the ~32 tiles an XCD works on at one time then form a group_m x (32/group_m)
     // block, i.e. few A and few B panels, each reused from L2 by several workgroups.
@@ -494,6 +499,7 @@ struct GroupedArgs {
     int nprob;
     int kind[DMVAE_MAX_GROUP];
     int start[DMVAE_MAX_GROUP + 1];
+    int cls_start[DMVAE_MAX_GROUP], cls_end[DMVAE_MAX_GROUP];
     GemmArgs p[DMVAE_MAX_GROUP];
     dmvae_adam_ctx adam;      // DMVAE_EPI_ADAM launches only
 };
@@ -515,11 +521,19 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_grouped_kernel(GroupedArgs 
             return;
         }
     }
+    // A CLASS is a run of consecutive problems with the same tile shape (cls[] holds each
+    // problem's class bounds as workgroup ids).  The XCD runs are cut over the class, not over
+    // each problem: an XCD then works on one or two problems with large blocks of their tiles
+    // instead of an eighth of every problem, so far fewer operand panels are fetched by more
+    // than one L2.  The workgroup mix per XCD / CU is unchanged (a permutation inside a class).
     int i = 0;
     while (i + 1 < g.nprob && (int)blockIdx.x >= g.start[i + 1]) ++i;
-    const int bid = (int)blockIdx.x - g.start[i];
+    const int item = g.cls_start[i] + xcd_run_index((int)blockIdx.x, g.cls_start[i], g.cls_end[i]);
+    i = 0;
+    while (i + 1 < g.nprob && item >= g.start[i + 1]) ++i;
+    const int bid = item - g.start[i];
     const int kind = g.kind[i];
-    const int gs = g.start[i], cnt = g.start[i + 1] - gs;
+    const int gs = 0, cnt = -1;                           // the body takes bid as the tile id
 #if DMVAE_ABLATE == 6     // placement / timeline stamps of every workgroup (tools/stamps.py)
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -544,14 +558,15 @@ static int g_group_m = 0;                   // tuning knob (dmvae_debug_set_knob
 // supertiles gm tile-rows high, so its L2 sees ~gm A panels (BM x K each) and ~R/gm B panels
 // (BN x K each); fabric traffic ~ gm*BM + (R/gm)*BN is least at gm = sqrt(R*BN/BM).  Measured on
 // the step (tools/knob_ab.py 0 ...): fixed 8 -> 0.3356 ms, 4 (= this rule for N = 512) -> 0.3300 ms.
-static int auto_group_m(int tiles_m, int tiles_n, int bm, int bn) {
+static int auto_group_m(int tiles_m, int tiles_n, int bm, int bn, double run = 0.0) {
     if (g_group_m > 0) return g_group_m;
-    const double R = std::max(1.0, tiles_m * (double)tiles_n / 8.0);
+    const double R = run > 0.0 ? run : std::max(1.0, tiles_m * (double)tiles_n / 8.0);
     int gm = (int)(std::sqrt(R * bn / bm) + 0.5);
     const int need = (int)((R + tiles_n - 1) / tiles_n);       // rows a run spans anyway
     gm = std::max(gm, need);
     return std::max(1, std::min(gm, tiles_m));
 }
+static int g_grouped_cls = 1;               // tuning knob (dmvae_debug_set_knob 4): XCD runs cut per tile-shape class (1) or per problem (0)
 static int g_grouped_mixed = 1;             // tuning knob (dmvae_debug_set_knob 2): 0 all 64x64, 1 planned per-problem tiles, 2 largest tile each shape divides
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4>
 static const char* kernel_name(bool grouped) {   // the template instantiation, as rocprofv3 prints it
@@ -651,6 +666,23 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
     }
     for (int i = nprob; i < DMVAE_MAX_GROUP; ++i) g.kind[i] = 2;
     for (int i = nprob; i <= DMVAE_MAX_GROUP; ++i) g.start[i] = total;
+    // classes: runs of consecutive problems with one tile shape (see the kernel); knob 4 = 0 makes
+    // every problem its own class (each problem spread over all eight XCDs)
+    for (int i = 0; i < DMVAE_MAX_GROUP; ++i) { g.cls_start[i] = g.start[std::min(i, nprob)]; g.cls_end[i] = g.start[std::min(i + 1, nprob)]; }
+    if (g_grouped_cls)
+        for (int lo = 0; lo < nprob;) {
+            int hi = lo + 1;
+            while (hi < nprob && g.kind[hi] == g.kind[lo]) ++hi;
+            const double run = std::max(1.0, (g.start[hi] - g.start[lo]) / 8.0);
+            for (int i = lo; i < hi; ++i) {
+                g.cls_start[i] = g.start[lo];
+                g.cls_end[i] = g.start[hi];
+                const int kind = g.kind[i], bm = kind == 2 ? 64 : 128, bn = kind == 0 ? 128 : 64;
+                const int t = g.start[i + 1] - g.start[i];
+                g.p[i].group_m = auto_group_m(g.p[i].M / bm, g.p[i].N / bn, bm, bn, std::min<double>(t, run));
+            }
+            lo = hi;
+        }
     int extra = 0;
     g.adam = dmvae_adam_ctx{};
     if (ctx) {
@@ -702,6 +734,7 @@ void gemm_bf16_set_knob(int which, int v) {
     if (which == 1) g_nw8 = v;
     if (which == 2) g_grouped_mixed = v;
     if (which == 3) g_deep = v;
+    if (which == 4) g_grouped_cls = v;
 }
 
 // Tile choice, BM*1000+BN.  These GEMMs run at the per-CU L2->LDS streaming rate, so the figure
