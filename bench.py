@@ -118,7 +118,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # DMVAE_DP_FORCE=1 on a one-GPU box: a one-rank RCCL communicator, so the N > 1 launch sequence
+    # runs with the real (identity) collectives -- a rehearsal, never the reported N = 1 number
+    force_dp = world == 1 and os.environ.get("DMVAE_DP_FORCE") == "1"
+    if force_dp:
+        for k, v in (("MASTER_PORT", "29513"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
+    if world > 1 or force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "gloo":     # rehearsal of the N > 1 orchestration on a one-GPU box: ranks share the card
@@ -231,7 +237,7 @@ def main():
                                % ("configs[1]: " if is_cfg2 else "", arch),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                    "hip_graph": (not args.no_graph) and sync is None, "float_atomics": False,
-                   "update": "adam fused into the dW launch" if world == 1 else "bucketed all-reduce overlapped with backward, then adam"},
+                   "update": "adam fused into the dW launch" if sync is None else "bucketed all-reduce overlapped with backward, then adam"},
         "step_flops_algorithmic": fpi * B,
         "step_mfma_frac_of_peak": round(fpi * B / (ms_step * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4),
         "last_loss": round(float(st.last_loss), 4),
@@ -277,7 +283,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         import torch.distributed as dist
         dist.destroy_process_group()
 

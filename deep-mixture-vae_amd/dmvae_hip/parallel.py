@@ -9,6 +9,8 @@ exchange is ONE collective per step on the flat fp32 gradient arena
 CPU in the tests); the 1/world factor is folded into the Adam kernel
 (grad_scale), so no separate scaling pass touches HBM.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -27,7 +29,10 @@ class GradExchange:
 
     def __init__(self, group=None):
         self.group = group
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # DMVAE_DP_FORCE=1 keeps the exchange on in a world of one rank: the real collectives then run
+        # (as identities) on a one-GPU box -- how tests/test_gpu_step.py drives RCCL itself
+        force = os.environ.get("DMVAE_DP_FORCE") == "1"
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
 
@@ -48,7 +53,6 @@ class GradExchange:
     # arena) is exposed.  DMVAE_DP_OVERLAP=0 falls back to the single all-reduce.
     @property
     def overlap(self):
-        import os
         return self.enabled and os.environ.get("DMVAE_DP_OVERLAP", "1") != "0"
 
     def start(self, grad_slice):

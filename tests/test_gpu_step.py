@@ -339,6 +339,62 @@ def test_two_ranks_equal_one_rank_to_fp32_roundoff(overlap):
     assert d.max() <= 4.1e-3
 
 
+def _rccl_rank(port, overlap, out):
+    """a world of ONE rank on RCCL: every collective of the data-parallel step is the real library
+    call (an identity), on the streams and buffers the N > 1 job uses"""
+    import torch.distributed as dist
+    p = os.path.join(ROOT, "deep-mixture-vae_amd")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                      DMVAE_DP_FORCE="1", DMVAE_DP_OVERLAP="1" if overlap else "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from dmvae_hip import StepEngine, GradExchange
+    kw, B = dict(input_dim=784, latent_dim=64, n_classes=10), 512
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    data = torch.rand((4 * B, 784), device="cuda", generator=g)
+    perm = torch.randperm(4 * B, device="cuda", generator=g).to(torch.int32)
+    ex = GradExchange()
+    assert ex.enabled and ex.world == 1 and ex.overlap == overlap
+    res = []
+    for sync in (ex, None):
+        eng = StepEngine(dtype="bf16", max_batch=B, mode="exact", seed=77, **kw)
+        eng.init_parameters(3)
+        ex.broadcast_(eng.param)
+        eng.refresh_shadow()
+        eng.reset_epoch(4, kl_ratio=1.0)
+        step = eng.capture_step(data, perm, grad_sync=sync, grad_scale=1.0)
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        res.append((eng.param.cpu().numpy(), eng.read_state().adam_t, eng.read_state().epoch_loss))
+    out.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_rccl_exchange_on_one_rank_is_the_identity(overlap):
+    """The N > 1 step sequence (staged backward, bucketed asynchronous all-reduce on RCCL's stream,
+    per-bucket Adam) with a one-rank communicator must reproduce the single-process fused step bit
+    for bit: the collectives are identities, so any difference is a stream-ordering or
+    bucket-coverage fault in the data-parallel path."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    proc = ctx.Process(target=_rccl_rank, args=(port, overlap, out))
+    proc.start()
+    (p_dp, t_dp, l_dp), (p_one, t_one, l_one) = out.get(timeout=300)
+    proc.join(60)
+    assert proc.exitcode == 0
+    assert t_dp == t_one == 4
+    assert l_dp == l_one
+    np.testing.assert_array_equal(p_dp, p_one)
+
+
 def test_deep_stack_more_than_sixteen_weight_gradients():
     """8 + 8 layers give 20 dW problems: more than one grouped launch holds (16).  The queue is then
     launched early; fused, plain and staged backward must still agree bit for bit, and the bf16
