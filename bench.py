@@ -115,6 +115,11 @@ def cpu_baseline(args, seconds):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON: libraries that write to file descriptor 1 themselves
+    # (RCCL prints a version banner there at communicator creation) are pointed at stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -282,7 +287,8 @@ def main():
         out["kernel_ms_per_step_sum"] = round(sum(t["ms_per_step"] for t in table), 4)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
-    print(json.dumps(out), flush=True)
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or force_dp:
         import torch.distributed as dist
         dist.destroy_process_group()
