@@ -38,7 +38,8 @@ class Config:
 
     def __init__(self, input_dim=784, latent_dim=10, n_classes=10,
                  enc_layers=(500, 500), head_dim=2000,
-                 dec_layers=(2000, 500, 500), input_type="binary"):
+                 dec_layers=(2000, 500, 500), input_type="binary", cnn=False):
+        self.cnn = bool(cnn)
         self.input_dim = int(input_dim)
         self.latent_dim = int(latent_dim)
         self.n_classes = int(n_classes)
@@ -46,6 +47,19 @@ class Config:
         self.head_dim = int(head_dim)
         self.dec_layers = tuple(int(v) for v in dec_layers)
         self.input_type = input_type
+        if self.cnn:
+            # the checked-in encoder trunk (base_models.py:176-216): 28x28x1 images, six 3x3 SAME
+            # convolutions, three 2x2 SAME max-pools, then FullyConnected 2048 -> enc_layers[0]
+            assert self.input_dim == 784 and len(self.enc_layers) == 1, "cnn trunk: 784 inputs, one fc layer"
+
+    # (name, cin, cout, H=W of its input/output, pool after it)   base_models.py:181-201
+    CONV_STACK = (("conv0", 1, 32, 28, False), ("conv1", 32, 32, 28, True),
+                  ("conv2", 32, 64, 14, False), ("conv3", 64, 64, 14, True),
+                  ("conv4", 64, 128, 7, False), ("conv5", 128, 128, 7, True))
+    CONV_FLAT = 4 * 4 * 128      # 7 -> 4 under SAME pooling; "input_dim": 2048 at base_models.py:202
+
+    def conv_table(self):
+        return self.CONV_STACK if self.cnn else ()
 
     def layer_table(self):
         """[(name, fan_in, fan_out, bias_kind)] in forward order.
@@ -54,9 +68,10 @@ class Config:
         291-293); "xavier": FullyConnected bias of shape (1,out) created with
         the same xavier initializer (includes/layers.py:24-28)."""
         t = []
-        prev = self.input_dim
+        prev = self.CONV_FLAT if self.cnn else self.input_dim
         for i, h in enumerate(self.enc_layers):
-            t.append(("enc%d" % i, prev, h, "zero"))
+            # cnn: the trunk's last layer is a FullyConnected ("fc" spec, base_models.py:202), bias xavier
+            t.append(("enc%d" % i, prev, h, "xavier" if self.cnn else "zero"))
             prev = h
         trunk = prev
         t.append(("zh", trunk, self.head_dim, "zero"))
@@ -72,7 +87,7 @@ class Config:
         return t
 
     def n_params(self):
-        n = 0
+        n = sum(9 * ci * co + co for _, ci, co, _, _ in self.conv_table())
         for _, fi, fo, _ in self.layer_table():
             n += fi * fo + fo
         return n + 2 * self.n_classes * self.latent_dim
@@ -94,6 +109,12 @@ def init_params(cfg, seed=0, dtype=np.float64):
     means ~ N(0,1), prior log_vars = 0 (priors.py:57-65)."""
     rng = np.random.RandomState(seed)
     p = {}
+    for name, ci, co, _, _ in cfg.conv_table():
+        # Convolution (includes/layers.py:39-51): weight (3,3,cin,cout) and bias (cout,) both from the
+        # xavier initializer; TF's fans for a conv kernel are 9*cin / 9*cout, for a 1-D shape n / n.
+        # Stored flattened (ky,kx,cin) x cout = the HWIO memory order.
+        p["W_" + name] = xavier_uniform(rng, 9 * ci, 9 * co, (9 * ci, co), dtype)
+        p["b_" + name] = xavier_uniform(rng, co, co, (co,), dtype)
     for name, fi, fo, bk in cfg.layer_table():
         p["W_" + name] = xavier_uniform(rng, fi, fo, (fi, fo), dtype)
         if bk == "zero":
@@ -107,6 +128,8 @@ def init_params(cfg, seed=0, dtype=np.float64):
 
 def param_names(cfg):
     names = []
+    for name, _, _, _, _ in cfg.conv_table():
+        names += ["W_" + name, "b_" + name]
     for name, _, _, _ in cfg.layer_table():
         names += ["W_" + name, "b_" + name]
     return names + ["prior_means", "prior_log_vars"]
@@ -193,10 +216,90 @@ def _dense(x, W, b, relu):
     return np.maximum(y, 0) if relu else y
 
 
+def im2col3x3(x):
+    """[B,H,W,C] -> [B,H,W,9C]: column (ky*3+kx)*C + c holds x[y+ky-1, x+kx-1, c], zero outside the
+    image (tf.nn.conv2d padding='SAME', stride 1, 3x3: one zero pixel on every side)."""
+    B, H, W, C = x.shape
+    xp = np.zeros((B, H + 2, W + 2, C), x.dtype)
+    xp[:, 1:-1, 1:-1] = x
+    return np.concatenate([xp[:, ky:ky + H, kx:kx + W] for ky in range(3) for kx in range(3)], axis=3)
+
+
+def col2im3x3(dcol, C):
+    """adjoint of im2col3x3"""
+    B, H, W, _ = dcol.shape
+    dxp = np.zeros((B, H + 2, W + 2, C), dcol.dtype)
+    for ky in range(3):
+        for kx in range(3):
+            t = ky * 3 + kx
+            dxp[:, ky:ky + H, kx:kx + W] += dcol[..., t * C:(t + 1) * C]
+    return dxp[:, 1:-1, 1:-1]
+
+
+def conv3x3_relu(x, Wm, b):
+    """includes/layers.py:53-60: relu(bias_add(conv2d(x, W, strides 1, SAME), b)), W flattened HWIO"""
+    return np.maximum(im2col3x3(x) @ Wm + b, 0)
+
+
+def maxpool2_same(x):
+    """tf.nn.max_pool ksize 2 strides 2 padding SAME (includes/layers.py:72-75): out = ceil(H/2); the
+    pad (bottom / right only, when H is odd) never wins.  Returns (out, first-argmax one-hot [B,H,W,C])
+    -- the gradient goes to the first maximum of a window in row-major order."""
+    B, H, W, C = x.shape
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    xp = np.full((B, 2 * Ho, 2 * Wo, C), -np.inf, x.dtype)
+    xp[:, :H, :W] = x
+    win = np.stack([xp[:, dy::2, dx::2] for dy in range(2) for dx in range(2)], axis=0)   # [4,B,Ho,Wo,C]
+    out = win.max(axis=0)
+    first = np.argmax(win, axis=0)            # np.argmax returns the first maximum
+    route = np.zeros((B, 2 * Ho, 2 * Wo, C), bool)
+    for dy in range(2):
+        for dx in range(2):
+            route[:, dy::2, dx::2] = first == dy * 2 + dx
+    return out, route[:, :H, :W]
+
+
+def maxpool2_same_backward(dout, route):
+    B, H, W, C = route.shape
+    Ho, Wo = dout.shape[1:3]
+    up = np.repeat(np.repeat(dout, 2, axis=1), 2, axis=2)[:, :H, :W]
+    return up * route
+
+
+def cnn_trunk(p, cfg, X, acts):
+    """base_models.py:176-216: reshape to (-1,28,28,1), the conv / pool stack, flatten (h, w, c)"""
+    h = X.reshape(X.shape[0], 28, 28, 1)
+    for i, (name, ci, co, hw, pool) in enumerate(cfg.conv_table()):
+        acts[name + "_in"] = h
+        h = conv3x3_relu(h, p["W_" + name], p["b_" + name])
+        acts[name] = h
+        if pool:
+            h, acts["route%d" % i] = maxpool2_same(h)
+            acts["pool%d" % i] = h
+    acts["flat"] = h.reshape(h.shape[0], -1)
+    return acts["flat"]
+
+
+def cnn_trunk_backward(p, cfg, a, dflat, g):
+    dh = dflat.reshape(a["pool5"].shape)
+    table = cfg.conv_table()
+    for i in reversed(range(len(table))):
+        name, ci, co, hw, pool = table[i]
+        if pool:
+            dh = maxpool2_same_backward(dh, a["route%d" % i])
+        dy = dh * (a[name] > 0)
+        col = im2col3x3(a[name + "_in"])
+        g["W_" + name] = col.reshape(-1, 9 * ci).T @ dy.reshape(-1, co)
+        g["b_" + name] = dy.reshape(-1, co).sum(0)
+        if i > 0:
+            dh = col2im3x3(dy @ p["W_" + name].T, ci)
+    return g
+
+
 def encode(p, cfg, X):
     """Encoder trunk + z head + c head, base_models.py:220-249."""
     acts = {"x": X}
-    h = X
+    h = cnn_trunk(p, cfg, X, acts) if cfg.cnn else X
     for i in range(len(cfg.enc_layers)):
         h = _dense(h, p["W_enc%d" % i], p["b_enc%d" % i], True)
         acts["enc%d" % i] = h
@@ -365,11 +468,13 @@ def backward(p, cfg, a, masks=None):
     for i in reversed(range(ne)):
         y = a["enc%d" % i]
         dy = dh * (y > 0)
-        xin = a["enc%d" % (i - 1)] if i > 0 else X
+        xin = a["enc%d" % (i - 1)] if i > 0 else (a["flat"] if cfg.cnn else X)
         g["W_enc%d" % i] = xin.T @ dy
         g["b_enc%d" % i] = dy.sum(0)
-        if i > 0:
+        if i > 0 or cfg.cnn:
             dh = dy @ p["W_enc%d" % i].T
+    if cfg.cnn:
+        cnn_trunk_backward(p, cfg, a, dh, g)
     return g
 
 

@@ -119,3 +119,56 @@ def placeholder_with_default(value, shape=None, name=None):
 
 def placeholder(dtype=None, shape=None, name=None):
     return _Token(name)
+
+
+# ---- additions for the Convolution / MaxPooling layers of code/includes/layers.py:39-77 (the CNN trunk of
+# base_models.py:178-216).  Written as plain loops over taps / windows -- deliberately NOT the im2col
+# formulation of oracle/dmvae_oracle.py, so that the golden vectors check it.
+def _same_pads(size, k, s):
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return out, total // 2, total - total // 2       # TF puts the odd pixel at the end
+
+
+def _conv2d(inputs, W, strides=(1, 1, 1, 1), padding="SAME"):
+    assert padding == "SAME"
+    x = np.asarray(inputs, np.float64)
+    B, H, Wd, C = x.shape
+    kh, kw, ci, co = W.shape
+    assert ci == C
+    sh, sw = strides[1], strides[2]
+    Ho, pt, pb = _same_pads(H, kh, sh)
+    Wo, pl, pr = _same_pads(Wd, kw, sw)
+    xp = np.zeros((B, H + pt + pb, Wd + pl + pr, C))
+    xp[:, pt:pt + H, pl:pl + Wd] = x
+    out = np.zeros((B, Ho, Wo, co))
+    for ky in range(kh):
+        for kx in range(kw):
+            patch = xp[:, ky:ky + (Ho - 1) * sh + 1:sh, kx:kx + (Wo - 1) * sw + 1:sw]
+            out += np.tensordot(patch, W[ky, kx], axes=([3], [0]))
+    return out
+
+
+def _bias_add(x, b):
+    return x + np.asarray(b).reshape((1,) * (np.ndim(x) - 1) + (-1,))
+
+
+def _max_pool(inputs, ksize, strides, padding="SAME"):
+    assert padding == "SAME"
+    x = np.asarray(inputs, np.float64)
+    B, H, Wd, C = x.shape
+    kh, kw, sh, sw = ksize[1], ksize[2], strides[1], strides[2]
+    Ho, pt, pb = _same_pads(H, kh, sh)
+    Wo, pl, pr = _same_pads(Wd, kw, sw)
+    xp = np.full((B, H + pt + pb, Wd + pl + pr, C), -np.inf)
+    xp[:, pt:pt + H, pl:pl + Wd] = x
+    out = np.empty((B, Ho, Wo, C))
+    for i in range(Ho):
+        for j in range(Wo):
+            out[:, i, j] = xp[:, i * sh:i * sh + kh, j * sw:j * sw + kw].max(axis=(1, 2))
+    return out
+
+
+nn.conv2d = _conv2d
+nn.bias_add = _bias_add
+nn.max_pool = _max_pool

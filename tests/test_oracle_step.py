@@ -94,6 +94,17 @@ def torch_loss(pt, cfg, X, eps, kl_ratio, mode, gumbel, tau):
         y = x @ pt["W_" + n] + pt["b_" + n]
         return torch.relu(y) if relu else y
     h = X
+    if getattr(cfg, "cnn", False):      # base_models.py:176-216 with torch's own conv / pool
+        F = torch.nn.functional
+        h = X.reshape(-1, 1, 28, 28)
+        for name, ci, co, hw, pool in cfg.conv_table():
+            W = pt["W_" + name].reshape(3, 3, ci, co).permute(3, 2, 0, 1)      # HWIO -> OIHW
+            h = torch.relu(F.conv2d(h, W, pt["b_" + name], padding=1))
+            if pool:
+                if h.shape[-1] % 2:                                          # SAME: pad bottom / right
+                    h = F.pad(h, (0, 1, 0, 1), value=float("-inf"))
+                h = F.max_pool2d(h, 2)
+        h = h.permute(0, 2, 3, 1).reshape(X.shape[0], -1)                    # flatten (h, w, c)
     for i in range(len(cfg.enc_layers)):
         h = dense(h, "enc%d" % i, True)
     hz = dense(h, "zh", True)
@@ -149,6 +160,31 @@ def test_backward_matches_autograd(mode, input_type):
     assert set(g) == set(p)
     for k in p:
         np.testing.assert_allclose(g[k], pt[k].grad.numpy(), rtol=1e-9, atol=1e-13, err_msg=k)
+
+
+def test_cnn_trunk_backward_matches_autograd():
+    """the conv / max-pool trunk (base_models.py:176-216) in the oracle against torch's
+    conv2d / max_pool2d and autograd, float64, whole loss."""
+    cfg = O.Config(784, 6, 4, enc_layers=(24,), head_dim=20, dec_layers=(20, 16), cnn=True)
+    assert cfg.n_params() == sum(v.size for v in O.init_params(cfg, 0).values())
+    rng = np.random.RandomState(11)
+    p = O.init_params(cfg, 5)
+    B = 3
+    X = O.synthetic_images(B, 784, seed=2).astype(np.float64)
+    eps = rng.randn(B, 6)
+    a = O.forward(p, cfg, X, eps, 1.0, "exact")
+    g = O.backward(p, cfg, a)
+    assert a["flat"].shape == (B, 2048) and a["pool5"].shape == (B, 4, 4, 128)
+    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    loss, recon, klc, klz = torch_loss(pt, cfg, torch.tensor(X), torch.tensor(eps), 1.0, "exact", None, 1.0)
+    loss.backward()
+    assert a["loss"] == pytest.approx(loss.item(), rel=1e-12)
+    assert set(g) == set(p)
+    for k in p:
+        np.testing.assert_allclose(g[k], pt[k].grad.numpy(), rtol=1e-8, atol=1e-12, err_msg=k)
+    # xavier fans of the conv kernels / biases (includes/layers.py:39-51)
+    assert np.abs(p["W_conv3"]).max() <= math.sqrt(6.0 / (9 * 64 + 9 * 64))
+    assert np.abs(p["b_conv3"]).max() <= math.sqrt(6.0 / (64 + 64))
 
 
 def test_central_difference_spot_check():
