@@ -108,8 +108,22 @@ struct PLayer {
     int64_t w_off, b_off, ldw;    // arena element offsets; ldw = row stride of W
 };
 
+// One 3x3 SAME convolution of the CNN trunk (base_models.py:181-201), as the GEMM it runs as
+struct PConv {
+    std::string name;
+    int cin, cout, hw, pool;          // channels, image side of its input = output, 2x2 SAME max-pool behind it
+    int cin_ld, cout_pad;             // channel stride of the input / output activation (pad64; the image itself: 1)
+    int kpad, ktpad;                  // pad64(9*cin) = K of the forward GEMM, pad64(9*cout) = K of the input-gradient GEMM
+    int64_t w_off, b_off;             // W [kpad][cout_pad] (HWIO flattened, zero pads), b [cout_pad]
+    int64_t o_col, o_act, o_pool;     // workspace: patch matrix of its input (kept for dW), relu output, pooled output
+};
+
 struct dmvae_plan {
     dmvae_config cfg;
+    std::vector<PConv> conv;          // cfg.trunk == DMVAE_TRUNK_CNN only
+    int flat = 0;                     // 4*4*128 = 2048: width of the flattened pool output feeding enc0
+    int64_t o_dflat = 0, o_g[2] = {0, 0}, o_coldy = 0, o_wt = 0;
+    int64_t conv_param_end = 0;
     int Bp, Ip, Dp, Kp, Hp, Tp;   // padded batch / input / latent / classes / head / trunk
     int es;                        // bytes per activation element
     std::vector<PLayer> enc, dec;
@@ -166,6 +180,28 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
         L.b_off = off; off += out_pad;
     };
     int prev = c->input_dim, prev_pad = p->Ip;
+    if (c->trunk == DMVAE_TRUNK_CNN) {
+        // the checked-in encoder (base_models.py:176-216): reshape (-1,28,28,1); conv 1-32, 32-32, pool, 32-64, 64-64,
+        // pool, 64-128, 128-128, pool (SAME: 28 -> 14 -> 7 -> 4); flatten (h,w,c) = 2048; FullyConnected 2048 -> enc[0]
+        if (c->input_dim != 784 || c->n_enc != 1) { delete p; set_error("dmvae_plan_create: the CNN trunk takes 784 inputs and one fc layer"); return DMVAE_EINVAL; }
+        static const int spec[6][4] = {{1, 32, 28, 0}, {32, 32, 28, 1}, {32, 64, 14, 0}, {64, 64, 14, 1}, {64, 128, 7, 0}, {128, 128, 7, 1}};
+        int ld_in = 1;
+        for (int i = 0; i < 6; ++i) {
+            PConv L;
+            L.name = "conv" + std::to_string(i);
+            L.cin = spec[i][0]; L.cout = spec[i][1]; L.hw = spec[i][2]; L.pool = spec[i][3];
+            L.cin_ld = ld_in; L.cout_pad = pad64(L.cout); L.kpad = pad64(9 * L.cin); L.ktpad = pad64(9 * L.cout);
+            L.w_off = off; off += (int64_t)L.kpad * L.cout_pad;
+            L.b_off = off; off += L.cout_pad;
+            add_tensor(p, "W_" + L.name, L.w_off, 9 * L.cin, L.cout, L.cout_pad);
+            add_tensor(p, "b_" + L.name, L.b_off, 1, L.cout, L.cout_pad);
+            p->conv.push_back(L);
+            ld_in = L.cout_pad;
+        }
+        p->conv_param_end = off;
+        p->flat = 4 * 4 * 128;
+        prev = p->flat; prev_pad = p->flat;
+    }
     for (int i = 0; i < c->n_enc; ++i) {
         PLayer L;
         place(L, "enc" + std::to_string(i), prev, c->enc[i], prev_pad, pad64(c->enc[i]));
@@ -213,6 +249,25 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
     const int64_t Bp = p->Bp, es = p->es;
     p->o_xf = take(Bp * p->Ip * 4);
     p->o_x = (c->dtype == DMVAE_F32) ? p->o_xf : take(Bp * p->Ip * es);
+    {
+        int64_t gmax = 0, cmax = 0, wmax = 0;
+        for (auto& L : p->conv) {
+            const int64_t npix = Bp * L.hw * L.hw;
+            L.o_col = take(npix * L.kpad * es);
+            L.o_act = take(npix * L.cout_pad * es);
+            const int ho = (L.hw + 1) / 2;
+            L.o_pool = L.pool ? take(Bp * ho * ho * L.cout_pad * es) : 0;
+            gmax = std::max(gmax, npix * L.cout_pad);
+            cmax = std::max(cmax, npix * L.ktpad);
+            wmax = std::max<int64_t>(wmax, (int64_t)pad64(L.cin) * L.ktpad);
+        }
+        if (!p->conv.empty()) {
+            p->o_g[0] = take(gmax * es); p->o_g[1] = take(gmax * es);
+            p->o_coldy = take(cmax * es);
+            p->o_wt = take(wmax * es);
+            p->o_dflat = take(Bp * p->flat * es);
+        }
+    }
     for (auto& L : p->enc) p->o_enc.push_back(take(Bp * L.out_pad * es));
     p->o_hzc = take(Bp * 2 * p->Hp * es);
     p->o_mv = take(Bp * 2 * p->Dp * 4);
@@ -236,7 +291,7 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
     p->n_lblk = latent_nblocks(p->Bp, c->latent_dim, c->n_classes);
     p->o_lpart = take((int64_t)p->n_lblk * 2 * 4);
     p->o_dprior = take((int64_t)p->n_lblk * 2 * KD * 4);
-    int maxN = std::max(2 * p->Hp, p->Ip);
+    int maxN = std::max(std::max(2 * p->Hp, p->Ip), p->flat);
     for (auto& L : p->enc) maxN = std::max(maxN, L.out_pad);
     for (auto& L : p->dec) maxN = std::max(maxN, L.out_pad);
     maxN = std::max(maxN, 2 * KD);
@@ -316,10 +371,88 @@ static int fwd_dense(dmvae_plan* p, hipStream_t s, const void* A, int64_t lda, i
                         reinterpret_cast<const char*>(Wp(p, L.w_off + w_col)), L.ldw, &e, 1, deferred);
 }
 
+// CNN trunk forward (base_models.py:176-216): per convolution  patch matrix -> GEMM + bias + ReLU, the
+// three SAME max-pools behind conv1 / conv3 / conv5; leaves the flattened [B][2048] pool output.
+static int conv_trunk_forward(dmvae_plan* p, hipStream_t s, const void** flat) {
+    const int dt = p->cfg.dtype;
+    const void* in = WS(p, p->o_x);             // the batch as [B][28][28][1]: pixel stride 1, image stride Ip
+    int64_t bstride = p->Ip;
+    for (auto& L : p->conv) {
+        TRY(im2col3x3_launch(s, dt, in, bstride, L.cin_ld, L.cin, L.hw, L.hw, p->Bp, WS(p, L.o_col), L.kpad));
+        dmvae_epilogue e;
+        memset(&e, 0, sizeof(e));
+        e.kind = DMVAE_EPI_BIAS_RELU; e.out = WS(p, L.o_act); e.ldo = L.cout_pad; e.bias = p->buf.param + L.b_off;
+        TRY(gemm_checked(s, dt, DMVAE_GEMM_FWD, p->Bp * L.hw * L.hw, L.cout_pad, L.kpad, WS(p, L.o_col), L.kpad,
+                         Wp(p, L.w_off), L.cout_pad, &e, 1));
+        in = WS(p, L.o_act); bstride = (int64_t)L.hw * L.hw * L.cout_pad;
+        if (L.pool) {
+            TRY(maxpool2_fwd_launch(s, dt, WS(p, L.o_act), L.hw, L.hw, L.cout_pad, p->Bp, WS(p, L.o_pool)));
+            const int ho = (L.hw + 1) / 2;
+            in = WS(p, L.o_pool); bstride = (int64_t)ho * ho * L.cout_pad;
+        }
+    }
+    *flat = in;
+    return 0;
+}
+
+// largest split of K = n_pix that keeps K-slices whole multiples of 64 and long enough to amortise a tile
+static int conv_dw_split(int64_t K, int tiles) {
+    const int64_t units = K / 64;
+    int64_t target = std::min<int64_t>(units / 16, std::max(1, 2048 / std::max(1, tiles)));
+    for (int64_t d = std::max<int64_t>(1, target); d > 1; --d)
+        if (units % d == 0) return (int)d;
+    return 1;
+}
+
+// CNN trunk backward: d_flat (gradient of the flattened pool output) -> every conv layer's dW / db (split-K
+// GEMM over the kept patch matrix, fp32 atomics into the zeroed gradient range) and the chain of input
+// gradients (patch matrix of dY x flipped kernel, ReLU gate in the epilogue; pools routed to the first maximum).
+static int conv_trunk_backward(dmvae_plan* p, hipStream_t s) {
+    const int dt = p->cfg.dtype;
+    hipError_t me = hipMemsetAsync(p->buf.grad + p->conv.front().w_off, 0, (size_t)(p->conv_param_end - p->conv.front().w_off) * 4, s);
+    if (me != hipSuccess) { set_error("conv gradient memset: %s", hipGetErrorString(me)); return (int)me; }
+    const void* dcur = WS(p, p->o_dflat);
+    int cur = 1;                                    // the next result goes to o_g[cur ^ 1] ... start with o_g[0]
+    for (int i = (int)p->conv.size() - 1; i >= 0; --i) {
+        const PConv& L = p->conv[i];
+        const int64_t npix = (int64_t)p->Bp * L.hw * L.hw;
+        if (L.pool) {                               // un-pool + the ReLU in front of the pool
+            cur ^= 1;
+            TRY(maxpool2_bwd_relu_launch(s, dt, WS(p, L.o_act), dcur, L.hw, L.hw, L.cout_pad, p->Bp, WS(p, p->o_g[cur])));
+            dcur = WS(p, p->o_g[cur]);
+        }
+        {   // dW = patches^T dY, db = colsum(dY)
+            dmvae_epilogue e;
+            memset(&e, 0, sizeof(e));
+            const int split = conv_dw_split(npix, (L.kpad / 64) * (L.cout_pad / 64));
+            e.kind = DMVAE_EPI_ATOMIC_F32; e.out = p->buf.grad + L.w_off; e.ldo = L.cout_pad; e.out2 = p->buf.grad + L.b_off;
+            TRY(gemm_checked(s, dt, DMVAE_GEMM_DW, L.kpad, L.cout_pad, (int)npix, WS(p, L.o_col), L.kpad, dcur, L.cout_pad, &e, split));
+        }
+        if (i > 0) {   // d(input) = conv(dY, flipped kernel), gated by the input activation's ReLU
+            const PConv& Lp = p->conv[i - 1];
+            const int cin_pad = L.cin_ld;           // = Lp.cout_pad
+            TRY(conv_wflip_launch(s, dt, Wp(p, L.w_off), L.cout_pad, L.cin, L.cout, WS(p, p->o_wt), cin_pad, L.ktpad));
+            TRY(im2col3x3_launch(s, dt, dcur, (int64_t)L.hw * L.hw * L.cout_pad, L.cout_pad, L.cout, L.hw, L.hw, p->Bp, WS(p, p->o_coldy), L.ktpad));
+            const void* gate = Lp.pool ? WS(p, Lp.o_pool) : WS(p, Lp.o_act);   // pool output > 0 <=> some unit of its window > 0
+            cur ^= 1;
+            dmvae_epilogue e;
+            memset(&e, 0, sizeof(e));
+            e.kind = DMVAE_EPI_RELU_MASK; e.out = WS(p, p->o_g[cur]); e.ldo = cin_pad; e.aux0 = gate; e.ld0 = cin_pad;
+            TRY(gemm_checked(s, dt, DMVAE_GEMM_DX, (int)npix, cin_pad, L.ktpad, WS(p, p->o_coldy), L.ktpad, WS(p, p->o_wt), L.ktpad, &e, 1));
+            dcur = WS(p, p->o_g[cur]);
+        }
+    }
+    return 0;
+}
+
 static int encode_impl(dmvae_plan* p, hipStream_t s) {
     const void* in = WS(p, p->o_x);
     int64_t ld = p->Ip;
     int kd = p->Ip;
+    if (!p->conv.empty()) {
+        TRY(conv_trunk_forward(p, s, &in));
+        ld = kd = p->flat;
+    }
     for (size_t i = 0; i < p->enc.size(); ++i) {
         const PLayer& L = p->enc[i];
         TRY(fwd_dense(p, s, in, ld, kd, L, L.out_pad, 0, DMVAE_EPI_BIAS_RELU, WS(p, p->o_enc[i]), L.out_pad));
@@ -572,14 +705,19 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
                  WS(p, p->o_denc[ne - 1]), p->Tp));
     for (int i = ne - 1; i >= 0; --i) {
         const PLayer& L = p->enc[i];
-        const void* xin = i > 0 ? WS(p, p->o_enc[i - 1]) : WS(p, p->o_x);
-        const int64_t ldx = i > 0 ? p->enc[i - 1].out_pad : p->Ip;
+        const bool cnn = !p->conv.empty();
+        const void* flat = cnn ? (p->conv.back().pool ? WS(p, p->conv.back().o_pool) : WS(p, p->conv.back().o_act)) : nullptr;
+        const void* xin = i > 0 ? WS(p, p->o_enc[i - 1]) : (cnn ? flat : WS(p, p->o_x));
+        const int64_t ldx = i > 0 ? p->enc[i - 1].out_pad : (cnn ? p->flat : p->Ip);
         TRY(grad_dense(p, s, xin, ldx, L.in_pad, WS(p, p->o_denc[i]), L.out_pad, L.out_pad, L.w_off, L.ldw, L.b_off));
         if (i > 0)
             TRY(dx_dense(p, s, WS(p, p->o_denc[i]), L.out_pad, L.out_pad, L.w_off, L.ldw, L.in_pad,
                          WS(p, p->o_enc[i - 1]), p->enc[i - 1].out_pad, WS(p, p->o_denc[i - 1]), p->enc[i - 1].out_pad));
+        else if (cnn)   // gradient of the flattened pool output (gate: pool output > 0, see conv_trunk_backward)
+            TRY(dx_dense(p, s, WS(p, p->o_denc[0]), L.out_pad, L.out_pad, L.w_off, L.ldw, L.in_pad, flat, p->flat, WS(p, p->o_dflat), p->flat));
     }
     TRY(flush_dw(p, s, 2));   // trunk dW group (everything queued so far when not staged)
+    if (!p->conv.empty()) TRY(conv_trunk_backward(p, s));
   }
     if (p->side_busy) {       // join: Adam / the gradient exchange / the next step must see the side stream's work
         hipError_t e = hipEventRecord(p->ev_join, p->side);
@@ -611,7 +749,7 @@ extern "C" int dmvae_plan_grad_buckets(const dmvae_plan* p, int64_t bounds[4]) {
 extern "C" int dmvae_plan_train_step(dmvae_plan* p, void* stream, int n_valid, const float* eps, int64_t ld_eps,
                                      const float* gumbel, int64_t ld_gumbel, float inv_B) {
     DMVAE_REQUIRE(p && p->bound, "dmvae_plan_train_step: plan not bound");
-    if (p->cfg.dtype != DMVAE_BF16) {     // f32: the plain pair
+    if (p->cfg.dtype != DMVAE_BF16 || !p->conv.empty()) {     // f32, or conv gradients (not in the dW group): the plain pair
         TRY(dmvae_plan_forward_backward(p, stream, n_valid, eps, ld_eps, gumbel, ld_gumbel, inv_B));
         return dmvae_plan_update(p, stream, 1.f);
     }
@@ -661,6 +799,10 @@ extern "C" int dmvae_plan_view(const dmvae_plan* p, const char* name, void** ptr
         const int i = n[3] - '0';
         *ptr = base + p->o_dec[i]; *ld = p->dec[i].out_pad; *dtype = p->cfg.dtype;
     }
+    else if (n.rfind("conv", 0) == 0 && n.size() == 5 && n[4] - '0' >= 0 && n[4] - '0' < (int)p->conv.size()) {
+        const PConv& L = p->conv[n[4] - '0'];       // [B*H*W][cout_pad] relu outputs
+        *ptr = base + L.o_act; *ld = L.cout_pad; *dtype = p->cfg.dtype;
+    } else if (n == "flat" && !p->conv.empty()) { *ptr = base + p->conv.back().o_pool; *ld = p->flat; *dtype = p->cfg.dtype; }
     else { set_error("dmvae_plan_view: unknown view '%s'", name); return DMVAE_EINVAL; }
     return 0;
 }

@@ -40,5 +40,10 @@ int philox_launch(hipStream_t s, float* out, int64_t n, uint64_t seed, uint64_t 
 int cast_launch(hipStream_t s, const void* in, void* out, int64_t n, int to_bf16);
 int spin_launch(hipStream_t s, int us);
 void* gemm_bf16_stamps();
+// CNN trunk (conv.hip)
+int im2col3x3_launch(hipStream_t s, int dtype, const void* in, int64_t bstride, int ldc, int C, int H, int W, int64_t n_img, void* out, int Kpad);
+int maxpool2_fwd_launch(hipStream_t s, int dtype, const void* in, int H, int W, int ld, int64_t n_img, void* out);
+int maxpool2_bwd_relu_launch(hipStream_t s, int dtype, const void* in, const void* dout, int H, int W, int ld, int64_t n_img, void* din);
+int conv_wflip_launch(hipStream_t s, int dtype, const void* W, int ldw, int Cin, int Cout, void* Wt, int rows_pad, int Ktpad);
 
 }  // namespace dmvae

@@ -21,6 +21,7 @@ GEMM_FWD, GEMM_DX, GEMM_DW = 0, 1, 2
 (EPI_BIAS_RELU, EPI_BIAS_F32, EPI_BIAS_RECON, EPI_RELU_MASK, EPI_LATENT,
  EPI_STORE_F32, EPI_ATOMIC_F32, EPI_BIAS_SIGMOID, EPI_ADAM) = range(9)
 MAX_LAYERS = 8
+TRUNK_MLP, TRUNK_CNN = 0, 1
 
 EXPORTS = [
     "dmvae_gemm", "dmvae_gemm_partials", "dmvae_gemm_grouped_dw", "dmvae_gemm_grouped", "dmvae_gemm_grouped_dw_adam", "dmvae_plan_train_step",
@@ -103,7 +104,7 @@ class Config(C.Structure):
         ("n_dec", C.c_int32), ("dec", C.c_int32 * MAX_LAYERS),
         ("input_type", C.c_int32), ("dtype", C.c_int32), ("max_batch", C.c_int32), ("mode", C.c_int32),
         ("temperature", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
-        ("seed", C.c_uint64), ("deterministic", C.c_int32), ("reserved", C.c_int32),
+        ("seed", C.c_uint64), ("deterministic", C.c_int32), ("trunk", C.c_int32),
     ]
 
 

@@ -55,14 +55,21 @@ def default_session():
     return _default_session
 
 
-def layer_table(input_dim, latent_dim, n_classes, enc_layers, head_dim, dec_layers):
+# the conv stack of the checked-in encoder, base_models.py:181-201: (name, cin, cout, image side, pooled)
+CONV_STACK = (("conv0", 1, 32, 28, False), ("conv1", 32, 32, 28, True), ("conv2", 32, 64, 14, False),
+              ("conv3", 64, 64, 14, True), ("conv4", 64, 128, 7, False), ("conv5", 128, 128, 7, True))
+CONV_FLAT = 4 * 4 * 128
+
+
+def layer_table(input_dim, latent_dim, n_classes, enc_layers, head_dim, dec_layers, cnn=False):
     """[(name, fan_in, fan_out, bias_kind)] in graph-construction order
     (base_models.py:218-293).  bias_kind: 'zero' = tf.layers.dense default,
-    'xavier' = FullyConnected bias (1,out) (includes/layers.py:24-28)."""
+    'xavier' = FullyConnected bias (1,out) (includes/layers.py:24-28).  cnn: the
+    trunk's dense part is the one "fc" layer 2048 -> enc_layers[0] of base_models.py:202."""
     t = []
-    prev = input_dim
+    prev = CONV_FLAT if cnn else input_dim
     for i, h in enumerate(enc_layers):
-        t.append(("enc%d" % i, prev, h, "zero"))
+        t.append(("enc%d" % i, prev, h, "xavier" if cnn else "zero"))
         prev = h
     trunk = prev
     t += [("zh", trunk, head_dim, "zero"), ("mean", head_dim, latent_dim, "zero"),
@@ -84,7 +91,8 @@ class StepEngine:
     def __init__(self, input_dim, latent_dim, n_classes, enc_layers=(500, 500), head_dim=2000,
                  dec_layers=(2000, 500, 500), input_type="binary", dtype="bf16", max_batch=100,
                  mode="exact", temperature=1.0, seed=0, deterministic=False, session=None,
-                 beta1=0.9, beta2=0.999, adam_eps=1e-8):
+                 beta1=0.9, beta2=0.999, adam_eps=1e-8, cnn=False):
+        self.cnn = bool(cnn)
         self.session = session or default_session()
         dev = self.session.device
         self.device = dev
@@ -113,6 +121,7 @@ class StepEngine:
         cfg.beta1, cfg.beta2, cfg.adam_eps = float(beta1), float(beta2), float(adam_eps)
         cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         cfg.deterministic = 1 if deterministic else 0
+        cfg.trunk = _lib.TRUNK_CNN if self.cnn else _lib.TRUNK_MLP
         self._cfg = cfg
         h = C.c_void_p()
         check(lib.dmvae_plan_create(C.byref(cfg), C.byref(h)), "dmvae_plan_create")
@@ -182,8 +191,16 @@ class StepEngine:
         (priors.py:57-65)."""
         rng = np.random.RandomState(seed)
         p = {}
+        if self.cnn:
+            # Convolution (includes/layers.py:39-51): kernel (3,3,cin,cout) and bias (cout,) both xavier;
+            # TF's fans: 9*cin / 9*cout for the kernel, n / n for a 1-D shape.  Stored HWIO-flattened.
+            for name, ci, co, _, _ in CONV_STACK:
+                lim = math.sqrt(6.0 / (9 * ci + 9 * co))
+                p["W_" + name] = rng.uniform(-lim, lim, size=(9 * ci, co))
+                lb = math.sqrt(6.0 / (co + co))
+                p["b_" + name] = rng.uniform(-lb, lb, size=(co,))
         for name, fi, fo, bk in layer_table(self.input_dim, self.latent_dim, self.n_classes,
-                                            self.enc_layers, self.head_dim, self.dec_layers):
+                                            self.enc_layers, self.head_dim, self.dec_layers, self.cnn):
             lim = math.sqrt(6.0 / (fi + fo))
             p["W_" + name] = rng.uniform(-lim, lim, size=(fi, fo))
             if bk == "zero":
@@ -324,6 +341,13 @@ class StepEngine:
         tdt = torch.bfloat16 if dt.value == _lib.BF16 else torch.float32
         es = 2 if dt.value == _lib.BF16 else 4
         off = p.value - self.work.data_ptr()
+        if name.startswith("conv"):          # [batch_pad * H * W][channels] relu outputs of a conv layer
+            hw = CONV_STACK[int(name[4])][3]
+            n = self.batch_pad * hw * hw
+            flat = self.work[off: off + n * ld.value * es].view(tdt)
+            t = torch.as_strided(flat, (n, ld.value), (ld.value, 1))
+            nr = (self.max_batch if rows is None else rows) * hw * hw
+            return t[:nr, : (CONV_STACK[int(name[4])][2] if cols is None else cols)]
         flat = self.work[off: off + self.batch_pad * ld.value * es].view(tdt)
         t = torch.as_strided(flat, (self.batch_pad, ld.value), (ld.value, 1))
         full_cols = {"mean": self.latent_dim, "log_var": self.latent_dim, "logits": self.n_classes,
@@ -336,6 +360,10 @@ class StepEngine:
         forward pass, under the names the parameters use (enc<i>, zh, ch, dec<i>)."""
         hp = self.view("hzc", rows).shape[1] // 2
         out = {}
+        if self.cnn:                          # [rows, H, W, channels] relu outputs of the conv layers
+            for i, (name, _, co, hw, _) in enumerate(CONV_STACK):
+                v = self.view(name, rows)
+                out[name] = v.reshape(v.shape[0] // (hw * hw), hw, hw, co)
         for i, w in enumerate(self.enc_layers):
             out["enc%d" % i] = self.view("enc%d" % i, rows, w)
         hzc = self.view("hzc", rows)

@@ -231,6 +231,14 @@ int dmvae_cast_bf16_to_f32(void* stream, const void* in, float* out, int64_t n);
  * Step plan: the whole session.run([loss, train_step]) as one enqueue.
  * ====================================================================== */
 #define DMVAE_MAX_LAYERS 8
+/* Encoder trunk.  MLP: tf.layers.dense x n_enc on the 784 inputs (base_models.py:218-226, the branch
+ * BASELINE.json names).  CNN: the checked-in `self.cnn = True` branch (base_models.py:156,176-216): the
+ * batch as 28x28x1 images, six 3x3 SAME convolutions (32,32,64,64,128,128) with 2x2 SAME max-pools behind
+ * the 2nd / 4th / 6th, flattened (h,w,c) to 2048, then ONE FullyConnected layer enc[0] (n_enc must be 1,
+ * input_dim 784).  The conv layers run as GEMMs over explicit patch matrices (csrc/conv.hip); their
+ * tensors are "W_conv0".."W_conv5" [9*Cin][Cout] (HWIO flattened) and "b_conv*", first in the arena. */
+#define DMVAE_TRUNK_MLP 0
+#define DMVAE_TRUNK_CNN 1
 
 typedef struct dmvae_config {
     int32_t input_dim, latent_dim, n_classes;
@@ -245,7 +253,7 @@ typedef struct dmvae_config {
     float beta1, beta2, adam_eps;
     uint64_t seed;
     int32_t deterministic;                           /* 1: no float atomics anywhere             */
-    int32_t reserved;
+    int32_t trunk;                                   /* DMVAE_TRUNK_MLP (default) or DMVAE_TRUNK_CNN */
 } dmvae_config;
 
 typedef struct dmvae_tensor_info {

@@ -1,0 +1,110 @@
+"""the CNN encoder trunk (base_models.py:176-216, `cnn=True`) on the GPU against the oracle.
+The conv layers run as the step's GEMMs over explicit patch matrices (csrc/conv.hip)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "deep-mixture-vae_amd"))
+
+pytestmark = pytest.mark.gpu
+
+import dmvae_oracle as O  # noqa: E402
+
+KW = dict(input_dim=784, latent_dim=8, n_classes=5, enc_layers=(96,), head_dim=64, dec_layers=(64, 48))
+
+
+def make(dtype, B, seed=2):
+    from dmvae_hip import StepEngine
+    eng = StepEngine(dtype=dtype, max_batch=B, mode="exact", cnn=True, **KW)
+    eng.init_parameters(seed)
+    return eng
+
+
+def batch(B):
+    rng = np.random.RandomState(4)
+    X = O.synthetic_images(B, 784, seed=9)
+    eps = rng.randn(B, KW["latent_dim"]).astype(np.float32)
+    return X, eps
+
+
+def test_cnn_tensors_and_init_follow_the_reference_layers():
+    eng = make("fp32", 8)
+    cfg = O.Config(cnn=True, **KW)
+    p = eng.get_parameters()
+    ref = O.init_params(cfg, 2)
+    assert set(p) == set(ref)
+    for k in ref:
+        assert p[k].shape == ref[k].shape, k
+        np.testing.assert_allclose(p[k], ref[k], rtol=1e-6, atol=1e-7, err_msg=k)      # same rules, same stream
+    assert eng.tensors["W_conv3"][1:3] == (9 * 64, 64) and eng.tensors["W_enc0"][1:3] == (2048, 96)
+
+
+def test_fp32_cnn_step_matches_oracle():
+    B = 12
+    eng = make("fp32", B)
+    cfg = O.Config(cnn=True, **KW)
+    X, eps = batch(B)
+    p = {k: v.astype(np.float64) for k, v in eng.get_parameters().items()}
+    Xd, ed = torch.as_tensor(X).cuda(), torch.as_tensor(eps).cuda()
+    eng.write_state(kl_ratio=1.0, lr=0.002)
+    eng.load_batch(Xd, None, 0, B)
+    eng.forward_backward(B, ed, None)
+    torch.cuda.synchronize()
+    a = O.forward(p, cfg, X.astype(np.float64), eps.astype(np.float64), 1.0, "exact")
+    acts = eng.hidden_activations(B)
+    for k in ("conv0", "conv1", "conv3", "conv5", "enc0", "zh", "dec1"):
+        np.testing.assert_allclose(acts[k].cpu().numpy(), a[k], atol=5e-5, err_msg=k)
+    np.testing.assert_allclose(eng.view("flat", B).cpu().numpy(), a["flat"], atol=5e-5)
+    masks = {k: (v > 0).cpu().numpy() for k, v in acts.items()}
+    flips = sum(int((masks[k] != (a[k] > 0)).sum()) for k in masks)
+    assert flips <= 1e-4 * sum(mk.size for mk in masks.values()), flips
+    g = O.backward(p, cfg, a, masks)
+    st = eng.read_state()
+    assert abs(st.last_loss - a["loss"]) <= 1e-3, (st.last_loss, a["loss"])
+    gg = eng.get_gradients()
+    assert set(gg) == set(g)
+    for k in g:
+        scale = np.abs(g[k]).max() + 1e-12
+        assert np.abs(gg[k] - g[k]).max() <= 2e-4 * scale, (k, np.abs(gg[k] - g[k]).max(), scale)
+    total = sum(float(np.abs(v).sum()) for v in gg.values())
+    assert abs(eng.grad.abs().sum().item() - total) <= 1e-4 * total          # arena pads carry no gradient
+    # two more steps with Adam, through the one-call step
+    m, v = O.adam_tf_init(p)
+    O.adam_tf(p, g, m, v, 1, 0.002)
+    eng.update(1.0)
+    for t in (2, 3):
+        eng.train_step(Xd, None, B, ed, None)
+        a2, _ = O.train_step(p, m, v, t, cfg, X.astype(np.float64), eps.astype(np.float64), 1.0, 0.002, "exact")
+        torch.cuda.synchronize()
+        assert abs(eng.read_state().last_loss - a2["loss"]) <= 5e-3, (eng.read_state().last_loss, a2["loss"])
+    assert eng.read_state().adam_t == 3
+    pg = eng.get_parameters()
+    for k in p:
+        d = np.abs(pg[k] - p[k])
+        assert np.percentile(d, 99.0) <= 3e-4, (k, np.percentile(d, 99.0))
+
+
+def test_bf16_cnn_step_close_to_fp32_engine_and_trains():
+    B = 64
+    X, eps = batch(B)
+    Xd, ed = torch.as_tensor(X).cuda(), torch.as_tensor(eps).cuda()
+    f32, b16 = make("fp32", B), make("bf16", B)
+    for e in (f32, b16):
+        e.load_batch(Xd, None, 0, B)
+        e.forward_backward(B, ed, None)
+    torch.cuda.synchronize()
+    lf, lb = f32.read_state().last_loss, b16.read_state().last_loss
+    assert abs(lf - lb) <= 5e-3 * abs(lf), (lf, lb)
+    gf, gb = f32.get_gradients(), b16.get_gradients()
+    for k in gf:
+        err = np.linalg.norm(gb[k] - gf[k]) / (np.linalg.norm(gf[k]) + 1e-12)
+        assert err <= 0.15, (k, err)
+    losses = []
+    for _ in range(30):
+        b16.train_step(Xd, None, B, ed, None)
+        losses.append(b16.read_state().last_loss)
+    assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0], (losses[0], losses[-1])
