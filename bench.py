@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--enc_layers", default="500,500")
     ap.add_argument("--head_dim", type=int, default=2000)
     ap.add_argument("--dec_layers", default="2000,500,500")
+    ap.add_argument("--cnn", action="store_true", help="the checked-in CNN encoder trunk (base_models.py:176-216) instead of the "
+                    "MLP branch the metric names; --enc_layers is then its one dense layer (500)")
     ap.add_argument("--latent_dim", type=int, default=64)
     ap.add_argument("--n_clusters", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -58,9 +60,15 @@ def parse():
     return ap.parse_args()
 
 
-def flops_per_image(I, D, K, enc=(500, 500), head=2000, dec=(2000, 500, 500)):
-    """train FLOP/img = 2*(3M - I*enc0), M = MACs of one forward."""
-    m, prev = 0, I
+def flops_per_image(I, D, K, enc=(500, 500), head=2000, dec=(2000, 500, 500), cnn=False):
+    """train FLOP/img = 2*(3M - I*enc0), M = MACs of one forward.  cnn: the six 3x3
+    convolutions of base_models.py:181-201 (pixels * 9*cin * cout MACs each) in front of fc 2048 -> enc[0];
+    the first layer (conv0 / enc0) has no input gradient."""
+    m, prev, first = 0, I, I * enc[0]
+    if cnn:
+        convs = ((784, 1, 32), (784, 32, 32), (196, 32, 64), (196, 64, 64), (49, 64, 128), (49, 128, 128))
+        m += sum(px * 9 * ci * co for px, ci, co in convs)
+        prev, first = 2048, 784 * 9 * 32
     for h in enc:
         m += prev * h
         prev = h
@@ -70,7 +78,7 @@ def flops_per_image(I, D, K, enc=(500, 500), head=2000, dec=(2000, 500, 500)):
         m += prev * h
         prev = h
     m += prev * I
-    return 2 * (3 * m - I * enc[0])
+    return 2 * (3 * m - first)
 
 
 def cpu_baseline(args, seconds):
@@ -151,7 +159,7 @@ def main():
     enc = tuple(int(v) for v in args.enc_layers.split(","))
     dec = tuple(int(v) for v in args.dec_layers.split(","))
     eng = StepEngine(I, D, K, enc_layers=enc, head_dim=args.head_dim, dec_layers=dec, dtype=args.dtype, max_batch=B,
-                     seed=1234 + rank, deterministic=args.deterministic)
+                     seed=1234 + rank, deterministic=args.deterministic, cnn=args.cnn)
     eng.init_parameters(0)
     eng.write_state(lr=args.lr)
     ex = GradExchange()
@@ -229,9 +237,9 @@ def main():
 
     ms_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
-    fpi = flops_per_image(I, D, K, enc, args.head_dim, dec)
-    is_cfg2 = (I, D, K, B, enc, args.head_dim, dec, args.dtype) == (784, 64, 10, 4096, (500, 500), 2000, (2000, 500, 500), "bf16")
-    arch = "%d-%s-(%d|%d)-z%d/K%d-%s-%d" % (I, "-".join(map(str, enc)), args.head_dim, args.head_dim, D, K, "-".join(map(str, dec)), I)
+    fpi = flops_per_image(I, D, K, enc, args.head_dim, dec, args.cnn)
+    is_cfg2 = (I, D, K, B, enc, args.head_dim, dec, args.dtype, args.cnn) == (784, 64, 10, 4096, (500, 500), 2000, (2000, 500, 500), "bf16", False)
+    arch = ("cnn(32,32,p,64,64,p,128,128,p)-" if args.cnn else "") + "%d-%s-(%d|%d)-z%d/K%d-%s-%d" % (I, "-".join(map(str, enc)), args.head_dim, args.head_dim, D, K, "-".join(map(str, dec)), I)
     out = {
         "metric": "images/sec (train), MNIST K=10 z=64 batch=4096/GPU bf16" if is_cfg2
                   else "images/sec (train), DMVAE %s batch=%d/GPU %s" % (arch, B, args.dtype),
@@ -241,8 +249,8 @@ def main():
         "config": {"workload": "%sDMVAE MLP %s, one ELBO training step (gather+fwd+loss+bwd+Adam), synthetic rows resident in HBM"
                                % ("configs[1]: " if is_cfg2 else "", arch),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                   "hip_graph": (not args.no_graph) and sync is None, "float_atomics": False,
-                   "update": "adam fused into the dW launch" if sync is None else "bucketed all-reduce overlapped with backward, then adam"},
+                   "hip_graph": (not args.no_graph) and sync is None, "float_atomics": bool(args.cnn),
+                   "update": "stand-alone adam" if args.cnn and sync is None else "adam fused into the dW launch" if sync is None else "bucketed all-reduce overlapped with backward, then adam"},
         "step_flops_algorithmic": fpi * B,
         "step_mfma_frac_of_peak": round(fpi * B / (ms_step * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4),
         "last_loss": round(float(st.last_loss), 4),

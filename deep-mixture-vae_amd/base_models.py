@@ -111,11 +111,10 @@ class DeepMixtureVAE(VAE):
                  deterministic=True, session=None):
         VAE.__init__(self, name, input_type, input_dim, latent_dim, activation=activation, initializer=initializer)
         self.n_classes = n_classes
-        # The checked-in reference forces cnn = True (base_models.py:156); the path this build
-        # accelerates is the MLP branch (:218-226) named by BASELINE.json.
+        # The checked-in reference forces cnn = True (base_models.py:156); the path BASELINE.json names is
+        # the MLP branch (:218-226), the default here.  cnn=True builds the checked-in trunk
+        # (:176-216): six 3x3 SAME convolutions, three 2x2 SAME max-pools, FullyConnected 2048 -> 500.
         self.cnn = bool(cnn)
-        if self.cnn:
-            raise NotImplementedError("cnn=True: the convolutional trunk is a 'next' row (SURVEY.md 8f); use cnn=False")
         if activation not in (None, "relu") and getattr(activation, "__name__", "") != "relu":
             raise NotImplementedError("activation must be ReLU (train.py:196 passes tf.nn.relu)")
         if noise not in ("device", "host"):
@@ -123,6 +122,10 @@ class DeepMixtureVAE(VAE):
         self.batch_size = int(batch_size)
         self.dtype = dtype
         self.enc_layers, self.head_dim, self.dec_layers = tuple(enc_layers), int(head_dim), tuple(dec_layers)
+        if self.cnn:
+            if int(input_dim) != 784:
+                raise ValueError("cnn=True reshapes the inputs to 28x28x1 (base_models.py:176): input_dim must be 784")
+            self.enc_layers = (self.enc_layers[-1],)      # the trunk's one dense layer: ("fc", 2048 -> 500), :202
         self.gumbel, self.temperature = bool(gumbel), float(temperature)
         self.noise, self.seed, self.deterministic = noise, int(seed), bool(deterministic)
         self._session = session
@@ -146,7 +149,7 @@ class DeepMixtureVAE(VAE):
                                   head_dim=self.head_dim, dec_layers=self.dec_layers, input_type=self.input_type,
                                   dtype=self.dtype, max_batch=self.batch_size, mode="relaxed" if self.gumbel else "exact",
                                   temperature=self.temperature, seed=self.seed + 7919 * sess.rank,
-                                  deterministic=self.deterministic, session=sess)
+                                  deterministic=self.deterministic, session=sess, cnn=self.cnn)
         self._engine.init_parameters(self.seed)
         # names of the graph's placeholders / tensors (fetch through the methods below)
         self.X, self.epsilon, self.cluster = "X", "epsilon_Z", "epsilon_C"

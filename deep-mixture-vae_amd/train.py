@@ -69,6 +69,8 @@ parser.add_argument("--temperature", type=float, default=1.0)
 parser.add_argument("--enc_layers", type=str, default="500,500")
 parser.add_argument("--head_dim", type=int, default=2000)
 parser.add_argument("--dec_layers", type=str, default="2000,500,500")
+parser.add_argument("--cnn", action="store_true", default=False,
+                    help="the checked-in convolutional encoder trunk (base_models.py:156,176-216) instead of the MLP branch")
 
 
 def main(argv):
@@ -112,7 +114,7 @@ def main(argv):
     sess = Session()
     model = base_models.DeepMixtureVAE(
         model_name, dataset.input_type, dataset.input_dim, argv.latent_dim, n_clusters,
-        activation="relu", initializer="xavier", cnn=False,
+        activation="relu", initializer="xavier", cnn=argv.cnn,
         batch_size=argv.batch_size // world, dtype=argv.dtype,
         enc_layers=[int(v) for v in argv.enc_layers.split(",")], head_dim=argv.head_dim,
         dec_layers=[int(v) for v in argv.dec_layers.split(",")], gumbel=argv.gumbel, temperature=argv.temperature,
