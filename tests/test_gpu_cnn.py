@@ -108,3 +108,32 @@ def test_bf16_cnn_step_close_to_fp32_engine_and_trains():
         b16.train_step(Xd, None, B, ed, None)
         losses.append(b16.read_state().last_loss)
     assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0], (losses[0], losses[-1])
+
+
+def test_cnn_staged_backward_and_bucket_update_match_the_whole_step():
+    """the data-parallel launch sequence (three backward segments, one Adam per gradient bucket) on the CNN
+    trunk: same gradients as the whole pass up to the summation order of the split-K conv weight gradients
+    (fp32 atomics), conv tensors inside the trunk bucket."""
+    B = 32
+    X, eps = batch(B)
+    Xd, ed = torch.as_tensor(X).cuda(), torch.as_tensor(eps).cuda()
+    whole, staged = make("fp32", B), make("fp32", B)
+    whole.load_batch(Xd, None, 0, B)
+    whole.forward_backward(B, ed, None)
+    staged.load_batch(Xd, None, 0, B)
+    for st in (0, 1, 2):
+        staged.forward_backward_stage(st, B, ed, None)
+    torch.cuda.synchronize()
+    gw, gs = whole.get_gradients(), staged.get_gradients()
+    for k in gw:
+        np.testing.assert_allclose(gs[k], gw[k], rtol=0, atol=1e-5 * (np.abs(gw[k]).max() + 1e-12), err_msg=k)
+    buckets = staged.grad_buckets()                           # in completion order: decoder, heads, trunk
+    off, rows, cols, ld = staged.tensors["W_conv5"]
+    assert buckets[2][0] <= off < buckets[2][1]               # conv parameters belong to the trunk bucket
+    whole.update(1.0)
+    for lo, hi in buckets:
+        staged.update_range(lo, hi, 1.0)
+    torch.cuda.synchronize()
+    pw, ps = whole.get_parameters(), staged.get_parameters()
+    for k in pw:
+        assert np.percentile(np.abs(pw[k] - ps[k]), 99.9) <= 1e-5, k

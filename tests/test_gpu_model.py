@@ -241,10 +241,29 @@ def test_regeneration_and_cluster_samples_match_reference_definitions(tmp_path, 
 
 def test_unsupported_surfaces_fail_loudly():
     import base_models
-    with pytest.raises(NotImplementedError):
-        base_models.DeepMixtureVAE("m", "binary", 784, 10, 10, cnn=True)
+    with pytest.raises(ValueError):                    # the CNN trunk reshapes to 28x28x1 (base_models.py:176)
+        base_models.DeepMixtureVAE("m", "binary", 100, 10, 10, cnn=True)
     with pytest.raises(NotImplementedError):
         base_models.VaDE("v", "binary", 784, 10, 10)
+
+
+def test_cnn_model_trains_through_the_reference_surface():
+    """`cnn=True` = the checked-in trunk (base_models.py:156,176-216) behind the same class surface:
+    define_train_step / train_op / get_accuracy, parameters named after the reference's layers."""
+    import base_models
+    from includes.utils import Dataset
+    X = O.synthetic_images(512, 784, seed=4)
+    y = np.random.RandomState(0).randint(0, 10, 512)
+    model = base_models.DeepMixtureVAE("c", "binary", 784, 8, 10, activation="relu", initializer="xavier", cnn=True,
+                                       batch_size=128, dtype="bf16", head_dim=256, dec_layers=(256, 128)).build_graph()
+    eng = model.engine
+    assert eng.cnn and eng.enc_layers == (500,) and eng.tensors["W_conv0"][1:3] == (9, 32)
+    data = Dataset((X, y), batch_size=128)
+    model.define_train_step(0.002, data.epoch_len * 10)
+    losses = [model.train_op(None, data, 1.0) for _ in range(4)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    acc = model.get_accuracy(None, Dataset((X, y), batch_size=128))
+    assert 0.0 <= acc <= 1.0
 
 
 def test_train_cli_one_epoch(tmp_path, monkeypatch):
