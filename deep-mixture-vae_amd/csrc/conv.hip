@@ -26,7 +26,7 @@ template <> struct Vec16<bf16_t> { typedef uint4 type; static constexpr int N = 
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ in, int64_t bstride, int ldc, int C, int H, int W,
                                                         int n_pix, T* __restrict__ out, int Kpad) {
-    constexpr int V = VEC ? Vec16<T>::N : 1;
+    constexpr int V = Vec16<T>::N;                  // every thread writes 16 bytes; !VEC: gathered element by element (C = 1)
     constexpr int PB = 64;                          // pixels per block pass: all index arithmetic stays 32-bit
     const int kv = Kpad / V, HW = H * W;
     for (int p0 = blockIdx.x * PB; p0 < n_pix; p0 += gridDim.x * PB) {
@@ -45,7 +45,15 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ in
                 if (live) v = *reinterpret_cast<const typename Vec16<T>::type*>(in + src);
                 *reinterpret_cast<typename Vec16<T>::type*>(out + dst) = v;
             } else {
-                out[dst] = live ? in[src] : T(0);
+                alignas(16) T v[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const int kj = k + j, tj = kj / C, cj = kj - tj * C;
+                    const int yj = y + tj / 3 - 1, xj = x + tj % 3 - 1;
+                    const bool lj = tj < 9 && yj >= 0 && yj < H && xj >= 0 && xj < W;
+                    v[j] = lj ? in[(int64_t)b * bstride + (int64_t)(yj * W + xj) * ldc + cj] : T(0);
+                }
+                *reinterpret_cast<typename Vec16<T>::type*>(out + dst) = *reinterpret_cast<const typename Vec16<T>::type*>(v);
             }
         }
     }
