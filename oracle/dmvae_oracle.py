@@ -12,6 +12,11 @@ Pinning status (see DESIGN.md "Oracle"):
   * the decoder's hidden FullyConnected stack (row A7, base_models.py:279-289) is pinned by
     executing the reference's own includes/layers.py + includes/network.py
     (oracle/make_network_golden.py).
+  * the CNN encoder trunk (base_models.py:176-216) is pinned by executing the
+    reference's own Convolution / MaxPooling / FullyConnected / DeepNetwork classes on its spec
+    list (oracle/make_cnn_golden.py, tests/golden/cnn_golden.npz); tf.nn.conv2d / max_pool /
+    bias_add themselves are np_tf_ops' restatement of the documented TF semantics, and the
+    trunk's backward is checked against torch conv2d / max_pool2d autograd in float64.
   * tf.layers.dense layers, sigmoid cross-entropy, autodiff backward and Adam live in
     TensorFlow 1.x (third party, not vendored, not installed): for those rows
     this file restates the documented TF semantics; PARITY UNPINNED by any
