@@ -64,7 +64,8 @@ static const char* gemm_name(int dtype, int layout) {
 }
 
 static int gemm_checked(hipStream_t s, int dtype, int layout, int M, int N, int K, const void* A, int64_t lda,
-                        const void* B, int64_t ldb, const dmvae_epilogue* epi, int split, GemmArgs* deferred = nullptr) {
+                        const void* B, int64_t ldb, const dmvae_epilogue* epi, int split, GemmArgs* deferred = nullptr,
+                        int conv_p = 0, int conv_c = 0) {
     DMVAE_REQUIRE(dtype == DMVAE_F32 || dtype == DMVAE_BF16, "dmvae_gemm: bad dtype %d", dtype);
     DMVAE_REQUIRE(layout >= 0 && layout <= 2, "dmvae_gemm: bad layout %d", layout);
     DMVAE_REQUIRE(A && B && epi && epi->out, "dmvae_gemm: null pointer");
@@ -78,6 +79,10 @@ static int gemm_checked(hipStream_t s, int dtype, int layout, int M, int N, int 
     GemmArgs a;
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb;
     a.M = M; a.N = N; a.K = K; a.k_split = K / split; a.group_m = 8;
+    a.conv_p = conv_p; a.conv_c = conv_c;
+    DMVAE_REQUIRE(conv_c == 0 || (conv_c % 64 == 0 && lda == conv_c &&
+                                  (layout == DMVAE_GEMM_DW ? M == 9 * conv_c : (K == 9 * conv_c && split == 1))),
+                  "dmvae_gemm: conv mode needs A with lda = channels per tap and 9 * channels along K (M for the weight gradient)");
     a.epi = *epi;
     if (a.epi.m_valid <= 0) a.epi.m_valid = M;
     if (a.epi.n_valid <= 0) a.epi.n_valid = N;
@@ -108,21 +113,26 @@ struct PLayer {
     int64_t w_off, b_off, ldw;    // arena element offsets; ldw = row stride of W
 };
 
-// One 3x3 SAME convolution of the CNN trunk (base_models.py:181-201), as the GEMM it runs as
+// One 3x3 SAME convolution of the CNN trunk (base_models.py:181-201), as the GEMMs it runs as (conv.hip).
+// Activations are zero-bordered: [Bp][P][P][ld] (P = hw + 2) with P + 1 zero guard rows on either end; an
+// o_* offset points at the guard, rows0() at padded pixel 0.
 struct PConv {
     std::string name;
     int cin, cout, hw, pool;          // channels, image side of its input = output, 2x2 SAME max-pool behind it
-    int cin_ld, cout_pad;             // channel stride of the input / output activation (pad64; the image itself: 1)
-    int kpad, ktpad;                  // pad64(9*cin) = K of the forward GEMM, pad64(9*cout) = K of the input-gradient GEMM
-    int64_t w_off, b_off;             // W [kpad][cout_pad] (HWIO flattened, zero pads), b [cout_pad]
-    int64_t o_col, o_act, o_pool;     // workspace: patch matrix of its input (kept for dW), relu output, pooled output
+    int cin_ld, cout_ld;              // channel stride of the input / output activation (pad64; the image itself: 1)
+    int P;                            // hw + 2
+    int kdim;                         // K of the forward GEMM: 9 * cin_ld (first layer: 64, an explicit 9-column patch matrix)
+    int64_t w_off, b_off;             // W [(tap, c < cin_ld)][cout_ld] (HWIO with padded channels, zero pads), b [cout_ld]
+    int64_t o_act, o_dact;            // relu output and its gradient
+    int64_t o_pool, o_dpool;          // pooled output (zero-bordered for the next conv; the last one plain = the flat trunk output) and its gradient
+    int64_t o_col;                    // first layer only: its patch matrix [Bp*P*P][64]
 };
 
 struct dmvae_plan {
     dmvae_config cfg;
     std::vector<PConv> conv;          // cfg.trunk == DMVAE_TRUNK_CNN only
     int flat = 0;                     // 4*4*128 = 2048: width of the flattened pool output feeding enc0
-    int64_t o_dflat = 0, o_g[2] = {0, 0}, o_coldy = 0, o_wt = 0;
+    int64_t o_dflat = 0, o_wt = 0;
     int64_t conv_param_end = 0;
     int Bp, Ip, Dp, Kp, Hp, Tp;   // padded batch / input / latent / classes / head / trunk
     int es;                        // bytes per activation element
@@ -190,13 +200,15 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
             PConv L;
             L.name = "conv" + std::to_string(i);
             L.cin = spec[i][0]; L.cout = spec[i][1]; L.hw = spec[i][2]; L.pool = spec[i][3];
-            L.cin_ld = ld_in; L.cout_pad = pad64(L.cout); L.kpad = pad64(9 * L.cin); L.ktpad = pad64(9 * L.cout);
-            L.w_off = off; off += (int64_t)L.kpad * L.cout_pad;
-            L.b_off = off; off += L.cout_pad;
-            add_tensor(p, "W_" + L.name, L.w_off, 9 * L.cin, L.cout, L.cout_pad);
-            add_tensor(p, "b_" + L.name, L.b_off, 1, L.cout, L.cout_pad);
+            L.cin_ld = ld_in; L.cout_ld = pad64(L.cout); L.P = L.hw + 2;
+            L.kdim = i == 0 ? 64 : 9 * L.cin_ld;
+            L.w_off = off; off += (int64_t)L.kdim * L.cout_ld;
+            L.b_off = off; off += L.cout_ld;
+            // logical [9*cin][cout]; row (tap, c) sits at tap * cin_ld + c: a 3-D view when cin < cin_ld (dmvae_hip.h)
+            add_tensor(p, "W_" + L.name, L.w_off, 9 * L.cin, L.cout, L.cout_ld);
+            add_tensor(p, "b_" + L.name, L.b_off, 1, L.cout, L.cout_ld);
             p->conv.push_back(L);
-            ld_in = L.cout_pad;
+            ld_in = L.cout_ld;
         }
         p->conv_param_end = off;
         p->flat = 4 * 4 * 128;
@@ -250,20 +262,20 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
     p->o_xf = take(Bp * p->Ip * 4);
     p->o_x = (c->dtype == DMVAE_F32) ? p->o_xf : take(Bp * p->Ip * es);
     {
-        int64_t gmax = 0, cmax = 0, wmax = 0;
-        for (auto& L : p->conv) {
-            const int64_t npix = Bp * L.hw * L.hw;
-            L.o_col = take(npix * L.kpad * es);
-            L.o_act = take(npix * L.cout_pad * es);
+        int64_t wmax = 0;
+        for (size_t i = 0; i < p->conv.size(); ++i) {
+            PConv& L = p->conv[i];
+            auto bordered = [&](int P, int ld) { return take((Bp * P * P + 2 * (P + 1)) * ld * es); };
+            L.o_col = i == 0 ? take(Bp * L.P * L.P * L.kdim * es) : 0;
+            L.o_act = bordered(L.P, L.cout_ld);
+            L.o_dact = bordered(L.P, L.cout_ld);
             const int ho = (L.hw + 1) / 2;
-            L.o_pool = L.pool ? take(Bp * ho * ho * L.cout_pad * es) : 0;
-            gmax = std::max(gmax, npix * L.cout_pad);
-            cmax = std::max(cmax, npix * L.ktpad);
-            wmax = std::max<int64_t>(wmax, (int64_t)pad64(L.cin) * L.ktpad);
+            const bool last = i + 1 == p->conv.size();
+            L.o_pool = L.pool ? (last ? take(Bp * ho * ho * L.cout_ld * es) : bordered(ho + 2, L.cout_ld)) : 0;
+            L.o_dpool = (L.pool && !last) ? bordered(ho + 2, L.cout_ld) : 0;
+            if (i > 0) wmax = std::max<int64_t>(wmax, (int64_t)L.cin_ld * 9 * L.cout_ld);
         }
         if (!p->conv.empty()) {
-            p->o_g[0] = take(gmax * es); p->o_g[1] = take(gmax * es);
-            p->o_coldy = take(cmax * es);
             p->o_wt = take(wmax * es);
             p->o_dflat = take(Bp * p->flat * es);
         }
@@ -371,76 +383,91 @@ static int fwd_dense(dmvae_plan* p, hipStream_t s, const void* A, int64_t lda, i
                         reinterpret_cast<const char*>(Wp(p, L.w_off + w_col)), L.ldw, &e, 1, deferred);
 }
 
-// CNN trunk forward (base_models.py:176-216): per convolution  patch matrix -> GEMM + bias + ReLU, the
-// three SAME max-pools behind conv1 / conv3 / conv5; leaves the flattened [B][2048] pool output.
+// pointer to padded pixel 0 of a zero-bordered activation (skips the P + 1 guard rows)
+static inline char* rows0(const dmvae_plan* p, int64_t off, int P, int ld) { return WS(p, off) + (int64_t)(P + 1) * ld * p->es; }
+
+// CNN trunk forward (base_models.py:176-216).  First layer: explicit 9-column patch matrix; every other
+// convolution is ONE conv-mode GEMM straight off the zero-bordered activation (conv.hip) + bias + ReLU, then
+// the border rows (which computed relu(bias)) are re-zeroed; SAME max-pools behind conv1 / conv3 / conv5.
 static int conv_trunk_forward(dmvae_plan* p, hipStream_t s, const void** flat) {
     const int dt = p->cfg.dtype;
-    const void* in = WS(p, p->o_x);             // the batch as [B][28][28][1]: pixel stride 1, image stride Ip
-    int64_t bstride = p->Ip;
-    for (auto& L : p->conv) {
-        TRY(im2col3x3_launch(s, dt, in, bstride, L.cin_ld, L.cin, L.hw, L.hw, p->Bp, WS(p, L.o_col), L.kpad));
+    const void* in = nullptr;                       // zero-bordered input of the next convolution, at padded pixel 0
+    for (size_t i = 0; i < p->conv.size(); ++i) {
+        const PConv& L = p->conv[i];
+        const int M = p->Bp * L.P * L.P;
         dmvae_epilogue e;
         memset(&e, 0, sizeof(e));
-        e.kind = DMVAE_EPI_BIAS_RELU; e.out = WS(p, L.o_act); e.ldo = L.cout_pad; e.bias = p->buf.param + L.b_off;
-        TRY(gemm_checked(s, dt, DMVAE_GEMM_FWD, p->Bp * L.hw * L.hw, L.cout_pad, L.kpad, WS(p, L.o_col), L.kpad,
-                         Wp(p, L.w_off), L.cout_pad, &e, 1));
-        in = WS(p, L.o_act); bstride = (int64_t)L.hw * L.hw * L.cout_pad;
+        e.kind = DMVAE_EPI_BIAS_RELU; e.out = rows0(p, L.o_act, L.P, L.cout_ld); e.ldo = L.cout_ld; e.bias = p->buf.param + L.b_off;
+        if (i == 0) {
+            TRY(im2col_first_launch(s, dt, WS(p, p->o_x), p->Ip, L.hw, p->Bp, WS(p, L.o_col), L.kdim));
+            TRY(gemm_checked(s, dt, DMVAE_GEMM_FWD, M, L.cout_ld, L.kdim, WS(p, L.o_col), L.kdim, Wp(p, L.w_off), L.cout_ld, &e, 1));
+        } else {
+            TRY(gemm_checked(s, dt, DMVAE_GEMM_FWD, M, L.cout_ld, L.kdim, in, L.cin_ld, Wp(p, L.w_off), L.cout_ld, &e, 1, nullptr, L.P, L.cin_ld));
+        }
+        TRY(zero_border_launch(s, dt, rows0(p, L.o_act, L.P, L.cout_ld), L.P, L.cout_ld, p->Bp));
+        in = rows0(p, L.o_act, L.P, L.cout_ld);
         if (L.pool) {
-            TRY(maxpool2_fwd_launch(s, dt, WS(p, L.o_act), L.hw, L.hw, L.cout_pad, p->Bp, WS(p, L.o_pool)));
-            const int ho = (L.hw + 1) / 2;
-            in = WS(p, L.o_pool); bstride = (int64_t)ho * ho * L.cout_pad;
+            const bool last = i + 1 == p->conv.size();
+            const int Po = (L.hw + 1) / 2 + 2;
+            void* out = last ? (void*)WS(p, L.o_pool) : (void*)rows0(p, L.o_pool, Po, L.cout_ld);
+            TRY(maxpool2_fwd_launch(s, dt, in, L.hw, L.cout_ld, p->Bp, out, last ? 0 : 1));
+            in = out;
         }
     }
     *flat = in;
     return 0;
 }
 
-// largest split of K = n_pix that keeps K-slices whole multiples of 64 and long enough to amortise a tile
+// largest split of K that keeps K-slices whole multiples of 64 and long enough to amortise a tile
 static int conv_dw_split(int64_t K, int tiles) {
     const int64_t units = K / 64;
     int64_t target = std::min<int64_t>(units / 16, std::max(1, 2048 / std::max(1, tiles)));
+    for (int64_t d = std::max<int64_t>(1, target); d >= 8; --d)       // a multiple of 8: one XCD per slice (gemm_bf16_kernel)
+        if (units % d == 0 && d % 8 == 0) return (int)d;
     for (int64_t d = std::max<int64_t>(1, target); d > 1; --d)
         if (units % d == 0) return (int)d;
     return 1;
 }
 
-// CNN trunk backward: d_flat (gradient of the flattened pool output) -> every conv layer's dW / db (split-K
-// GEMM over the kept patch matrix, fp32 atomics into the zeroed gradient range) and the chain of input
-// gradients (patch matrix of dY x flipped kernel, ReLU gate in the epilogue; pools routed to the first maximum).
+// CNN trunk backward from d_flat (gradient of the flattened pool output).  Per layer, last to first:
+//   un-pool + ReLU gate (maxpool2_bwd_relu)  ->  dY, zero-bordered;
+//   dW: ONE DW-layout GEMM with M = (tap, channel): a tile row reads the layer's input shifted by its tap's row
+//       offset, against dY over all padded rows (split-K, fp32 atomics into the zeroed gradient range); db rides along;
+//   d(input): ONE conv-mode GEMM of dY with the flipped kernel, gated by the input activation's ReLU (which
+//       also zeroes the border rows: the activation is zero there).
 static int conv_trunk_backward(dmvae_plan* p, hipStream_t s) {
     const int dt = p->cfg.dtype;
     hipError_t me = hipMemsetAsync(p->buf.grad + p->conv.front().w_off, 0, (size_t)(p->conv_param_end - p->conv.front().w_off) * 4, s);
     if (me != hipSuccess) { set_error("conv gradient memset: %s", hipGetErrorString(me)); return (int)me; }
-    const void* dcur = WS(p, p->o_dflat);
-    int cur = 1;                                    // the next result goes to o_g[cur ^ 1] ... start with o_g[0]
     for (int i = (int)p->conv.size() - 1; i >= 0; --i) {
         const PConv& L = p->conv[i];
-        const int64_t npix = (int64_t)p->Bp * L.hw * L.hw;
-        if (L.pool) {                               // un-pool + the ReLU in front of the pool
-            cur ^= 1;
-            TRY(maxpool2_bwd_relu_launch(s, dt, WS(p, L.o_act), dcur, L.hw, L.hw, L.cout_pad, p->Bp, WS(p, p->o_g[cur])));
-            dcur = WS(p, p->o_g[cur]);
+        const int M = p->Bp * L.P * L.P;
+        const bool last = i + 1 == (int)p->conv.size();
+        char* dact = rows0(p, L.o_dact, L.P, L.cout_ld);
+        if (L.pool) {
+            const int Po = (L.hw + 1) / 2 + 2;
+            const void* dpool = last ? (const void*)WS(p, p->o_dflat) : (const void*)rows0(p, L.o_dpool, Po, L.cout_ld);
+            TRY(maxpool2_bwd_relu_launch(s, dt, rows0(p, L.o_act, L.P, L.cout_ld), dpool, L.hw, L.cout_ld, p->Bp, dact, last ? 0 : 1));
         }
-        {   // dW = patches^T dY, db = colsum(dY)
-            dmvae_epilogue e;
-            memset(&e, 0, sizeof(e));
-            const int split = conv_dw_split(npix, (L.kpad / 64) * (L.cout_pad / 64));
-            e.kind = DMVAE_EPI_ATOMIC_F32; e.out = p->buf.grad + L.w_off; e.ldo = L.cout_pad; e.out2 = p->buf.grad + L.b_off;
-            TRY(gemm_checked(s, dt, DMVAE_GEMM_DW, L.kpad, L.cout_pad, (int)npix, WS(p, L.o_col), L.kpad, dcur, L.cout_pad, &e, split));
+        dmvae_epilogue e;
+        memset(&e, 0, sizeof(e));
+        e.kind = DMVAE_EPI_ATOMIC_F32; e.ldo = L.cout_ld;
+        if (i == 0) {
+            e.out = p->buf.grad + L.w_off; e.out2 = p->buf.grad + L.b_off;
+            TRY(gemm_checked(s, dt, DMVAE_GEMM_DW, L.kdim, L.cout_ld, M, WS(p, L.o_col), L.kdim, dact, L.cout_ld, &e,
+                             conv_dw_split(M, (L.kdim / 64) * (L.cout_ld / 64))));
+            break;
         }
-        if (i > 0) {   // d(input) = conv(dY, flipped kernel), gated by the input activation's ReLU
-            const PConv& Lp = p->conv[i - 1];
-            const int cin_pad = L.cin_ld;           // = Lp.cout_pad
-            TRY(conv_wflip_launch(s, dt, Wp(p, L.w_off), L.cout_pad, L.cin, L.cout, WS(p, p->o_wt), cin_pad, L.ktpad));
-            TRY(im2col3x3_launch(s, dt, dcur, (int64_t)L.hw * L.hw * L.cout_pad, L.cout_pad, L.cout, L.hw, L.hw, p->Bp, WS(p, p->o_coldy), L.ktpad));
-            const void* gate = Lp.pool ? WS(p, Lp.o_pool) : WS(p, Lp.o_act);   // pool output > 0 <=> some unit of its window > 0
-            cur ^= 1;
-            dmvae_epilogue e;
-            memset(&e, 0, sizeof(e));
-            e.kind = DMVAE_EPI_RELU_MASK; e.out = WS(p, p->o_g[cur]); e.ldo = cin_pad; e.aux0 = gate; e.ld0 = cin_pad;
-            TRY(gemm_checked(s, dt, DMVAE_GEMM_DX, (int)npix, cin_pad, L.ktpad, WS(p, p->o_coldy), L.ktpad, WS(p, p->o_wt), L.ktpad, &e, 1));
-            dcur = WS(p, p->o_g[cur]);
-        }
+        const PConv& Lp = p->conv[i - 1];
+        const char* in = Lp.pool ? rows0(p, Lp.o_pool, L.P, L.cin_ld) : rows0(p, Lp.o_act, L.P, L.cin_ld);
+        e.out = p->buf.grad + L.w_off; e.out2 = p->buf.grad + L.b_off;
+        TRY(gemm_checked(s, dt, DMVAE_GEMM_DW, 9 * L.cin_ld, L.cout_ld, M, in, L.cin_ld, dact, L.cout_ld, &e,
+                         conv_dw_split(M, 9 * (L.cin_ld / 64) * (L.cout_ld / 64)), nullptr, L.P, L.cin_ld));
+        TRY(conv_wflip_launch(s, dt, Wp(p, L.w_off), L.cin_ld, L.cout_ld, WS(p, p->o_wt)));
+        memset(&e, 0, sizeof(e));
+        e.kind = DMVAE_EPI_RELU_MASK; e.ldo = L.cin_ld; e.aux0 = in; e.ld0 = L.cin_ld;
+        e.out = Lp.pool ? rows0(p, Lp.o_dpool, L.P, L.cin_ld) : rows0(p, Lp.o_dact, L.P, L.cin_ld);
+        TRY(gemm_checked(s, dt, DMVAE_GEMM_DX, M, L.cin_ld, 9 * L.cout_ld, dact, L.cout_ld, WS(p, p->o_wt), 9 * L.cout_ld, &e, 1, nullptr, L.P, L.cout_ld));
     }
     return 0;
 }
@@ -800,8 +827,8 @@ extern "C" int dmvae_plan_view(const dmvae_plan* p, const char* name, void** ptr
         *ptr = base + p->o_dec[i]; *ld = p->dec[i].out_pad; *dtype = p->cfg.dtype;
     }
     else if (n.rfind("conv", 0) == 0 && n.size() == 5 && n[4] - '0' >= 0 && n[4] - '0' < (int)p->conv.size()) {
-        const PConv& L = p->conv[n[4] - '0'];       // [B*H*W][cout_pad] relu outputs
-        *ptr = base + L.o_act; *ld = L.cout_pad; *dtype = p->cfg.dtype;
+        const PConv& L = p->conv[n[4] - '0'];       // zero-bordered [B][hw+2][hw+2][cout_ld] relu outputs, at padded pixel 0
+        *ptr = rows0(p, L.o_act, L.P, L.cout_ld); *ld = L.cout_ld; *dtype = p->cfg.dtype;
     } else if (n == "flat" && !p->conv.empty()) { *ptr = base + p->conv.back().o_pool; *ld = p->flat; *dtype = p->cfg.dtype; }
     else { set_error("dmvae_plan_view: unknown view '%s'", name); return DMVAE_EINVAL; }
     return 0;

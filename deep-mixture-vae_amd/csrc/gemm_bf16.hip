@@ -214,7 +214,7 @@ __device__ __forceinline__ int xcd_run_index(const int gid, const int gstart, co
 // 4-slot ring in the same 64 KiB, i.e. 48 KiB instead of 32 KiB in flight).
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW, int BKT = BK>
 __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_raw, const int gstart, const int nwg, bf16_t* smem,
-                                               const dmvae_adam_ctx* ac = nullptr) {
+                                               const dmvae_adam_ctx* ac = nullptr, const int kslice = -1) {
     constexpr bool A_KC = (LAYOUT != DMVAE_GEMM_DW);
     constexpr bool B_KC = (LAYOUT == DMVAE_GEMM_DX);
     constexpr int A_ELEMS = BM * BKT, B_ELEMS = BN * BKT, STAGE = A_ELEMS + B_ELEMS;
@@ -246,12 +246,15 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
         tn = in / gm;
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = blockIdx.y * a.k_split;
+    const int kbeg = (kslice >= 0 ? kslice : (int)blockIdx.y) * a.k_split;
     const int nk = a.k_split / BKT;
 
     const bf16_t* Ag = reinterpret_cast<const bf16_t*>(a.A);
     const bf16_t* Bg = reinterpret_cast<const bf16_t*>(a.B);
-    Ag += A_KC ? ((int64_t)m0 * a.lda + kbeg) : ((int64_t)kbeg * a.lda + m0);
+    if (!A_KC && a.conv_c)   // conv-mode weight gradient: tile row m0 = (tap, channel) -> the activation rows shifted by the tap
+        Ag += ((int64_t)kbeg * a.lda + conv_tap_offset(m0 / a.conv_c, m0 % a.conv_c, a.conv_p, a.lda));
+    else
+        Ag += A_KC ? ((int64_t)m0 * a.lda + kbeg) : ((int64_t)kbeg * a.lda + m0);
     Bg += B_KC ? ((int64_t)n0 * a.ldb + kbeg) : ((int64_t)kbeg * a.ldb + n0);
     const int64_t stepA = A_KC ? (int64_t)BKT : (int64_t)BKT * a.lda;
     const int64_t stepB = B_KC ? (int64_t)BKT : (int64_t)BKT * a.ldb;
@@ -290,10 +293,24 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
 
     // issue the loads of K tile t (clamped to the last tile: keeps the vmcnt arithmetic uniform;
     // a clamped tile lands in a ring slot nobody reads) into ring slot `slot`
+    // conv mode (GemmArgs::conv_c): tiles are issued in K order, so (tap, channel) is a running counter
+    int cv_tap = 0, cv_c0 = 0;
+    int64_t cv_off = 0;
     auto issue = [&](int t, int slot) {
         const int tc = t < nk ? t : nk - 1;
         const unsigned s = lds_w + 2u * (unsigned)(slot * STAGE);
-        glds_tile(Ag + tc * stepA, goA, s, 1024u * NW);
+        int64_t aoff = tc * stepA;
+        if constexpr (A_KC) {
+            if (a.conv_c) {
+                if (t < nk) {
+                    cv_off = conv_tap_offset(cv_tap, cv_c0, a.conv_p, a.lda);
+                    cv_c0 += BKT;
+                    if (cv_c0 >= a.conv_c) { cv_c0 = 0; ++cv_tap; }
+                }
+                aoff = cv_off;
+            }
+        }
+        glds_tile(Ag + aoff, goA, s, 1024u * NW);
         glds_tile(Bg + tc * stepB, goB, s + 2u * A_ELEMS, 1024u * NW);
     };
     // fragments of K sub-step ks (32 deep) of ring slot `slot`
@@ -483,6 +500,16 @@ template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW>
 // (the recon epilogue with its prefetched targets would spill under that budget: left unconstrained)
 __global__ __launch_bounds__(64 * NW, (EPI == DMVAE_EPI_BIAS_RECON ? 1 : NW / 2)) void gemm_bf16_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * (BM + BN) * BK];
+    if constexpr (LAYOUT == DMVAE_GEMM_DW) {
+        // conv-mode weight gradient, split-K: the tiles of ONE K slice are the nine taps of the same activation
+        // rows (and share the dY rows) -- put them on one XCD so the slice is fetched into one L2, once.
+        // Workgroups are dealt x-fastest round-robin over the 8 XCDs: linear id L -> XCD L & 7, its j-th there.
+        if (a.conv_c && (gridDim.y & 7) == 0) {
+            const int L = (int)(blockIdx.y * gridDim.x + blockIdx.x), xcd = L & 7, j = L >> 3, T = (int)gridDim.x;
+            gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW>(a, j % T, 0, -1, smem, nullptr, (j / T) * 8 + xcd);
+            return;
+        }
+    }
     gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW>(a, blockIdx.x, 0, gridDim.x, smem);
 }
 
@@ -765,7 +792,8 @@ int gemm_bf16_tile_m(int M, int N, int split) {
 template <int LAYOUT, int EPI>
 static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split) {
     GemmArgs a = a0;
-    const int t = gemm_bf16_tile_m(a.M, a.N, split);
+    int t = gemm_bf16_tile_m(a.M, a.N, split);
+    if (LAYOUT == DMVAE_GEMM_DW && a.conv_c) t = 64 * 1000 + (a.N % 128 == 0 ? 128 : 64);   // a tile row stays inside one tap
     // (256x128 tiles -- one 8-wave workgroup per CU, 3 x 48 KiB ring, 25 % fewer bytes per flop -- were
     //  measured three times and not kept: at M = 4096 the 2048-wide forward layer 16.7 vs 15.9 us, its dX
     //  17.1 vs 19.0 us; whole step at B = 16384: 1.0753 vs 1.0706 ms, at B = 8192 / D 256 / K 50: 0.8079 vs

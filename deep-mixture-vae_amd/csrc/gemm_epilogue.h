@@ -16,8 +16,20 @@ struct GemmArgs {
     const void* B; int64_t ldb;
     int M, N, K, k_split;   // k_split: contraction depth handled by one blockIdx.y
     int group_m;            // supertile height (tile rows) of the L2-friendly tile order
+    // Implicit 3x3 SAME convolution (csrc/conv.hip): conv_c != 0 makes the k-contiguous A operand a
+    // patch matrix that is never formed.  A's rows are the pixels of zero-bordered images in HBM
+    // ([B][P][P][lda], P = side + 2) and K runs over (tap, channel) with conv_c channels per tap:
+    // K tile k reads the SAME rows shifted by (tap/3 - 1) * P + (tap%3 - 1) pixels -- a wave-uniform
+    // pointer offset per tile; the per-lane offsets of the LDS-DMA stay loop-invariant.  In the DW layout
+    // (weight gradient, M = 9 * conv_c rows = (tap, channel)) the shift belongs to the tile row instead.
+    int conv_p, conv_c;
     dmvae_epilogue epi;
 };
+
+// element offset of K position k (multiple of the tile depth) of a conv-mode A operand
+__host__ __device__ __forceinline__ int64_t conv_tap_offset(int tap, int c0, int P, int64_t lda) {
+    return (int64_t)((tap / 3 - 1) * P + (tap % 3 - 1)) * lda + c0;
+}
 
 template <typename T> struct ActIO;
 template <> struct ActIO<bf16_t> {

@@ -51,7 +51,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
 
     const float* Ag = reinterpret_cast<const float*>(a.A);
     const float* Bg = reinterpret_cast<const float*>(a.B);
-    Ag += A_KC ? ((int64_t)m0 * a.lda + kbeg) : ((int64_t)kbeg * a.lda + m0);
+    if (!A_KC && a.conv_c)   // conv-mode weight gradient (gemm_epilogue.h): tile row m0 = (tap, channel)
+        Ag += ((int64_t)kbeg * a.lda + conv_tap_offset(m0 / a.conv_c, m0 % a.conv_c, a.conv_p, a.lda));
+    else
+        Ag += A_KC ? ((int64_t)m0 * a.lda + kbeg) : ((int64_t)kbeg * a.lda + m0);
     Bg += B_KC ? ((int64_t)n0 * a.ldb + kbeg) : ((int64_t)kbeg * a.ldb + n0);
     const int64_t stepA = A_KC ? (int64_t)FBK : (int64_t)FBK * a.lda;
     const int64_t stepB = B_KC ? (int64_t)FBK : (int64_t)FBK * a.ldb;
@@ -94,8 +97,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
             }
         }
     };
+    // conv mode (GemmArgs::conv_c, see gemm_epilogue.h): the k-contiguous A operand is an implicit patch
+    // matrix -- K tile t reads the same rows shifted by its tap; (tap, channel) is a running counter
+    const float* const Ag0 = Ag;
+    int cv_tap = 0, cv_c0 = 0;
+    if constexpr (A_KC) {
+        if (a.conv_c) {
+            Ag = Ag0 + conv_tap_offset(0, 0, a.conv_p, a.lda);
+            ra = f32_stage_load<A_KC>(Ag, a.lda, tid);
+            f32_stage_store<A_KC>(smem, ra, tid);
+            __syncthreads();
+        }
+    }
     for (int kt = 0; kt < nk - 1; ++kt) {   // branch-free steady state, last step peeled
         Ag += stepA; Bg += stepB;
+        if constexpr (A_KC) {
+            if (a.conv_c) {
+                cv_c0 += FBK;
+                if (cv_c0 >= a.conv_c) { cv_c0 = 0; ++cv_tap; }
+                Ag = Ag0 + conv_tap_offset(cv_tap, cv_c0, a.conv_p, a.lda);
+            }
+        }
         ra = f32_stage_load<A_KC>(Ag, a.lda, tid);
         rb = f32_stage_load<B_KC>(Bg, a.ldb, tid);
         compute(kt & 1);

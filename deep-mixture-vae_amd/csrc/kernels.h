@@ -41,9 +41,10 @@ int cast_launch(hipStream_t s, const void* in, void* out, int64_t n, int to_bf16
 int spin_launch(hipStream_t s, int us);
 void* gemm_bf16_stamps();
 // CNN trunk (conv.hip)
-int im2col3x3_launch(hipStream_t s, int dtype, const void* in, int64_t bstride, int ldc, int C, int H, int W, int64_t n_img, void* out, int Kpad);
-int maxpool2_fwd_launch(hipStream_t s, int dtype, const void* in, int H, int W, int ld, int64_t n_img, void* out);
-int maxpool2_bwd_relu_launch(hipStream_t s, int dtype, const void* in, const void* dout, int H, int W, int ld, int64_t n_img, void* din);
-int conv_wflip_launch(hipStream_t s, int dtype, const void* W, int ldw, int Cin, int Cout, void* Wt, int rows_pad, int Ktpad);
+int im2col_first_launch(hipStream_t s, int dtype, const void* x, int64_t bstride, int H, int64_t n_img, void* out, int Kpad);
+int zero_border_launch(hipStream_t s, int dtype, void* a, int P, int ld, int64_t n_img);
+int maxpool2_fwd_launch(hipStream_t s, int dtype, const void* in, int H, int ld, int64_t n_img, void* out, int out_border);
+int maxpool2_bwd_relu_launch(hipStream_t s, int dtype, const void* in, const void* dout, int H, int ld, int64_t n_img, void* din, int dout_border);
+int conv_wflip_launch(hipStream_t s, int dtype, const void* W, int cin_ld, int cout_ld, void* Wt);
 
 }  // namespace dmvae

@@ -162,6 +162,13 @@ class StepEngine:
         off, rows, cols, ld = self.tensors[name]
         if name.startswith("b_"):
             return torch.as_strided(arena, (cols,), (1,), off)
+        if name.startswith("W_conv"):
+            # HWIO kernel [9][cin][cout]; in the arena every tap holds cin_ld >= cin channel rows (the
+            # activations' channel stride: 64 for the 32-channel layers), so the view is 3-D
+            i = int(name[6:])
+            cin = CONV_STACK[i][1]
+            cin_ld = 1 if i == 0 else (CONV_STACK[i - 1][2] + 63) // 64 * 64
+            return torch.as_strided(arena, (9, cin, cols), (cin_ld * ld, ld, 1), off)
         return torch.as_strided(arena, (rows, cols), (ld, 1), off)
 
     def param_view(self, name):
@@ -173,15 +180,20 @@ class StepEngine:
     def parameter_names(self):
         return list(self.tensors.keys())
 
+    def _to_host(self, view, name):
+        a = view.detach().cpu().numpy().copy()
+        return a.reshape(self.tensors[name][1], self.tensors[name][2]) if a.ndim == 3 else a     # conv kernels: [9*cin][cout]
+
     def get_parameters(self):
-        return {k: self.param_view(k).detach().cpu().numpy().copy() for k in self.tensors}
+        return {k: self._to_host(self.param_view(k), k) for k in self.tensors}
 
     def get_gradients(self):
-        return {k: self.grad_view(k).detach().cpu().numpy().copy() for k in self.tensors}
+        return {k: self._to_host(self.grad_view(k), k) for k in self.tensors}
 
     def set_parameters(self, params):
         for k, v in params.items():
-            self.param_view(k).copy_(torch.as_tensor(np.asarray(v, dtype=np.float32)).to(self.device))
+            dst = self.param_view(k)
+            dst.copy_(torch.as_tensor(np.asarray(v, dtype=np.float32)).to(self.device).reshape(dst.shape))
         self.refresh_shadow()
 
     def init_parameters(self, seed=0):
@@ -341,13 +353,13 @@ class StepEngine:
         tdt = torch.bfloat16 if dt.value == _lib.BF16 else torch.float32
         es = 2 if dt.value == _lib.BF16 else 4
         off = p.value - self.work.data_ptr()
-        if name.startswith("conv"):          # [batch_pad * H * W][channels] relu outputs of a conv layer
+        if name.startswith("conv"):          # zero-bordered [batch_pad][hw+2][hw+2][channels] relu outputs of a conv layer
             hw = CONV_STACK[int(name[4])][3]
-            n = self.batch_pad * hw * hw
-            flat = self.work[off: off + n * ld.value * es].view(tdt)
-            t = torch.as_strided(flat, (n, ld.value), (ld.value, 1))
-            nr = (self.max_batch if rows is None else rows) * hw * hw
-            return t[:nr, : (CONV_STACK[int(name[4])][2] if cols is None else cols)]
+            P = hw + 2
+            flat = self.work[off: off + self.batch_pad * P * P * ld.value * es].view(tdt)
+            t = torch.as_strided(flat, (self.batch_pad, P, P, ld.value), (P * P * ld.value, P * ld.value, ld.value, 1))
+            nb = self.max_batch if rows is None else rows
+            return t[:nb, 1:-1, 1:-1, : (CONV_STACK[int(name[4])][2] if cols is None else cols)]
         flat = self.work[off: off + self.batch_pad * ld.value * es].view(tdt)
         t = torch.as_strided(flat, (self.batch_pad, ld.value), (ld.value, 1))
         full_cols = {"mean": self.latent_dim, "log_var": self.latent_dim, "logits": self.n_classes,
@@ -362,8 +374,7 @@ class StepEngine:
         out = {}
         if self.cnn:                          # [rows, H, W, channels] relu outputs of the conv layers
             for i, (name, _, co, hw, _) in enumerate(CONV_STACK):
-                v = self.view(name, rows)
-                out[name] = v.reshape(v.shape[0] // (hw * hw), hw, hw, co)
+                out[name] = self.view(name, rows)
         for i, w in enumerate(self.enc_layers):
             out["enc%d" % i] = self.view("enc%d" % i, rows, w)
         hzc = self.view("hzc", rows)
