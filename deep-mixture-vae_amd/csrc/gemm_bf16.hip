@@ -212,7 +212,8 @@ __device__ __forceinline__ int xcd_run_index(const int gid, const int gstart, co
 // NW = waves per workgroup: 4 (2 x 2) or 8 (4 x 2: two waves per SIMD share one tile's LDS traffic).
 // BKT = K depth of one ring slot (64; 32 is available to the dW layout: a 128x128 tile then gets a
 // 4-slot ring in the same 64 KiB, i.e. 48 KiB instead of 32 KiB in flight).
-template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW, int BKT = BK>
+// CONV: conv mode (GemmArgs::conv_c, gemm_epilogue.h) -- a compile-time variant, so the dense kernels carry none of it.
+template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW, int BKT = BK, bool CONV = false>
 __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_raw, const int gstart, const int nwg, bf16_t* smem,
                                                const dmvae_adam_ctx* ac = nullptr, const int kslice = -1) {
     constexpr bool A_KC = (LAYOUT != DMVAE_GEMM_DW);
@@ -251,7 +252,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
 
     const bf16_t* Ag = reinterpret_cast<const bf16_t*>(a.A);
     const bf16_t* Bg = reinterpret_cast<const bf16_t*>(a.B);
-    if (!A_KC && a.conv_c)   // conv-mode weight gradient: tile row m0 = (tap, channel) -> the activation rows shifted by the tap
+    if (!A_KC && CONV)       // conv-mode weight gradient: tile row m0 = (tap, channel) -> the activation rows shifted by the tap
         Ag += ((int64_t)kbeg * a.lda + conv_tap_offset(m0 / a.conv_c, m0 % a.conv_c, a.conv_p, a.lda));
     else
         Ag += A_KC ? ((int64_t)m0 * a.lda + kbeg) : ((int64_t)kbeg * a.lda + m0);
@@ -300,8 +301,8 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
         const int tc = t < nk ? t : nk - 1;
         const unsigned s = lds_w + 2u * (unsigned)(slot * STAGE);
         int64_t aoff = tc * stepA;
-        if constexpr (A_KC) {
-            if (a.conv_c) {
+        if constexpr (A_KC && CONV) {
+            {
                 if (t < nk) {
                     cv_off = conv_tap_offset(cv_tap, cv_c0, a.conv_p, a.lda);
                     cv_c0 += BKT;
@@ -500,17 +501,25 @@ template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW>
 // (the recon epilogue with its prefetched targets would spill under that budget: left unconstrained)
 __global__ __launch_bounds__(64 * NW, (EPI == DMVAE_EPI_BIAS_RECON ? 1 : NW / 2)) void gemm_bf16_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * (BM + BN) * BK];
+    gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW>(a, blockIdx.x, 0, gridDim.x, smem);
+}
+
+// The same tile in conv mode (implicit 3x3 convolution, csrc/conv.hip): its own kernel, so the dense
+// instantiations above are bit-for-bit what they were (a run-time flag in their K loop cost 1.6 % of the step).
+template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_bf16_conv_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * (BM + BN) * BK];
     if constexpr (LAYOUT == DMVAE_GEMM_DW) {
-        // conv-mode weight gradient, split-K: the tiles of ONE K slice are the nine taps of the same activation
-        // rows (and share the dY rows) -- put them on one XCD so the slice is fetched into one L2, once.
-        // Workgroups are dealt x-fastest round-robin over the 8 XCDs: linear id L -> XCD L & 7, its j-th there.
-        if (a.conv_c && (gridDim.y & 7) == 0) {
+        // weight gradient, split-K: the tiles of ONE K slice are the nine taps of the same activation rows (and
+        // share the dY rows) -- put them on one XCD so the slice is fetched into one L2, once.  Workgroups are
+        // dealt x-fastest round-robin over the 8 XCDs: linear id L -> XCD L & 7, its j-th workgroup there.
+        if ((gridDim.y & 7) == 0) {
             const int L = (int)(blockIdx.y * gridDim.x + blockIdx.x), xcd = L & 7, j = L >> 3, T = (int)gridDim.x;
-            gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW>(a, j % T, 0, -1, smem, nullptr, (j / T) * 8 + xcd);
+            gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW, BK, true>(a, j % T, 0, -1, smem, nullptr, (j / T) * 8 + xcd);
             return;
         }
     }
-    gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW>(a, blockIdx.x, 0, gridDim.x, smem);
+    gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW, BK, true>(a, blockIdx.x, 0, gridDim.x, smem);
 }
 
 // Grouped launch: several independent GEMM problems of one layout / epilogue / tile shape in ONE
@@ -619,6 +628,16 @@ static int launch(hipStream_t s, const GemmArgs& a, int split) {
     ProfScope ps(s, kernel_name<BM, BN, LAYOUT, EPI, NSTAGE, NW>(false), 2.0 * a.M * a.N * (double)a.K, gemm_bytes(a));
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, LAYOUT, EPI, NSTAGE, NW>), grid, dim3(64 * NW), 0, s, a);
     return check_launch("gemm_bf16");
+}
+
+template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4>
+static int launch_conv(hipStream_t s, const GemmArgs& a, int split) {
+    dim3 grid((a.M / BM) * (a.N / BN), split);
+    static char nm[64];
+    snprintf(nm, sizeof(nm), "gemm_bf16_conv_kernel<%d, %d, %d, %d, %d, %d>", BM, BN, LAYOUT, EPI, NSTAGE, NW);
+    ProfScope ps(s, nm, 2.0 * a.M * a.N * (double)a.K, gemm_bytes(a));
+    hipLaunchKernelGGL((gemm_bf16_conv_kernel<BM, BN, LAYOUT, EPI, NSTAGE, NW>), grid, dim3(64 * NW), 0, s, a);
+    return check_launch("gemm_bf16_conv");
 }
 
 // Grouped launch of n independent problems that share a layout and an epilogue kind.  Tile per
@@ -793,7 +812,23 @@ template <int LAYOUT, int EPI>
 static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split) {
     GemmArgs a = a0;
     int t = gemm_bf16_tile_m(a.M, a.N, split);
-    if (LAYOUT == DMVAE_GEMM_DW && a.conv_c) t = 64 * 1000 + (a.N % 128 == 0 ? 128 : 64);   // a tile row stays inside one tap
+    if (a.conv_c) {          // conv mode (csrc/conv.hip): the three (layout, epilogue) pairs a convolution layer uses
+        constexpr bool ok = (LAYOUT == DMVAE_GEMM_FWD && EPI == DMVAE_EPI_BIAS_RELU) || (LAYOUT == DMVAE_GEMM_DX && EPI == DMVAE_EPI_RELU_MASK) ||
+                            (LAYOUT == DMVAE_GEMM_DW && EPI == DMVAE_EPI_ATOMIC_F32);
+        if constexpr (ok) {
+            if (LAYOUT == DMVAE_GEMM_DW) t = 64 * 1000 + (a.N % 128 == 0 ? 128 : 64);   // a tile row stays inside one tap
+            a.group_m = auto_group_m(a.M / (t / 1000), a.N / (t % 1000), t / 1000, t % 1000);
+            switch (t) {
+                case 128128: return launch_conv<128, 128, LAYOUT, EPI, 2, 8>(s, a, split);
+                case 128064: return launch_conv<128, 64, LAYOUT, EPI, 3, 8>(s, a, split);
+                case 64128: return launch_conv<64, 128, LAYOUT, EPI, 3>(s, a, split);
+                default: return launch_conv<64, 64, LAYOUT, EPI, 4>(s, a, split);
+            }
+        } else {
+            set_error("dmvae_gemm(bf16): conv mode is built for FWD+BIAS_RELU, DX+RELU_MASK and DW+ATOMIC_F32");
+            return DMVAE_EUNSUPPORTED;
+        }
+    }
     // (256x128 tiles -- one 8-wave workgroup per CU, 3 x 48 KiB ring, 25 % fewer bytes per flop -- were
     //  measured three times and not kept: at M = 4096 the 2048-wide forward layer 16.7 vs 15.9 us, its dX
     //  17.1 vs 19.0 us; whole step at B = 16384: 1.0753 vs 1.0706 ms, at B = 8192 / D 256 / K 50: 0.8079 vs
