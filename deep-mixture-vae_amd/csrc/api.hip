@@ -63,6 +63,8 @@ static const char* gemm_name(int dtype, int layout) {
     return n[dtype][layout];
 }
 
+static inline int pad64(int x) { return (x + 63) / 64 * 64; }
+
 static int gemm_checked(hipStream_t s, int dtype, int layout, int M, int N, int K, const void* A, int64_t lda,
                         const void* B, int64_t ldb, const dmvae_epilogue* epi, int split, GemmArgs* deferred = nullptr,
                         int conv_p = 0, int conv_c = 0) {
@@ -80,9 +82,9 @@ static int gemm_checked(hipStream_t s, int dtype, int layout, int M, int N, int 
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb;
     a.M = M; a.N = N; a.K = K; a.k_split = K / split; a.group_m = 8;
     a.conv_p = conv_p; a.conv_c = conv_c;
-    DMVAE_REQUIRE(conv_c == 0 || (conv_c % 64 == 0 && lda == conv_c &&
-                                  (layout == DMVAE_GEMM_DW ? M == 9 * conv_c : (K == 9 * conv_c && split == 1))),
-                  "dmvae_gemm: conv mode needs A with lda = channels per tap and 9 * channels along K (M for the weight gradient)");
+    DMVAE_REQUIRE(conv_c == 0 || ((conv_c == 32 || conv_c % 64 == 0) && lda >= conv_c &&
+                                  (layout == DMVAE_GEMM_DW ? M == pad64(9 * conv_c) : (K == pad64(9 * conv_c) && split == 1))),
+                  "dmvae_gemm: conv mode: 32 or a multiple of 64 channels per tap (<= lda), 9 taps padded to 64 along K (M for the weight gradient)");
     a.epi = *epi;
     if (a.epi.m_valid <= 0) a.epi.m_valid = M;
     if (a.epi.n_valid <= 0) a.epi.n_valid = N;
@@ -104,7 +106,6 @@ static int gemm_partials(int dtype, int M, int N) {
 using namespace dmvae;
 
 // ====================================================================== plan
-static inline int pad64(int x) { return (x + 63) / 64 * 64; }
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 struct PLayer {
@@ -121,8 +122,8 @@ struct PConv {
     int cin, cout, hw, pool;          // channels, image side of its input = output, 2x2 SAME max-pool behind it
     int cin_ld, cout_ld;              // channel stride of the input / output activation (pad64; the image itself: 1)
     int P;                            // hw + 2
-    int kdim;                         // K of the forward GEMM: 9 * cin_ld (first layer: 64, an explicit 9-column patch matrix)
-    int64_t w_off, b_off;             // W [(tap, c < cin_ld)][cout_ld] (HWIO with padded channels, zero pads), b [cout_ld]
+    int kdim, ktdim;                  // K of the forward / input-gradient GEMM: 9 * cin / 9 * cout padded to 64 (first layer: an explicit 9-column patch matrix)
+    int64_t w_off, b_off;             // W [kdim][cout_ld]: HWIO flattened, rows (tap, c < cin), zero pad rows / columns; b [cout_ld]
     int64_t o_act, o_dact;            // relu output and its gradient
     int64_t o_pool, o_dpool;          // pooled output (zero-bordered for the next conv; the last one plain = the flat trunk output) and its gradient
     int64_t o_col;                    // first layer only: its patch matrix [Bp*P*P][64]
@@ -201,10 +202,9 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
             L.name = "conv" + std::to_string(i);
             L.cin = spec[i][0]; L.cout = spec[i][1]; L.hw = spec[i][2]; L.pool = spec[i][3];
             L.cin_ld = ld_in; L.cout_ld = pad64(L.cout); L.P = L.hw + 2;
-            L.kdim = i == 0 ? 64 : 9 * L.cin_ld;
+            L.kdim = pad64(9 * L.cin); L.ktdim = pad64(9 * L.cout);
             L.w_off = off; off += (int64_t)L.kdim * L.cout_ld;
             L.b_off = off; off += L.cout_ld;
-            // logical [9*cin][cout]; row (tap, c) sits at tap * cin_ld + c: a 3-D view when cin < cin_ld (dmvae_hip.h)
             add_tensor(p, "W_" + L.name, L.w_off, 9 * L.cin, L.cout, L.cout_ld);
             add_tensor(p, "b_" + L.name, L.b_off, 1, L.cout, L.cout_ld);
             p->conv.push_back(L);
@@ -273,7 +273,7 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
             const bool last = i + 1 == p->conv.size();
             L.o_pool = L.pool ? (last ? take(Bp * ho * ho * L.cout_ld * es) : bordered(ho + 2, L.cout_ld)) : 0;
             L.o_dpool = (L.pool && !last) ? bordered(ho + 2, L.cout_ld) : 0;
-            if (i > 0) wmax = std::max<int64_t>(wmax, (int64_t)L.cin_ld * 9 * L.cout_ld);
+            if (i > 0) wmax = std::max<int64_t>(wmax, (int64_t)L.cin_ld * L.ktdim);
         }
         if (!p->conv.empty()) {
             p->o_wt = take(wmax * es);
@@ -402,7 +402,7 @@ static int conv_trunk_forward(dmvae_plan* p, hipStream_t s, const void** flat) {
             TRY(im2col_first_launch(s, dt, WS(p, p->o_x), p->Ip, L.hw, p->Bp, WS(p, L.o_col), L.kdim));
             TRY(gemm_checked(s, dt, DMVAE_GEMM_FWD, M, L.cout_ld, L.kdim, WS(p, L.o_col), L.kdim, Wp(p, L.w_off), L.cout_ld, &e, 1));
         } else {
-            TRY(gemm_checked(s, dt, DMVAE_GEMM_FWD, M, L.cout_ld, L.kdim, in, L.cin_ld, Wp(p, L.w_off), L.cout_ld, &e, 1, nullptr, L.P, L.cin_ld));
+            TRY(gemm_checked(s, dt, DMVAE_GEMM_FWD, M, L.cout_ld, L.kdim, in, L.cin_ld, Wp(p, L.w_off), L.cout_ld, &e, 1, nullptr, L.P, L.cin));
         }
         TRY(zero_border_launch(s, dt, rows0(p, L.o_act, L.P, L.cout_ld), L.P, L.cout_ld, p->Bp));
         in = rows0(p, L.o_act, L.P, L.cout_ld);
@@ -461,13 +461,17 @@ static int conv_trunk_backward(dmvae_plan* p, hipStream_t s) {
         const PConv& Lp = p->conv[i - 1];
         const char* in = Lp.pool ? rows0(p, Lp.o_pool, L.P, L.cin_ld) : rows0(p, Lp.o_act, L.P, L.cin_ld);
         e.out = p->buf.grad + L.w_off; e.out2 = p->buf.grad + L.b_off;
-        TRY(gemm_checked(s, dt, DMVAE_GEMM_DW, 9 * L.cin_ld, L.cout_ld, M, in, L.cin_ld, dact, L.cout_ld, &e,
-                         conv_dw_split(M, 9 * (L.cin_ld / 64) * (L.cout_ld / 64)), nullptr, L.P, L.cin_ld));
-        TRY(conv_wflip_launch(s, dt, Wp(p, L.w_off), L.cin_ld, L.cout_ld, WS(p, p->o_wt)));
+        TRY(gemm_checked(s, dt, DMVAE_GEMM_DW, L.kdim, L.cout_ld, M, in, L.cin_ld, dact, L.cout_ld, &e,
+                         conv_dw_split(M, (L.kdim / 64) * (L.cout_ld / 64)), nullptr, L.P, L.cin));
+        if (L.kdim > 9 * L.cin) {   // rows past the ninth tap are padding: the GEMM filled them with a copy of tap 8
+            me = hipMemsetAsync(p->buf.grad + L.w_off + (int64_t)9 * L.cin * L.cout_ld, 0, (size_t)(L.kdim - 9 * L.cin) * L.cout_ld * 4, s);
+            if (me != hipSuccess) { set_error("conv gradient pad memset: %s", hipGetErrorString(me)); return (int)me; }
+        }
+        TRY(conv_wflip_launch(s, dt, Wp(p, L.w_off), L.cin, L.cin_ld, L.cout, L.cout_ld, WS(p, p->o_wt), L.ktdim));
         memset(&e, 0, sizeof(e));
         e.kind = DMVAE_EPI_RELU_MASK; e.ldo = L.cin_ld; e.aux0 = in; e.ld0 = L.cin_ld;
         e.out = Lp.pool ? rows0(p, Lp.o_dpool, L.P, L.cin_ld) : rows0(p, Lp.o_dact, L.P, L.cin_ld);
-        TRY(gemm_checked(s, dt, DMVAE_GEMM_DX, M, L.cin_ld, 9 * L.cout_ld, dact, L.cout_ld, WS(p, p->o_wt), 9 * L.cout_ld, &e, 1, nullptr, L.P, L.cout_ld));
+        TRY(gemm_checked(s, dt, DMVAE_GEMM_DX, M, L.cin_ld, L.ktdim, dact, L.cout_ld, WS(p, p->o_wt), L.ktdim, &e, 1, nullptr, L.P, L.cout));
     }
     return 0;
 }

@@ -13,8 +13,9 @@
 //   * the weight gradient is ONE DW-layout GEMM with M = (tap, channel): a tile row reads the
 //     activation shifted by its tap's row offset, against dY over all padded rows (dY's border
 //     rows are zero); split-K with fp32 atomics.
-// The cost is the border (15 % more rows at 28x28, 65 % at 7x7) and K = 9 * 64 for the 32-channel
-// layers; what it buys is that no patch matrix (9x the activation bytes) is written or read.
+// The cost is the border (15 % more rows at 28x28, 65 % at 7x7); what it buys is that no patch matrix
+// (9x the activation bytes) is written or read.  K counts the REAL channels: a 32-channel layer (stored
+// with 32 zero pad channels) puts two taps into one 64-wide K tile.
 //
 // T is the activation type of the plan (float in parity mode, bf16 otherwise); channel strides are
 // multiples of 64 (32-channel layers carry 32 zero channels).
@@ -150,16 +151,18 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_relu_kernel(const T* __restr
     }
 }
 
-// Kernel of the input-gradient convolution.  W is [(tap, ci < cin_ld)][cout_ld]; the result
-// Wt[ci][(tap', co < cout_ld)] = W[(8 - tap', ci)][co]: taps flipped ((2-ky)*3 + (2-kx) = 8 - tap), channels
-// transposed; W's zero pad rows / columns carry over.
+// Kernel of the input-gradient convolution.  W = [(tap, ci < cin)][ldw] (HWIO flattened); the result
+// Wt[ci < cin_ld][Kt], column (tap', co < cout) = W[(8 - tap', ci)][co]: taps flipped ((2-ky)*3 + (2-kx) = 8 - tap),
+// channels transposed; zero in the pad rows ci >= cin and the pad columns >= 9 * cout.
 template <typename T>
-__global__ __launch_bounds__(256) void conv_wflip_kernel(const T* __restrict__ W, int cin_ld, int cout_ld, T* __restrict__ Wt) {
-    const int Kt = 9 * cout_ld, total = cin_ld * Kt;
+__global__ __launch_bounds__(256) void conv_wflip_kernel(const T* __restrict__ W, int cin, int cin_ld, int cout, int ldw, T* __restrict__ Wt, int Kt) {
+    const int total = cin_ld * Kt;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         const int ci = e / Kt, k = e - ci * Kt;
-        const int tap = k / cout_ld, co = k - tap * cout_ld;
-        Wt[e] = W[(int64_t)((8 - tap) * cin_ld + ci) * cout_ld + co];
+        const int tap = k / cout, co = k - tap * cout;
+        T v = T(0);
+        if (ci < cin && tap < 9) v = W[(int64_t)((8 - tap) * cin + ci) * ldw + co];
+        Wt[e] = v;
     }
 }
 
@@ -210,11 +213,12 @@ int maxpool2_bwd_relu_launch(hipStream_t s, int dtype, const void* in, const voi
     return check_launch("maxpool2_bwd_relu");
 }
 
-int conv_wflip_launch(hipStream_t s, int dtype, const void* W, int cin_ld, int cout_ld, void* Wt) {
-    ProfScope ps(s, "conv_wflip", 0.0, 2.0 * cin_ld * 9 * cout_ld * esize(dtype));
-    const int nb = grid_for((int64_t)cin_ld * 9 * cout_ld);
-    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((conv_wflip_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)W, cin_ld, cout_ld, (bf16_t*)Wt);
-    else hipLaunchKernelGGL((conv_wflip_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)W, cin_ld, cout_ld, (float*)Wt);
+int conv_wflip_launch(hipStream_t s, int dtype, const void* W, int cin, int cin_ld, int cout, int ldw, void* Wt, int Kt) {
+    if (Kt < 9 * cout || cin_ld < cin) { set_error("conv_wflip: pads smaller than the kernel"); return DMVAE_EINVAL; }
+    ProfScope ps(s, "conv_wflip", 0.0, 2.0 * cin_ld * Kt * esize(dtype));
+    const int nb = grid_for((int64_t)cin_ld * Kt);
+    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((conv_wflip_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)W, cin, cin_ld, cout, ldw, (bf16_t*)Wt, Kt);
+    else hipLaunchKernelGGL((conv_wflip_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)W, cin, cin_ld, cout, ldw, (float*)Wt, Kt);
     return check_launch("conv_wflip");
 }
 

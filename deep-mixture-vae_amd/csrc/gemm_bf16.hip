@@ -252,8 +252,8 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
 
     const bf16_t* Ag = reinterpret_cast<const bf16_t*>(a.A);
     const bf16_t* Bg = reinterpret_cast<const bf16_t*>(a.B);
-    if (!A_KC && CONV)       // conv-mode weight gradient: tile row m0 = (tap, channel) -> the activation rows shifted by the tap
-        Ag += ((int64_t)kbeg * a.lda + conv_tap_offset(m0 / a.conv_c, m0 % a.conv_c, a.conv_p, a.lda));
+    if (!A_KC && CONV)       // conv-mode weight gradient: the tap shift of every column sits in the per-lane offsets (below),
+        Ag += ((int64_t)kbeg - (a.conv_p + 1)) * a.lda;     // taken relative to the most negative shift so that they stay unsigned
     else
         Ag += A_KC ? ((int64_t)m0 * a.lda + kbeg) : ((int64_t)kbeg * a.lda + m0);
     Bg += B_KC ? ((int64_t)n0 * a.ldb + kbeg) : ((int64_t)kbeg * a.ldb + n0);
@@ -280,6 +280,29 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     unsigned goA[BM * BKT / (512 * NW)], goB[BN * BKT / (512 * NW)];
     stage_offsets<BM, A_KC, NW, BKT>(a.lda, wave, lane, goA);
     stage_offsets<BN, B_KC, NW, BKT>(a.ldb, wave, lane, goB);
+    // Conv mode: K (or, for the weight gradient, M) runs over (tap, channel) with conv_c channels per tap, and an
+    // operand row holds lda >= conv_c channels.  conv_c >= 64: a 64-wide tile lies inside one tap.  conv_c = 32 (the
+    // 32-channel layers, stored with 32 zero pad channels): a tile covers TWO taps -- 16-byte chunks 0..3 belong to
+    // the first, 4..7 to the second (selA), each reading channels 0..31 of its own shifted row.
+    unsigned selA[BM * BKT / (512 * NW)];
+#pragma unroll
+    for (int i = 0; i < BM * BKT / (512 * NW); ++i) selA[i] = 0;
+    if constexpr (CONV) {
+        static_assert(A_KC || BM == 64, "conv-mode weight gradient: 64-row tiles");
+#pragma unroll
+        for (int i = 0; i < BM * BKT / (512 * NW); ++i) {
+            const int row = i * (8 * NW) + wave * 8 + (lane >> 3);            // both layouts: 8 rows x 8 chunks per wave pass
+            if constexpr (A_KC) {
+                const int k = swz_kc(row, lane & 7) * 8;                          // position inside the 64-wide K tile
+                selA[i] = (unsigned)(k / a.conv_c);
+                goA[i] = 2u * (unsigned)(row * (int)a.lda + k % a.conv_c);
+            } else {
+                const int m = m0 + swz_nc<64>(row, lane & 7) * 8;                // (tap, channel) of this chunk's columns
+                const int tap = min(m / a.conv_c, 8);                             // rows past 9 taps are padding (their gradient is zeroed)
+                goA[i] = 2u * (unsigned)((row + (tap / 3 - 1) * a.conv_p + (tap % 3 - 1) + a.conv_p + 1) * (int)a.lda + m % a.conv_c);
+            }
+        }
+    }
     unsigned short foA[BKT / 32][TM][2], foB[BKT / 32][TN][2];
 #pragma unroll
     for (int ks = 0; ks < BKT / 32; ++ks) {
@@ -294,24 +317,28 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
 
     // issue the loads of K tile t (clamped to the last tile: keeps the vmcnt arithmetic uniform;
     // a clamped tile lands in a ring slot nobody reads) into ring slot `slot`
-    // conv mode (GemmArgs::conv_c): tiles are issued in K order, so (tap, channel) is a running counter
+    // conv mode: tiles are issued in K order, so (tap, channel) of a tile's first column is a running counter
     int cv_tap = 0, cv_c0 = 0;
     int64_t cv_off = 0;
+    unsigned cv_delta = 0;                              // bytes from the tile's first tap to its second (conv_c = 32)
     auto issue = [&](int t, int slot) {
         const int tc = t < nk ? t : nk - 1;
         const unsigned s = lds_w + 2u * (unsigned)(slot * STAGE);
-        int64_t aoff = tc * stepA;
         if constexpr (A_KC && CONV) {
-            {
-                if (t < nk) {
-                    cv_off = conv_tap_offset(cv_tap, cv_c0, a.conv_p, a.lda);
-                    cv_c0 += BKT;
-                    if (cv_c0 >= a.conv_c) { cv_c0 = 0; ++cv_tap; }
-                }
-                aoff = cv_off;
+            if (t < nk) {
+                const int t0 = min(cv_tap, 8), t1 = min(cv_tap + 1, 8);       // taps past the ninth: padding columns, zero weights
+                cv_off = conv_tap_offset(t0, cv_c0, a.conv_p, a.lda);
+                cv_delta = (unsigned)(2 * (int)(conv_tap_offset(t1, 0, a.conv_p, a.lda) - conv_tap_offset(t0, 0, a.conv_p, a.lda)));
+                cv_c0 += BKT;
+                while (cv_c0 >= a.conv_c) { cv_c0 -= a.conv_c; ++cv_tap; }
             }
+            unsigned o[BM * BKT / (512 * NW)];
+#pragma unroll
+            for (int i = 0; i < BM * BKT / (512 * NW); ++i) o[i] = goA[i] + selA[i] * cv_delta;
+            glds_tile(Ag + cv_off, o, s, 1024u * NW);
+        } else {
+            glds_tile(Ag + tc * stepA, goA, s, 1024u * NW);
         }
-        glds_tile(Ag + aoff, goA, s, 1024u * NW);
         glds_tile(Bg + tc * stepB, goB, s + 2u * A_ELEMS, 1024u * NW);
     };
     // fragments of K sub-step ks (32 deep) of ring slot `slot`
@@ -818,11 +845,16 @@ static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split) {
         if constexpr (ok) {
             if (LAYOUT == DMVAE_GEMM_DW) t = 64 * 1000 + (a.N % 128 == 0 ? 128 : 64);   // a tile row stays inside one tap
             a.group_m = auto_group_m(a.M / (t / 1000), a.N / (t % 1000), t / 1000, t % 1000);
-            switch (t) {
-                case 128128: return launch_conv<128, 128, LAYOUT, EPI, 2, 8>(s, a, split);
-                case 128064: return launch_conv<128, 64, LAYOUT, EPI, 3, 8>(s, a, split);
-                case 64128: return launch_conv<64, 128, LAYOUT, EPI, 3>(s, a, split);
-                default: return launch_conv<64, 64, LAYOUT, EPI, 4>(s, a, split);
+            if constexpr (LAYOUT == DMVAE_GEMM_DW) {
+                if (t == 64128) return launch_conv<64, 128, LAYOUT, EPI, 3>(s, a, split);
+                return launch_conv<64, 64, LAYOUT, EPI, 4>(s, a, split);
+            } else {
+                switch (t) {
+                    case 128128: return launch_conv<128, 128, LAYOUT, EPI, 2, 8>(s, a, split);
+                    case 128064: return launch_conv<128, 64, LAYOUT, EPI, 3, 8>(s, a, split);
+                    case 64128: return launch_conv<64, 128, LAYOUT, EPI, 3>(s, a, split);
+                    default: return launch_conv<64, 64, LAYOUT, EPI, 4>(s, a, split);
+                }
             }
         } else {
             set_error("dmvae_gemm(bf16): conv mode is built for FWD+BIAS_RELU, DX+RELU_MASK and DW+ATOMIC_F32");

@@ -18,10 +18,12 @@ struct GemmArgs {
     int group_m;            // supertile height (tile rows) of the L2-friendly tile order
     // Implicit 3x3 SAME convolution (csrc/conv.hip): conv_c != 0 makes the k-contiguous A operand a
     // patch matrix that is never formed.  A's rows are the pixels of zero-bordered images in HBM
-    // ([B][P][P][lda], P = side + 2) and K runs over (tap, channel) with conv_c channels per tap:
-    // K tile k reads the SAME rows shifted by (tap/3 - 1) * P + (tap%3 - 1) pixels -- a wave-uniform
-    // pointer offset per tile; the per-lane offsets of the LDS-DMA stay loop-invariant.  In the DW layout
-    // (weight gradient, M = 9 * conv_c rows = (tap, channel)) the shift belongs to the tile row instead.
+    // ([B][P][P][lda], P = side + 2) and K runs over (tap, channel) with conv_c <= lda channels per tap
+    // (32, or a multiple of 64), padded to a multiple of 64 with zero-weight columns: the columns of tap t
+    // are the SAME rows shifted by (t/3 - 1) * P + (t%3 - 1) pixels -- a wave-uniform pointer offset per K
+    // tile (conv_c = 32: two taps per tile, the second a wave-uniform delta on half of the lanes); the
+    // per-lane offsets of the LDS-DMA stay loop-invariant.  In the DW layout (weight gradient, M = the
+    // (tap, channel) rows) the shift belongs to the tile's columns instead.
     int conv_p, conv_c;
     dmvae_epilogue epi;
 };

@@ -51,9 +51,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
 
     const float* Ag = reinterpret_cast<const float*>(a.A);
     const float* Bg = reinterpret_cast<const float*>(a.B);
-    if (!A_KC && a.conv_c)   // conv-mode weight gradient (gemm_epilogue.h): tile row m0 = (tap, channel)
-        Ag += ((int64_t)kbeg * a.lda + conv_tap_offset(m0 / a.conv_c, m0 % a.conv_c, a.conv_p, a.lda));
-    else
+    if (!A_KC && a.conv_c) {   // conv-mode weight gradient (gemm_epilogue.h): column m = (tap, channel); this thread's columns
+        const int m = m0 + (tid & 15) * 4, tap = min(m / a.conv_c, 8);   // (rows past the ninth tap are padding, zeroed by the caller)
+        Ag += (int64_t)kbeg * a.lda + conv_tap_offset(tap, m % a.conv_c, a.conv_p, a.lda) - (tid & 15) * 4;
+    } else
         Ag += A_KC ? ((int64_t)m0 * a.lda + kbeg) : ((int64_t)kbeg * a.lda + m0);
     Bg += B_KC ? ((int64_t)n0 * a.ldb + kbeg) : ((int64_t)kbeg * a.ldb + n0);
     const int64_t stepA = A_KC ? (int64_t)FBK : (int64_t)FBK * a.lda;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
             if (a.conv_c) {
                 cv_c0 += FBK;
                 if (cv_c0 >= a.conv_c) { cv_c0 = 0; ++cv_tap; }
-                Ag = Ag0 + conv_tap_offset(cv_tap, cv_c0, a.conv_p, a.lda);
+                Ag = Ag0 + conv_tap_offset(min(cv_tap, 8), cv_c0, a.conv_p, a.lda);     // past the ninth tap: padding columns, zero weights
             }
         }
         ra = f32_stage_load<A_KC>(Ag, a.lda, tid);

@@ -45,6 +45,6 @@ int im2col_first_launch(hipStream_t s, int dtype, const void* x, int64_t bstride
 int zero_border_launch(hipStream_t s, int dtype, void* a, int P, int ld, int64_t n_img);
 int maxpool2_fwd_launch(hipStream_t s, int dtype, const void* in, int H, int ld, int64_t n_img, void* out, int out_border);
 int maxpool2_bwd_relu_launch(hipStream_t s, int dtype, const void* in, const void* dout, int H, int ld, int64_t n_img, void* din, int dout_border);
-int conv_wflip_launch(hipStream_t s, int dtype, const void* W, int cin_ld, int cout_ld, void* Wt);
+int conv_wflip_launch(hipStream_t s, int dtype, const void* W, int cin, int cin_ld, int cout, int ldw, void* Wt, int Kt);
 
 }  // namespace dmvae

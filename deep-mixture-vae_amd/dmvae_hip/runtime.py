@@ -162,13 +162,6 @@ class StepEngine:
         off, rows, cols, ld = self.tensors[name]
         if name.startswith("b_"):
             return torch.as_strided(arena, (cols,), (1,), off)
-        if name.startswith("W_conv"):
-            # HWIO kernel [9][cin][cout]; in the arena every tap holds cin_ld >= cin channel rows (the
-            # activations' channel stride: 64 for the 32-channel layers), so the view is 3-D
-            i = int(name[6:])
-            cin = CONV_STACK[i][1]
-            cin_ld = 1 if i == 0 else (CONV_STACK[i - 1][2] + 63) // 64 * 64
-            return torch.as_strided(arena, (9, cin, cols), (cin_ld * ld, ld, 1), off)
         return torch.as_strided(arena, (rows, cols), (ld, 1), off)
 
     def param_view(self, name):
@@ -181,8 +174,7 @@ class StepEngine:
         return list(self.tensors.keys())
 
     def _to_host(self, view, name):
-        a = view.detach().cpu().numpy().copy()
-        return a.reshape(self.tensors[name][1], self.tensors[name][2]) if a.ndim == 3 else a     # conv kernels: [9*cin][cout]
+        return view.detach().cpu().numpy().copy()
 
     def get_parameters(self):
         return {k: self._to_host(self.param_view(k), k) for k in self.tensors}

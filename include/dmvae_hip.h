@@ -237,9 +237,7 @@ int dmvae_cast_bf16_to_f32(void* stream, const void* in, float* out, int64_t n);
  * the 2nd / 4th / 6th, flattened (h,w,c) to 2048, then ONE FullyConnected layer enc[0] (n_enc must be 1,
  * input_dim 784).  The conv layers run as the step's GEMMs in conv mode -- the patch matrix is implicit,
  * activations are stored with a zero border (csrc/conv.hip).  Their tensors come first in the arena:
- * "b_conv<i>" [Cout] and "W_conv<i>", reported as the logical HWIO-flattened [9*Cin][Cout] with ld = Cout
- * padded to 64; row (tap, c) sits at tap * Cin_ld + c, where Cin_ld is the channel stride of the layer's
- * input (1 for conv0, else Cin padded to 64), i.e. a [9][Cin][Cout] view with strides (Cin_ld * ld, ld, 1). */
+ * "W_conv<i>" [9*Cin][Cout] = the HWIO kernel flattened (ld = Cout padded to 64) and "b_conv<i>" [Cout]. */
 #define DMVAE_TRUNK_MLP 0
 #define DMVAE_TRUNK_CNN 1
 
