@@ -126,7 +126,6 @@ struct PConv {
     int64_t w_off, b_off;             // W [kdim][cout_ld]: HWIO flattened, rows (tap, c < cin), zero pad rows / columns; b [cout_ld]
     int64_t o_act, o_dact;            // relu output and its gradient
     int64_t o_pool, o_dpool;          // pooled output (zero-bordered for the next conv; the last one plain = the flat trunk output) and its gradient
-    int64_t o_col;                    // first layer only: its patch matrix [Bp*P*P][64]
 };
 
 struct dmvae_plan {
@@ -266,7 +265,6 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
         for (size_t i = 0; i < p->conv.size(); ++i) {
             PConv& L = p->conv[i];
             auto bordered = [&](int P, int ld) { return take((Bp * P * P + 2 * (P + 1)) * ld * es); };
-            L.o_col = i == 0 ? take(Bp * L.P * L.P * L.kdim * es) : 0;
             L.o_act = bordered(L.P, L.cout_ld);
             L.o_dact = bordered(L.P, L.cout_ld);
             const int ho = (L.hw + 1) / 2;
@@ -386,7 +384,7 @@ static int fwd_dense(dmvae_plan* p, hipStream_t s, const void* A, int64_t lda, i
 // pointer to padded pixel 0 of a zero-bordered activation (skips the P + 1 guard rows)
 static inline char* rows0(const dmvae_plan* p, int64_t off, int P, int ld) { return WS(p, off) + (int64_t)(P + 1) * ld * p->es; }
 
-// CNN trunk forward (base_models.py:176-216).  First layer: explicit 9-column patch matrix; every other
+// CNN trunk forward (base_models.py:176-216).  First layer (one input channel): a direct kernel; every other
 // convolution is ONE conv-mode GEMM straight off the zero-bordered activation (conv.hip) + bias + ReLU, then
 // the border rows (which computed relu(bias)) are re-zeroed; SAME max-pools behind conv1 / conv3 / conv5.
 static int conv_trunk_forward(dmvae_plan* p, hipStream_t s, const void** flat) {
@@ -398,13 +396,13 @@ static int conv_trunk_forward(dmvae_plan* p, hipStream_t s, const void** flat) {
         dmvae_epilogue e;
         memset(&e, 0, sizeof(e));
         e.kind = DMVAE_EPI_BIAS_RELU; e.out = rows0(p, L.o_act, L.P, L.cout_ld); e.ldo = L.cout_ld; e.bias = p->buf.param + L.b_off;
-        if (i == 0) {
-            TRY(im2col_first_launch(s, dt, WS(p, p->o_x), p->Ip, L.hw, p->Bp, WS(p, L.o_col), L.kdim));
-            TRY(gemm_checked(s, dt, DMVAE_GEMM_FWD, M, L.cout_ld, L.kdim, WS(p, L.o_col), L.kdim, Wp(p, L.w_off), L.cout_ld, &e, 1));
+        if (i == 0) {   // one input channel: direct kernel, writes borders and pad channels as zeros itself
+            TRY(conv_first_fwd_launch(s, dt, WS(p, p->o_x), p->Ip, L.hw, p->Bp, Wp(p, L.w_off), L.cout_ld, p->buf.param + L.b_off, L.cout,
+                                      rows0(p, L.o_act, L.P, L.cout_ld), L.cout_ld));
         } else {
             TRY(gemm_checked(s, dt, DMVAE_GEMM_FWD, M, L.cout_ld, L.kdim, in, L.cin_ld, Wp(p, L.w_off), L.cout_ld, &e, 1, nullptr, L.P, L.cin));
+            TRY(zero_border_launch(s, dt, rows0(p, L.o_act, L.P, L.cout_ld), L.P, L.cout_ld, p->Bp));
         }
-        TRY(zero_border_launch(s, dt, rows0(p, L.o_act, L.P, L.cout_ld), L.P, L.cout_ld, p->Bp));
         in = rows0(p, L.o_act, L.P, L.cout_ld);
         if (L.pool) {
             const bool last = i + 1 == p->conv.size();
@@ -453,9 +451,7 @@ static int conv_trunk_backward(dmvae_plan* p, hipStream_t s) {
         memset(&e, 0, sizeof(e));
         e.kind = DMVAE_EPI_ATOMIC_F32; e.ldo = L.cout_ld;
         if (i == 0) {
-            e.out = p->buf.grad + L.w_off; e.out2 = p->buf.grad + L.b_off;
-            TRY(gemm_checked(s, dt, DMVAE_GEMM_DW, L.kdim, L.cout_ld, M, WS(p, L.o_col), L.kdim, dact, L.cout_ld, &e,
-                             conv_dw_split(M, (L.kdim / 64) * (L.cout_ld / 64))));
+            TRY(conv_first_dw_launch(s, dt, WS(p, p->o_x), p->Ip, L.hw, p->Bp, dact, L.cout_ld, L.cout, p->buf.grad + L.w_off, L.cout_ld, p->buf.grad + L.b_off));
             break;
         }
         const PConv& Lp = p->conv[i - 1];

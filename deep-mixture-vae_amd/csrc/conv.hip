@@ -3,8 +3,8 @@
 //
 // A 3x3 SAME stride-1 convolution in NHWC / HWIO is the GEMM  [pixels][9*Cin] x [9*Cin][Cout]; its
 // weight gradient is X_patches^T dY and its input gradient is the same convolution of dY with the
-// flipped, channel-transposed kernel.  The patch matrix is NEVER FORMED (except for the one-channel
-// first layer): activations live in HBM with a zero border, [B][P][P][C], P = side + 2, plus P + 1
+// flipped, channel-transposed kernel.  The patch matrix is NEVER FORMED (the one-channel first layer is
+// a direct kernel, 9 multiply-adds per output): activations live in HBM with a zero border, [B][P][P][C], P = side + 2, plus P + 1
 // zero guard rows on either end, and the GEMMs run over the PADDED pixel index space:
 //   * row m of the patch matrix, tap (ky,kx), is row m + (ky-1)*P + (kx-1) of the activation
 //     itself -- a wave-uniform pointer offset per K tile (GemmArgs::conv_c, gemm_epilogue.h); the
@@ -38,24 +38,115 @@ template <typename T> struct Lanes {
     __device__ __forceinline__ T& operator[](int i) { return reinterpret_cast<T*>(&v)[i]; }
 };
 
-// First layer (one input channel): explicit patch matrix over the padded pixel space,
-//   out[m][k] = x[b, y+ky-1, x+kx-1]  (k = ky*3+kx < 9, m = interior pixel (y,x) of image b), else 0.
-// x = the batch as loaded, [B][bstride] with the 784 pixels of an image contiguous.
+// 8 consecutive channels <-> 8 floats
+__device__ __forceinline__ void store8(float* p, const float v[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float v[8]) {
+    uint4 q;
+    q.x = pack2bf(v[0], v[1]); q.y = pack2bf(v[2], v[3]); q.z = pack2bf(v[4], v[5]); q.w = pack2bf(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = q;
+}
+__device__ __forceinline__ void load8(const float* p, float v[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float v[8]) {
+    const uint4 q = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
+    v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+    v[4] = __uint_as_float(q.z << 16); v[5] = __uint_as_float(q.z & 0xffff0000u);
+    v[6] = __uint_as_float(q.w << 16); v[7] = __uint_as_float(q.w & 0xffff0000u);
+}
+
+// First layer (ONE input channel, 32 outputs, base_models.py:182): 9 multiply-adds per output -- no GEMM.  Direct
+// form over the padded pixel space: out[m][co] = relu(b[co] + sum_t x[b, y+ty-1, x+tx-1] * W[t][co]) for interior
+// pixels, zero for the border rows and the 32 pad channels (the whole zero-bordered activation in one pass).
+// x = the batch as loaded, [B][bstride] with the H*H pixels of an image contiguous; W = [9][ldw], fp32 bias.
+// Thread = (pixel lane, 8 channels): its 72 weights and 8 biases live in registers across its pixels.
 template <typename T>
-__global__ __launch_bounds__(256) void im2col_first_kernel(const T* __restrict__ x, int64_t bstride, int H, int n_rows, T* __restrict__ out, int Kpad) {
-    constexpr int V = Vec16<T>::N;
-    const int P = H + 2, R = P * P, kv = Kpad / V;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)n_rows * kv; e += (int64_t)gridDim.x * 256) {
-        const int m = (int)(e / kv), k = (int)(e - (int64_t)m * kv) * V;
-        const int b = m / R, r = m - b * R, yy = r / P, xx = r - yy * P;
-        alignas(16) T v[V];
+__global__ __launch_bounds__(256) void conv_first_fwd_kernel(const T* __restrict__ x, int64_t bstride, int H, int n_rows, const T* __restrict__ W, int ldw,
+                                                             const float* __restrict__ bias, T* __restrict__ out) {
+    const int c = (threadIdx.x & 3) * 8;
+    float w[9][8], bv[8];
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            const int t = k + j, y = yy - 1 + t / 3 - 1, xq = xx - 1 + t % 3 - 1;
-            const bool live = t < 9 && yy >= 1 && yy <= H && xx >= 1 && xx <= H && y >= 0 && y < H && xq >= 0 && xq < H;
-            v[j] = live ? x[(int64_t)b * bstride + y * H + xq] : T(0);
+    for (int t = 0; t < 9; ++t) load8(W + t * ldw + c, w[t]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = bias[c + j];
+    const float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int P = H + 2, R = P * P;
+    for (int m = blockIdx.x * 64 + (threadIdx.x >> 2); m < n_rows; m += gridDim.x * 64) {
+        const int b = m / R, r = m - b * R, yy = r / P, xx = r - yy * P;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        if (yy >= 1 && yy <= H && xx >= 1 && xx <= H) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = bv[j];
+            const T* img = x + (int64_t)b * bstride;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int y = yy - 1 + t / 3 - 1, xq = xx - 1 + t % 3 - 1;
+                const float xv = (y >= 0 && y < H && xq >= 0 && xq < H) ? to_f(img[y * H + xq]) : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, w[t][j], acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
         }
-        *reinterpret_cast<typename Vec16<T>::type*>(out + (int64_t)m * Kpad + k) = *reinterpret_cast<const typename Vec16<T>::type*>(v);
+        store8(out + (int64_t)m * 64 + c, acc);
+        store8(out + (int64_t)m * 64 + 32 + c, zero);
+    }
+}
+
+// ... and its weight / bias gradient: dW[t][co] = sum over interior pixels x[pix + tap t] * dY[pix][co], db = sum dY.
+// A block walks a slab of padded rows: thread = (row lane, 8 channels) with 9 + 1 accumulators x 8 channels in
+// registers; reduced over the 16 row lanes of a wave by shuffles, over the 4 waves through LDS, then one fp32
+// atomic per (tap, channel) per block.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_first_dw_kernel(const T* __restrict__ x, int64_t bstride, int H, int n_rows, const T* __restrict__ dY,
+                                                            float* __restrict__ dW, int ldw, float* __restrict__ db, int rows_per_block) {
+    const int P = H + 2, R = P * P;
+    const int cq = threadIdx.x & 3, c = cq * 8, lane = threadIdx.x >> 2;      // 64 row lanes x 4 channel octets
+    float acc[10][8];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+    const int m_begin = blockIdx.x * rows_per_block, m_end = min(n_rows, m_begin + rows_per_block);
+    for (int m = m_begin + lane; m < m_end; m += 64) {
+        const int b = m / R, r = m - b * R, yy = r / P, xx = r - yy * P;
+        if (yy < 1 || yy > H || xx < 1 || xx > H) continue;
+        float g[8];
+        load8(dY + (int64_t)m * 64 + c, g);
+        const T* img = x + (int64_t)b * bstride;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int y = yy - 1 + t / 3 - 1, xq = xx - 1 + t % 3 - 1;
+            const float xv = (y >= 0 && y < H && xq >= 0 && xq < H) ? to_f(img[y * H + xq]) : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[t][j] = fmaf(xv, g[j], acc[t][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[9][j] += g[j];
+    }
+    __shared__ float red[4][4][80];
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[t][j];
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);      // over the 16 row lanes of this wave (lane bits 2..5)
+            if ((threadIdx.x & 63) < 4) red[wave][cq][t * 8 + j] = v;
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * 80; i += 256) {
+        const int q = i / 80, v = i % 80, t = v >> 3, co = q * 8 + (v & 7);
+        const float sum = red[0][q][v] + red[1][q][v] + red[2][q][v] + red[3][q][v];
+        atomicAdd(t < 9 ? dW + t * ldw + co : db + co, sum);
     }
 }
 
@@ -172,14 +263,28 @@ static int grid_for(int64_t n) {
 }
 static inline int esize(int dtype) { return dtype == DMVAE_BF16 ? 2 : 4; }
 
-int im2col_first_launch(hipStream_t s, int dtype, const void* x, int64_t bstride, int H, int64_t n_img, void* out, int Kpad) {
+int conv_first_fwd_launch(hipStream_t s, int dtype, const void* x, int64_t bstride, int H, int64_t n_img, const void* W, int ldw,
+                          const float* bias, int cout, void* out, int ld) {
     const int64_t n_rows = n_img * (H + 2) * (H + 2);
-    if (Kpad % 64 || n_rows >= (1ll << 31)) { set_error("im2col_first: Kpad=%d / %lld rows", Kpad, (long long)n_rows); return DMVAE_EINVAL; }
-    ProfScope ps(s, "im2col_first", 0.0, (double)n_rows * Kpad * esize(dtype));
-    const int nb = grid_for(n_rows * (Kpad / (16 / esize(dtype))));
-    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((im2col_first_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, bstride, H, (int)n_rows, (bf16_t*)out, Kpad);
-    else hipLaunchKernelGGL((im2col_first_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)x, bstride, H, (int)n_rows, (float*)out, Kpad);
-    return check_launch("im2col_first");
+    if (ld != 64 || cout != 32 || n_rows >= (1ll << 31)) { set_error("conv_first_fwd: 32 channels in a 64-channel row (ld=%d cout=%d rows=%lld)", ld, cout, (long long)n_rows); return DMVAE_EINVAL; }
+    ProfScope ps(s, "conv_first_fwd", 2.0 * n_img * H * H * 9 * cout, (double)n_rows * ld * esize(dtype));
+    const int nb = (int)std::min<int64_t>((n_rows + 63) / 64, 256 * 16);
+    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((conv_first_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, bstride, H, (int)n_rows, (const bf16_t*)W, ldw, bias, (bf16_t*)out);
+    else hipLaunchKernelGGL((conv_first_fwd_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)x, bstride, H, (int)n_rows, (const float*)W, ldw, bias, (float*)out);
+    return check_launch("conv_first_fwd");
+}
+
+// dW / db must be zero on entry (fp32 atomics, one per (tap, channel) per block)
+int conv_first_dw_launch(hipStream_t s, int dtype, const void* x, int64_t bstride, int H, int64_t n_img, const void* dY, int ld, int cout,
+                         float* dW, int ldw, float* db) {
+    const int64_t n_rows = n_img * (H + 2) * (H + 2);
+    if (ld != 64 || cout != 32 || n_rows >= (1ll << 31)) { set_error("conv_first_dw: 32 channels in a 64-channel row (ld=%d cout=%d rows=%lld)", ld, cout, (long long)n_rows); return DMVAE_EINVAL; }
+    ProfScope ps(s, "conv_first_dw", 2.0 * n_img * H * H * 9 * cout, (double)n_rows * ld * esize(dtype));
+    const int nb = (int)std::min<int64_t>(2048, (n_rows + 255) / 256);
+    const int rpb = (int)((n_rows + nb - 1) / nb);
+    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((conv_first_dw_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, bstride, H, (int)n_rows, (const bf16_t*)dY, dW, ldw, db, rpb);
+    else hipLaunchKernelGGL((conv_first_dw_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)x, bstride, H, (int)n_rows, (const float*)dY, dW, ldw, db, rpb);
+    return check_launch("conv_first_dw");
 }
 
 int zero_border_launch(hipStream_t s, int dtype, void* a, int P, int ld, int64_t n_img) {
