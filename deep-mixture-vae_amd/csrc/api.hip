@@ -158,6 +158,7 @@ struct dmvae_plan {
     bool staged = false;              // dmvae_plan_forward_backward_stage: every segment launches its own dW group
     bool split_odd_dw = false;        // DMVAE_DW_SPLIT=1: 128-aligned part + remainder strip as two dW problems (see grad_dense)
     bool overlap_dw = true;
+    bool finalize_rides = true;       // DMVAE_FINALIZE_INLINE=1: step_finalize as its own launch (A/B)
 };
 
 static void add_tensor(dmvae_plan* p, const std::string& name, int64_t off, int rows, int cols, int64_t ld) {
@@ -349,6 +350,7 @@ extern "C" int dmvae_plan_bind(dmvae_plan* p, const dmvae_buffers* b) {
     }
     p->overlap_dw = getenv("DMVAE_DW_OVERLAP") != nullptr;
     p->split_odd_dw = getenv("DMVAE_DW_SPLIT") != nullptr;
+    p->finalize_rides = getenv("DMVAE_FINALIZE_INLINE") == nullptr;
     return 0;
 }
 
@@ -642,6 +644,16 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     const bool all = stage < 0;
     p->staged = !all;
     const int nd = (int)p->dec.size(), ne = (int)p->enc.size();
+    // Loss scalars, Adam t / lr_t and the prior-table gradients need only the forward partials.  Whole pass, bf16:
+    // the 1 + 80 blocks of step_finalize ride as extra workgroups of the grouped heads-dX launch further down (one
+    // kernel boundary less); staged (data parallel: the prior tables belong to this segment's bucket) and f32: a
+    // launch of their own, here.  MEASURED earlier: as a side BRANCH of the graph (fork / join events) the step
+    // took 0.344 ms against 0.326 ms -- a second branch costs more than the launch it hides.
+    const int KD2 = 2 * c.n_classes * c.latent_dim;
+    const dmvae_finalize_args fin = step_finalize_args(reinterpret_cast<float*>(WS(p, p->o_rpart)), p->n_rpart, reinterpret_cast<float*>(WS(p, p->o_lpart)),
+                                                       p->n_lblk, inv_B, p->buf.state, 1, c.beta1, c.beta2,
+                                                       reinterpret_cast<float*>(WS(p, p->o_dprior)), p->n_lblk, KD2, p->buf.grad + p->prior_off);
+    const bool fin_rides = all && dt == DMVAE_BF16 && p->finalize_rides;
   if (all || stage == 0) {
     p->dw_queue.clear();
     TRY(encode_impl(p, s));
@@ -678,15 +690,8 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
         TRY(gemm_checked(s, dt, DMVAE_GEMM_FWD, p->Bp, p->Ip, p->dec[nd - 1].out_pad, WS(p, p->o_dec[nd - 1]), p->dec[nd - 1].out_pad,
                          Wp(p, L.w_off), L.ldw, &e, 1));
     }
-    {   // Loss scalars + prior-table gradients need only the forward partials: ONE launch (was three).
-        // MEASURED: as a side branch beside the backward GEMMs (fork / join events in the captured
-        // graph) the step took 0.344 ms against 0.326 ms -- a second branch costs more than the
-        // launch it hides -- so it stays in line on the main stream.
-        const int KD2 = 2 * c.n_classes * c.latent_dim;
-        TRY(step_finalize_launch(s, reinterpret_cast<float*>(WS(p, p->o_rpart)), p->n_rpart, reinterpret_cast<float*>(WS(p, p->o_lpart)),
-                                 p->n_lblk, inv_B, p->buf.state, 1, c.beta1, c.beta2, reinterpret_cast<float*>(WS(p, p->o_dprior)), p->n_lblk, KD2,
-                                 p->buf.grad + p->prior_off));
-    }
+    if (!fin_rides)
+        TRY(step_finalize_launch(s, fin.rp, fin.nr, fin.lp, fin.nl, inv_B, p->buf.state, 1, c.beta1, c.beta2, fin.part, fin.nblk, fin.ncol, fin.gout));
     // ---- backward: decoder
     TRY(grad_dense(p, s, WS(p, p->o_dec[nd - 1]), p->dec[nd - 1].out_pad, p->dec[nd - 1].out_pad, WS(p, p->o_dl), p->Ip, p->Ip,
                    p->out.w_off, p->out.ldw, p->out.b_off));
@@ -721,7 +726,7 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
                      grp ? &q[0] : nullptr));
         TRY(dx_dense(p, s, WS(p, p->o_dlg), p->Kp, p->Kp, p->lg.w_off, p->lg.ldw, p->Hp, act_off(p, p->o_hzc, p->Hp), 2 * p->Hp,
                      const_cast<void*>(act_off(p, p->o_dhzc, p->Hp)), 2 * p->Hp, grp ? &q[1] : nullptr));
-        if (grp) TRY(gemm_bf16_grouped(s, DMVAE_GEMM_DX, q, 2));
+        if (grp) TRY(gemm_bf16_grouped(s, DMVAE_GEMM_DX, q, 2, fin_rides ? &fin : nullptr));
     }
     // ---- backward: trunk
     TRY(grad_dense(p, s, WS(p, p->o_enc[ne - 1]), p->Tp, p->Tp, WS(p, p->o_dhzc), 2 * p->Hp, 2 * p->Hp, p->zc.w_off, p->zc.ldw, p->zc.b_off));

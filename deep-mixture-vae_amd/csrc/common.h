@@ -75,6 +75,58 @@ __device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 float
     return r;
 }
 
+// step_finalize (elementwise.hip) as a device function, so that its 1 + ceil(ncol/16) blocks can also ride
+// as extra workgroups of another launch of the step (the grouped heads-dX GEMM): saves a kernel boundary.
+struct dmvae_finalize_args {
+    const float* rp; int nr;          // reconstruction-loss partials
+    const float* lp; int nl;          // latent kernel partials {kl_z, kl_c} per block
+    float inv_B; dmvae_state* st; int bump_adam; float b1, b2;
+    const float* part; int nblk, ncol; float* gout;      // prior-table gradient partials [nblk][ncol] -> gout[ncol]
+    int nblocks;                      // 1 + ceil(ncol / 16)
+};
+// block 0 = loss scalars, epoch accumulators, Adam t / lr_t, batch cursor;  blocks 1.. = the prior-table
+// gradients summed in a FIXED order: 16 row groups x 16 columns per block, each thread adds its rows in ascending
+// order, then the 16 groups are added in ascending order.  256 threads; red = 16 x 17 floats of LDS.
+__device__ __forceinline__ void step_finalize_block(const int blk, const dmvae_finalize_args& f, float (*red)[17]) {
+    if (blk == 0) {
+        float a = 0.f, z = 0.f, c = 0.f;
+        for (int i = threadIdx.x; i < f.nr; i += 256) a += f.rp[i];
+        for (int i = threadIdx.x; i < f.nl; i += 256) { z += f.lp[2 * i]; c += f.lp[2 * i + 1]; }
+        float* r4 = &red[0][0];
+        const float recon = block_sum_256(a, r4) * f.inv_B;
+        const float klz = block_sum_256(z, r4) * f.inv_B;
+        const float klc = block_sum_256(c, r4) * f.inv_B;
+        if (threadIdx.x == 0) {
+            dmvae_state* st = f.st;
+            const float loss = recon + st->kl_ratio * (klc + klz);
+            st->last_loss = loss; st->last_recon = recon; st->last_klz = klz; st->last_klc = klc;
+            st->epoch_loss += loss * st->epoch_weight;
+            st->epoch_recon += recon * st->epoch_weight;
+            st->epoch_klz += klz * st->epoch_weight;
+            st->epoch_klc += klc * st->epoch_weight;
+            st->noise_step += 1;
+            if (f.bump_adam) {     // the update of this step (stand-alone or fused into the dW launch) uses t = adam_t
+                st->adam_t += 1;
+                st->lr_t = adam_lr_t(st->lr, f.b1, f.b2, st->adam_t);
+            }
+            st->batch_cursor = (st->batches_per_epoch > 0) ? (st->batch_cursor + 1) % st->batches_per_epoch : 0;
+        }
+        return;
+    }
+    const int col = (blk - 1) * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;
+    float s = 0.f;
+    if (col < f.ncol)
+        for (int r = rg; r < f.nblk; r += 16) s += f.part[(int64_t)r * f.ncol + col];
+    red[rg][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && col < f.ncol) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
+        f.gout[col] = t;
+    }
+}
+
 // Fixed-order block sum over NW waves; result valid in thread 0.
 template <int NW>
 __device__ __forceinline__ float block_sum_waves(float v, float* red /* >= NW floats LDS */) {

@@ -203,51 +203,22 @@ int loss_finalize_launch(hipStream_t s, const float* rp, int nr, const float* lp
 // blocks 1.. = the prior-table gradients, d/d(prior) = sum over the latent kernel's blocks of
 // their partials [nblk][ncol], summed in a FIXED order: 16 row groups x 16 columns per block, each
 // thread adds its rows in ascending order, then the 16 groups are added in ascending order.
-__global__ __launch_bounds__(256) void step_finalize_kernel(const float* rp, int nr, const float* lp, int nl, float inv_B, dmvae_state* st,
-                                                            int bump_adam, float b1, float b2, const float* part, int nblk, int ncol, float* gout) {
+__global__ __launch_bounds__(256) void step_finalize_kernel(dmvae_finalize_args f) {
     __shared__ float red[16][17];
-    if (blockIdx.x == 0) {
-        float a = 0.f, z = 0.f, c = 0.f;
-        for (int i = threadIdx.x; i < nr; i += 256) a += rp[i];
-        for (int i = threadIdx.x; i < nl; i += 256) { z += lp[2 * i]; c += lp[2 * i + 1]; }
-        float* r4 = &red[0][0];
-        const float recon = block_sum_256(a, r4) * inv_B;
-        const float klz = block_sum_256(z, r4) * inv_B;
-        const float klc = block_sum_256(c, r4) * inv_B;
-        if (threadIdx.x == 0) {
-            const float loss = recon + st->kl_ratio * (klc + klz);
-            st->last_loss = loss; st->last_recon = recon; st->last_klz = klz; st->last_klc = klc;
-            st->epoch_loss += loss * st->epoch_weight;
-            st->epoch_recon += recon * st->epoch_weight;
-            st->epoch_klz += klz * st->epoch_weight;
-            st->epoch_klc += klc * st->epoch_weight;
-            st->noise_step += 1;
-            if (bump_adam) {     // the update of this step (stand-alone or fused into the dW launch) uses t = adam_t
-                st->adam_t += 1;
-                st->lr_t = adam_lr_t(st->lr, b1, b2, st->adam_t);
-            }
-            st->batch_cursor = (st->batches_per_epoch > 0) ? (st->batch_cursor + 1) % st->batches_per_epoch : 0;
-        }
-        return;
-    }
-    const int col = (blockIdx.x - 1) * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;
-    float s = 0.f;
-    if (col < ncol)
-        for (int r = rg; r < nblk; r += 16) s += part[(int64_t)r * ncol + col];
-    red[rg][threadIdx.x & 15] = s;
-    __syncthreads();
-    if (threadIdx.x < 16 && col < ncol) {
-        float t = 0.f;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
-        gout[col] = t;
-    }
+    step_finalize_block((int)blockIdx.x, f, red);
+}
+dmvae_finalize_args step_finalize_args(const float* rp, int nr, const float* lp, int nl, float inv_B, void* st, int bump_adam,
+                                       float b1, float b2, const float* part, int nblk, int ncol, float* gout) {
+    dmvae_finalize_args f;
+    f.rp = rp; f.nr = nr; f.lp = lp; f.nl = nl; f.inv_B = inv_B; f.st = reinterpret_cast<dmvae_state*>(st); f.bump_adam = bump_adam;
+    f.b1 = b1; f.b2 = b2; f.part = part; f.nblk = nblk; f.ncol = ncol; f.gout = gout; f.nblocks = 1 + (ncol + 15) / 16;
+    return f;
 }
 int step_finalize_launch(hipStream_t s, const float* rp, int nr, const float* lp, int nl, float inv_B, void* st, int bump_adam,
                          float b1, float b2, const float* part, int nblk, int ncol, float* gout) {
     ProfScope ps(s, "step_finalize", (double)nblk * ncol, 4.0 * ((double)nblk * ncol + nr + 2.0 * nl));
-    hipLaunchKernelGGL(step_finalize_kernel, dim3(1 + (ncol + 15) / 16), dim3(256), 0, s, rp, nr, lp, nl, inv_B,
-                       reinterpret_cast<dmvae_state*>(st), bump_adam, b1, b2, part, nblk, ncol, gout);
+    const dmvae_finalize_args f = step_finalize_args(rp, nr, lp, nl, inv_B, st, bump_adam, b1, b2, part, nblk, ncol, gout);
+    hipLaunchKernelGGL(step_finalize_kernel, dim3(f.nblocks), dim3(256), 0, s, f);
     return check_launch("step_finalize");
 }
 

@@ -565,6 +565,7 @@ struct GroupedArgs {
     int cls_start[DMVAE_MAX_GROUP], cls_end[DMVAE_MAX_GROUP];
     GemmArgs p[DMVAE_MAX_GROUP];
     dmvae_adam_ctx adam;      // DMVAE_EPI_ADAM launches only
+    dmvae_finalize_args fin;  // DMVAE_EPI_RELU_MASK launches: fin.nblocks extra workgroups run step_finalize (0 = none)
 };
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void gemm_bf16_grouped_kernel(GroupedArgs g) {
@@ -589,6 +590,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_grouped_kernel(GroupedArgs 
     // each problem: an XCD then works on one or two problems with large blocks of their tiles
     // instead of an eighth of every problem, so far fewer operand panels are fetched by more
     // than one L2.  The workgroup mix per XCD / CU is unchanged (a permutation inside a class).
+    if constexpr (EPI == DMVAE_EPI_RELU_MASK) {
+        if ((int)blockIdx.x >= g.start[g.nprob]) {   // the extra workgroups: loss scalars / Adam step / prior-table gradients
+            step_finalize_block((int)blockIdx.x - g.start[g.nprob], g.fin, reinterpret_cast<float(*)[17]>(smem));
+            return;
+        }
+    }
     int i = 0;
     while (i + 1 < g.nprob && (int)blockIdx.x >= g.start[i + 1]) ++i;
     const int item = g.cls_start[i] + xcd_run_index((int)blockIdx.x, g.cls_start[i], g.cls_end[i]);
@@ -671,7 +678,7 @@ static int launch_conv(hipStream_t s, const GemmArgs& a, int split) {
 // problem = the largest shape it divides, downgraded for the whole group while the grid would
 // not give every CU a workgroup.
 template <int LAYOUT, int EPI>
-static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const dmvae_adam_ctx* ctx = nullptr) {
+static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const dmvae_adam_ctx* ctx = nullptr, const dmvae_finalize_args* fin = nullptr) {
     auto best_kind = [](const GemmArgs& p) { return (p.M % 128 == 0 && p.N % 128 == 0) ? 0 : (p.M % 128 == 0 ? 1 : 2); };
     auto tiles = [](const GemmArgs& p, int kind) { return (p.M / (kind == 2 ? 64 : 128)) * (p.N / (kind == 0 ? 128 : 64)); };
     // bytes one workgroup of this kind streams into LDS: these kernels run at the per-CU L2->LDS
@@ -757,6 +764,8 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
             lo = hi;
         }
     int extra = 0;
+    g.fin = dmvae_finalize_args{};
+    if (fin && EPI == DMVAE_EPI_RELU_MASK) { g.fin = *fin; extra = fin->nblocks; }
     g.adam = dmvae_adam_ctx{};
     if (ctx) {
         g.adam = *ctx;
@@ -774,18 +783,19 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
 
 // instantiated groups: the nine dW of a step (DW / STORE_F32), the sibling head layers
 // [mean|log_var] + logits (FWD / BIAS_F32) and their two dX (DX / RELU_MASK)
-int gemm_bf16_grouped(hipStream_t s, int layout, const GemmArgs* probs, int nprob) {
+int gemm_bf16_grouped(hipStream_t s, int layout, const GemmArgs* probs, int nprob, const dmvae_finalize_args* fin) {
     if (nprob < 1 || nprob > DMVAE_MAX_GROUP) { set_error("dmvae_gemm_grouped: 1..%d problems", DMVAE_MAX_GROUP); return DMVAE_EINVAL; }
     const int epi = probs[0].epi.kind;
     for (int i = 1; i < nprob; ++i)
         if (probs[i].epi.kind != epi) { set_error("dmvae_gemm_grouped: all problems must share the epilogue kind"); return DMVAE_EINVAL; }
     if (layout == DMVAE_GEMM_DW && epi == DMVAE_EPI_STORE_F32) return grouped_launch<DMVAE_GEMM_DW, DMVAE_EPI_STORE_F32>(s, probs, nprob);
     if (layout == DMVAE_GEMM_FWD && epi == DMVAE_EPI_BIAS_F32) return grouped_launch<DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_F32>(s, probs, nprob);
-    if (layout == DMVAE_GEMM_DX && epi == DMVAE_EPI_RELU_MASK) return grouped_launch<DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK>(s, probs, nprob);
+    if (fin && !(layout == DMVAE_GEMM_DX && epi == DMVAE_EPI_RELU_MASK)) { set_error("dmvae_gemm_grouped: step_finalize rides on DX / RELU_MASK groups only"); return DMVAE_EINVAL; }
+    if (layout == DMVAE_GEMM_DX && epi == DMVAE_EPI_RELU_MASK) return grouped_launch<DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK>(s, probs, nprob, nullptr, fin);
     set_error("dmvae_gemm_grouped: layout %d with epilogue %d is not instantiated", layout, epi);
     return DMVAE_EUNSUPPORTED;
 }
-int gemm_bf16_grouped_dw(hipStream_t s, const GemmArgs* probs, int nprob) { return gemm_bf16_grouped(s, DMVAE_GEMM_DW, probs, nprob); }
+int gemm_bf16_grouped_dw(hipStream_t s, const GemmArgs* probs, int nprob) { return gemm_bf16_grouped(s, DMVAE_GEMM_DW, probs, nprob, nullptr); }
 // the dW group with the Adam update in the epilogue (every problem's epilogue kind = DMVAE_EPI_ADAM)
 int gemm_bf16_grouped_dw_adam(hipStream_t s, const GemmArgs* probs, int nprob, const dmvae_adam_ctx& ctx) {
     if (nprob < 1 || nprob > DMVAE_MAX_GROUP) { set_error("dmvae_gemm_grouped_dw_adam: 1..%d problems", DMVAE_MAX_GROUP); return DMVAE_EINVAL; }

@@ -16,7 +16,10 @@ struct AdamArgs {
 #define DMVAE_MAX_GROUP 16
 int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split);
 int gemm_bf16_grouped_dw(hipStream_t s, const GemmArgs* probs, int nprob);
-int gemm_bf16_grouped(hipStream_t s, int layout, const GemmArgs* probs, int nprob);
+// fin: the step_finalize blocks ride as extra workgroups of this launch (DX / RELU_MASK groups only)
+int gemm_bf16_grouped(hipStream_t s, int layout, const GemmArgs* probs, int nprob, const dmvae_finalize_args* fin = nullptr);
+dmvae_finalize_args step_finalize_args(const float* rp, int nr, const float* lp, int nl, float inv_B, void* st, int bump_adam,
+                                       float b1, float b2, const float* part, int nblk, int ncol, float* gout);
 int gemm_bf16_tile_m(int M, int N, int split);
 void gemm_bf16_force_tile(int t);
 void gemm_bf16_set_knob(int which, int v);
