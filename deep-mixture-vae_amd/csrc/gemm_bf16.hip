@@ -46,6 +46,7 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "kernels.h"
@@ -667,9 +668,12 @@ static int launch(hipStream_t s, const GemmArgs& a, int split) {
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4>
 static int launch_conv(hipStream_t s, const GemmArgs& a, int split) {
     dim3 grid((a.M / BM) * (a.N / BN), split);
-    static char nm[64];
-    snprintf(nm, sizeof(nm), "gemm_bf16_conv_kernel<%d, %d, %d, %d, %d, %d>", BM, BN, LAYOUT, EPI, NSTAGE, NW);
-    ProfScope ps(s, nm, 2.0 * a.M * a.N * (double)a.K, gemm_bytes(a));
+    static const std::string nm = [] {     // (initialised once, thread-safe)
+        char b[64];
+        snprintf(b, sizeof(b), "gemm_bf16_conv_kernel<%d, %d, %d, %d, %d, %d>", BM, BN, LAYOUT, EPI, NSTAGE, NW);
+        return std::string(b);
+    }();
+    ProfScope ps(s, nm.c_str(), 2.0 * a.M * a.N * (double)a.K, gemm_bytes(a));
     hipLaunchKernelGGL((gemm_bf16_conv_kernel<BM, BN, LAYOUT, EPI, NSTAGE, NW>), grid, dim3(64 * NW), 0, s, a);
     return check_launch("gemm_bf16_conv");
 }
