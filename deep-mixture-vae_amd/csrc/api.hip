@@ -120,7 +120,8 @@ struct PLayer {
 struct PConv {
     std::string name;
     int cin, cout, hw, pool;          // channels, image side of its input = output, 2x2 SAME max-pool behind it
-    int cin_ld, cout_ld;              // channel stride of the input / output activation (pad64; the image itself: 1)
+    int cin_ld, cout_ld;              // channel stride of the input / output activation: the channel count itself (32, 64, 128; the image: 1)
+    int cin_np, cout_np;              // channels padded to 64 = N of the GEMM that produces such an activation, ld of the weight matrix
     int P;                            // hw + 2
     int kdim, ktdim;                  // K of the forward / input-gradient GEMM: 9 * cin / 9 * cout padded to 64 (first layer: an explicit 9-column patch matrix)
     int64_t w_off, b_off;             // W [kdim][cout_ld]: HWIO flattened, rows (tap, c < cin), zero pad rows / columns; b [cout_ld]
@@ -201,12 +202,12 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
             PConv L;
             L.name = "conv" + std::to_string(i);
             L.cin = spec[i][0]; L.cout = spec[i][1]; L.hw = spec[i][2]; L.pool = spec[i][3];
-            L.cin_ld = ld_in; L.cout_ld = pad64(L.cout); L.P = L.hw + 2;
+            L.cin_ld = ld_in; L.cout_ld = L.cout; L.cin_np = pad64(L.cin); L.cout_np = pad64(L.cout); L.P = L.hw + 2;
             L.kdim = pad64(9 * L.cin); L.ktdim = pad64(9 * L.cout);
-            L.w_off = off; off += (int64_t)L.kdim * L.cout_ld;
-            L.b_off = off; off += L.cout_ld;
-            add_tensor(p, "W_" + L.name, L.w_off, 9 * L.cin, L.cout, L.cout_ld);
-            add_tensor(p, "b_" + L.name, L.b_off, 1, L.cout, L.cout_ld);
+            L.w_off = off; off += (int64_t)L.kdim * L.cout_np;
+            L.b_off = off; off += L.cout_np;
+            add_tensor(p, "W_" + L.name, L.w_off, 9 * L.cin, L.cout, L.cout_np);
+            add_tensor(p, "b_" + L.name, L.b_off, 1, L.cout, L.cout_np);
             p->conv.push_back(L);
             ld_in = L.cout_ld;
         }
@@ -272,7 +273,7 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
             const bool last = i + 1 == p->conv.size();
             L.o_pool = L.pool ? (last ? take(Bp * ho * ho * L.cout_ld * es) : bordered(ho + 2, L.cout_ld)) : 0;
             L.o_dpool = (L.pool && !last) ? bordered(ho + 2, L.cout_ld) : 0;
-            if (i > 0) wmax = std::max<int64_t>(wmax, (int64_t)L.cin_ld * L.ktdim);
+            if (i > 0) wmax = std::max<int64_t>(wmax, (int64_t)L.cin_np * L.ktdim);
         }
         if (!p->conv.empty()) {
             p->o_wt = take(wmax * es);
@@ -398,11 +399,12 @@ static int conv_trunk_forward(dmvae_plan* p, hipStream_t s, const void** flat) {
         dmvae_epilogue e;
         memset(&e, 0, sizeof(e));
         e.kind = DMVAE_EPI_BIAS_RELU; e.out = rows0(p, L.o_act, L.P, L.cout_ld); e.ldo = L.cout_ld; e.bias = p->buf.param + L.b_off;
-        if (i == 0) {   // one input channel: direct kernel, writes borders and pad channels as zeros itself
-            TRY(conv_first_fwd_launch(s, dt, WS(p, p->o_x), p->Ip, L.hw, p->Bp, Wp(p, L.w_off), L.cout_ld, p->buf.param + L.b_off, L.cout,
+        e.n_valid = L.cout;                          // a 32-channel output is stored 32 wide: the GEMM's other 32 columns are dropped
+        if (i == 0) {   // one input channel: direct kernel, writes the border rows as zeros itself
+            TRY(conv_first_fwd_launch(s, dt, WS(p, p->o_x), p->Ip, L.hw, p->Bp, Wp(p, L.w_off), L.cout_np, p->buf.param + L.b_off, L.cout,
                                       rows0(p, L.o_act, L.P, L.cout_ld), L.cout_ld));
         } else {
-            TRY(gemm_checked(s, dt, DMVAE_GEMM_FWD, M, L.cout_ld, L.kdim, in, L.cin_ld, Wp(p, L.w_off), L.cout_ld, &e, 1, nullptr, L.P, L.cin));
+            TRY(gemm_checked(s, dt, DMVAE_GEMM_FWD, M, L.cout_np, L.kdim, in, L.cin_ld, Wp(p, L.w_off), L.cout_np, &e, 1, nullptr, L.P, L.cin));
             TRY(zero_border_launch(s, dt, rows0(p, L.o_act, L.P, L.cout_ld), L.P, L.cout_ld, p->Bp));
         }
         in = rows0(p, L.o_act, L.P, L.cout_ld);
@@ -451,25 +453,25 @@ static int conv_trunk_backward(dmvae_plan* p, hipStream_t s) {
         }
         dmvae_epilogue e;
         memset(&e, 0, sizeof(e));
-        e.kind = DMVAE_EPI_ATOMIC_F32; e.ldo = L.cout_ld;
+        e.kind = DMVAE_EPI_ATOMIC_F32; e.ldo = L.cout_np; e.n_valid = L.cout;
         if (i == 0) {
-            TRY(conv_first_dw_launch(s, dt, WS(p, p->o_x), p->Ip, L.hw, p->Bp, dact, L.cout_ld, L.cout, p->buf.grad + L.w_off, L.cout_ld, p->buf.grad + L.b_off));
+            TRY(conv_first_dw_launch(s, dt, WS(p, p->o_x), p->Ip, L.hw, p->Bp, dact, L.cout_ld, L.cout, p->buf.grad + L.w_off, L.cout_np, p->buf.grad + L.b_off));
             break;
         }
         const PConv& Lp = p->conv[i - 1];
         const char* in = Lp.pool ? rows0(p, Lp.o_pool, L.P, L.cin_ld) : rows0(p, Lp.o_act, L.P, L.cin_ld);
         e.out = p->buf.grad + L.w_off; e.out2 = p->buf.grad + L.b_off;
-        TRY(gemm_checked(s, dt, DMVAE_GEMM_DW, L.kdim, L.cout_ld, M, in, L.cin_ld, dact, L.cout_ld, &e,
-                         conv_dw_split(M, (L.kdim / 64) * (L.cout_ld / 64)), nullptr, L.P, L.cin));
+        TRY(gemm_checked(s, dt, DMVAE_GEMM_DW, L.kdim, L.cout_np, M, in, L.cin_ld, dact, L.cout_ld, &e,
+                         conv_dw_split(M, (L.kdim / 64) * (L.cout_np / 64)), nullptr, L.P, L.cin));
         if (L.kdim > 9 * L.cin) {   // rows past the ninth tap are padding: the GEMM filled them with a copy of tap 8
-            me = hipMemsetAsync(p->buf.grad + L.w_off + (int64_t)9 * L.cin * L.cout_ld, 0, (size_t)(L.kdim - 9 * L.cin) * L.cout_ld * 4, s);
+            me = hipMemsetAsync(p->buf.grad + L.w_off + (int64_t)9 * L.cin * L.cout_np, 0, (size_t)(L.kdim - 9 * L.cin) * L.cout_np * 4, s);
             if (me != hipSuccess) { set_error("conv gradient pad memset: %s", hipGetErrorString(me)); return (int)me; }
         }
-        TRY(conv_wflip_launch(s, dt, Wp(p, L.w_off), L.cin, L.cin_ld, L.cout, L.cout_ld, WS(p, p->o_wt), L.ktdim));
+        TRY(conv_wflip_launch(s, dt, Wp(p, L.w_off), L.cin, L.cin_np, L.cout, L.cout_np, WS(p, p->o_wt), L.ktdim));
         memset(&e, 0, sizeof(e));
-        e.kind = DMVAE_EPI_RELU_MASK; e.ldo = L.cin_ld; e.aux0 = in; e.ld0 = L.cin_ld;
+        e.kind = DMVAE_EPI_RELU_MASK; e.ldo = L.cin_ld; e.aux0 = in; e.ld0 = L.cin_ld; e.n_valid = L.cin;
         e.out = Lp.pool ? rows0(p, Lp.o_dpool, L.P, L.cin_ld) : rows0(p, Lp.o_dact, L.P, L.cin_ld);
-        TRY(gemm_checked(s, dt, DMVAE_GEMM_DX, M, L.cin_ld, L.ktdim, dact, L.cout_ld, WS(p, p->o_wt), L.ktdim, &e, 1, nullptr, L.P, L.cout));
+        TRY(gemm_checked(s, dt, DMVAE_GEMM_DX, M, L.cin_np, L.ktdim, dact, L.cout_ld, WS(p, p->o_wt), L.ktdim, &e, 1, nullptr, L.P, L.cout));
     }
     return 0;
 }

@@ -17,8 +17,9 @@
 // (9x the activation bytes) is written or read.  K counts the REAL channels: a 32-channel layer (stored
 // with 32 zero pad channels) puts two taps into one 64-wide K tile.
 //
-// T is the activation type of the plan (float in parity mode, bf16 otherwise); channel strides are
-// multiples of 64 (32-channel layers carry 32 zero channels).
+// T is the activation type of the plan (float in parity mode, bf16 otherwise); an activation is stored
+// exactly as wide as its channel count (32, 64, 128): a GEMM that produces 32 channels runs a 64-wide N tile
+// and drops the other columns in its epilogue (dmvae_epilogue::n_valid).
 #include <algorithm>
 #include "common.h"
 #include "kernels.h"
@@ -67,7 +68,7 @@ __device__ __forceinline__ void load8(const bf16_t* p, float v[8]) {
 // Thread = (pixel lane, 8 channels): its 72 weights and 8 biases live in registers across its pixels.
 template <typename T>
 __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const T* __restrict__ x, int64_t bstride, int H, int n_rows, const T* __restrict__ W, int ldw,
-                                                             const float* __restrict__ bias, T* __restrict__ out) {
+                                                             const float* __restrict__ bias, T* __restrict__ out, int ld) {
     const int c = (threadIdx.x & 3) * 8;
     float w[9][8], bv[8];
 #pragma unroll
@@ -95,8 +96,8 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const T* __restrict
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
         }
-        store8(out + (int64_t)m * 64 + c, acc);
-        store8(out + (int64_t)m * 64 + 32 + c, zero);
+        store8(out + (int64_t)m * ld + c, acc);
+        if (ld == 64) store8(out + (int64_t)m * ld + 32 + c, zero);       // rows stored 64 wide carry 32 zero pad channels
     }
 }
 
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const T* __restrict
 // atomic per (tap, channel) per block.
 template <typename T>
 __global__ __launch_bounds__(256) void conv_first_dw_kernel(const T* __restrict__ x, int64_t bstride, int H, int n_rows, const T* __restrict__ dY,
-                                                            float* __restrict__ dW, int ldw, float* __restrict__ db, int rows_per_block) {
+                                                            float* __restrict__ dW, int ldw, float* __restrict__ db, int rows_per_block, int ld) {
     const int P = H + 2, R = P * P;
     const int cq = threadIdx.x & 3, c = cq * 8, lane = threadIdx.x >> 2;      // 64 row lanes x 4 channel octets
     float acc[10][8];
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void conv_first_dw_kernel(const T* __restrict_
         const int b = m / R, r = m - b * R, yy = r / P, xx = r - yy * P;
         if (yy < 1 || yy > H || xx < 1 || xx > H) continue;
         float g[8];
-        load8(dY + (int64_t)m * 64 + c, g);
+        load8(dY + (int64_t)m * ld + c, g);
         const T* img = x + (int64_t)b * bstride;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -266,11 +267,11 @@ static inline int esize(int dtype) { return dtype == DMVAE_BF16 ? 2 : 4; }
 int conv_first_fwd_launch(hipStream_t s, int dtype, const void* x, int64_t bstride, int H, int64_t n_img, const void* W, int ldw,
                           const float* bias, int cout, void* out, int ld) {
     const int64_t n_rows = n_img * (H + 2) * (H + 2);
-    if (ld != 64 || cout != 32 || n_rows >= (1ll << 31)) { set_error("conv_first_fwd: 32 channels in a 64-channel row (ld=%d cout=%d rows=%lld)", ld, cout, (long long)n_rows); return DMVAE_EINVAL; }
+    if ((ld != 32 && ld != 64) || cout != 32 || n_rows >= (1ll << 31)) { set_error("conv_first_fwd: 32 channels in rows of 32 or 64 (ld=%d cout=%d rows=%lld)", ld, cout, (long long)n_rows); return DMVAE_EINVAL; }
     ProfScope ps(s, "conv_first_fwd", 2.0 * n_img * H * H * 9 * cout, (double)n_rows * ld * esize(dtype));
     const int nb = (int)std::min<int64_t>((n_rows + 63) / 64, 256 * 16);
-    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((conv_first_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, bstride, H, (int)n_rows, (const bf16_t*)W, ldw, bias, (bf16_t*)out);
-    else hipLaunchKernelGGL((conv_first_fwd_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)x, bstride, H, (int)n_rows, (const float*)W, ldw, bias, (float*)out);
+    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((conv_first_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, bstride, H, (int)n_rows, (const bf16_t*)W, ldw, bias, (bf16_t*)out, ld);
+    else hipLaunchKernelGGL((conv_first_fwd_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)x, bstride, H, (int)n_rows, (const float*)W, ldw, bias, (float*)out, ld);
     return check_launch("conv_first_fwd");
 }
 
@@ -278,17 +279,17 @@ int conv_first_fwd_launch(hipStream_t s, int dtype, const void* x, int64_t bstri
 int conv_first_dw_launch(hipStream_t s, int dtype, const void* x, int64_t bstride, int H, int64_t n_img, const void* dY, int ld, int cout,
                          float* dW, int ldw, float* db) {
     const int64_t n_rows = n_img * (H + 2) * (H + 2);
-    if (ld != 64 || cout != 32 || n_rows >= (1ll << 31)) { set_error("conv_first_dw: 32 channels in a 64-channel row (ld=%d cout=%d rows=%lld)", ld, cout, (long long)n_rows); return DMVAE_EINVAL; }
+    if ((ld != 32 && ld != 64) || cout != 32 || n_rows >= (1ll << 31)) { set_error("conv_first_dw: 32 channels in rows of 32 or 64 (ld=%d cout=%d rows=%lld)", ld, cout, (long long)n_rows); return DMVAE_EINVAL; }
     ProfScope ps(s, "conv_first_dw", 2.0 * n_img * H * H * 9 * cout, (double)n_rows * ld * esize(dtype));
     const int nb = (int)std::min<int64_t>(2048, (n_rows + 255) / 256);
     const int rpb = (int)((n_rows + nb - 1) / nb);
-    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((conv_first_dw_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, bstride, H, (int)n_rows, (const bf16_t*)dY, dW, ldw, db, rpb);
-    else hipLaunchKernelGGL((conv_first_dw_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)x, bstride, H, (int)n_rows, (const float*)dY, dW, ldw, db, rpb);
+    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((conv_first_dw_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, bstride, H, (int)n_rows, (const bf16_t*)dY, dW, ldw, db, rpb, ld);
+    else hipLaunchKernelGGL((conv_first_dw_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)x, bstride, H, (int)n_rows, (const float*)dY, dW, ldw, db, rpb, ld);
     return check_launch("conv_first_dw");
 }
 
 int zero_border_launch(hipStream_t s, int dtype, void* a, int P, int ld, int64_t n_img) {
-    if (ld % 64) { set_error("zero_border: channel stride %d must be a multiple of 64", ld); return DMVAE_EINVAL; }
+    if (ld % 32) { set_error("zero_border: channel stride %d must be a multiple of 32", ld); return DMVAE_EINVAL; }
     const int64_t n = n_img * (4 * P - 4) * (ld / (16 / esize(dtype)));
     ProfScope ps(s, "zero_border", 0.0, (double)n * 16);
     if (dtype == DMVAE_BF16) hipLaunchKernelGGL((zero_border_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (bf16_t*)a, P, ld, n_img);
@@ -299,7 +300,7 @@ int zero_border_launch(hipStream_t s, int dtype, void* a, int P, int ld, int64_t
 int maxpool2_fwd_launch(hipStream_t s, int dtype, const void* in, int H, int ld, int64_t n_img, void* out, int out_border) {
     const int Ho = (H + 1) / 2;
     const int64_t n_win = n_img * Ho * Ho;
-    if (ld % 64) { set_error("maxpool2: channel stride %d must be a multiple of 64", ld); return DMVAE_EINVAL; }
+    if (ld % 32) { set_error("maxpool2: channel stride %d must be a multiple of 32", ld); return DMVAE_EINVAL; }
     ProfScope ps(s, "maxpool2_fwd", 0.0, ((double)n_img * H * H + n_win) * ld * esize(dtype));
     const int nb = grid_for(n_win * (ld / (16 / esize(dtype))));
     if (dtype == DMVAE_BF16) hipLaunchKernelGGL((maxpool2_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)in, H, ld, n_win, (bf16_t*)out, out_border);
@@ -310,7 +311,7 @@ int maxpool2_fwd_launch(hipStream_t s, int dtype, const void* in, int H, int ld,
 int maxpool2_bwd_relu_launch(hipStream_t s, int dtype, const void* in, const void* dout, int H, int ld, int64_t n_img, void* din, int dout_border) {
     const int Ho = (H + 1) / 2;
     const int64_t n_win = n_img * Ho * Ho;
-    if (ld % 64) { set_error("maxpool2: channel stride %d must be a multiple of 64", ld); return DMVAE_EINVAL; }
+    if (ld % 32) { set_error("maxpool2: channel stride %d must be a multiple of 32", ld); return DMVAE_EINVAL; }
     ProfScope ps(s, "maxpool2_bwd_relu", 0.0, (2.0 * n_img * H * H + n_win) * ld * esize(dtype));
     const int nb = grid_for(n_win * (ld / (16 / esize(dtype))));
     if (dtype == DMVAE_BF16) hipLaunchKernelGGL((maxpool2_bwd_relu_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)in, (const bf16_t*)dout, H, ld, n_win, (bf16_t*)din, dout_border);

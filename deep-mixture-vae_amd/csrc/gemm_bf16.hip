@@ -471,6 +471,9 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     for (int q = 0; q < BM * CH / NT; ++q) {
         const int idx = q * NT + tid;
         const int ml = idx / CH, c = idx % CH;
+        if constexpr (CONV) {     // a 32-channel activation is stored 32 wide: the tile's other columns are not part of the output
+            if (n0 + c * 4 >= a.epi.n_valid) continue;
+        }
         const f32x4 t = *reinterpret_cast<const f32x4*>(ct + ml * BN + ((c ^ (ml & 7)) << 2));
         float v[4] = {t[0], t[1], t[2], t[3]};
         if constexpr (EPI == DMVAE_EPI_ADAM) {
@@ -503,6 +506,9 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn * (BN / 2) + j * 16 + g * 4;
+                if constexpr (CONV) {
+                    if (n >= a.epi.n_valid) continue;
+                }
                 if constexpr (EPI == DMVAE_EPI_ATOMIC_F32) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) atomicAdd(db + n + e, bacc[j][e]);

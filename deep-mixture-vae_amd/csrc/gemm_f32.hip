@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
             const int m = m0 + wm * 32 + i * 16 + li;
             const int n = n0 + wn * 32 + j * 16 + g * 4;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (a.conv_c && n >= a.epi.n_valid) continue;      // conv mode: a 32-channel activation is stored 32 wide
             epilogue_quad<EPI, float>(a.epi, m, n, v, loss);
         }
     if constexpr (DW) {
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = n0 + wn * 32 + j * 16 + g * 4;
+                if (a.conv_c && n >= a.epi.n_valid) continue;
                 if constexpr (EPI == DMVAE_EPI_ATOMIC_F32) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) atomicAdd(db + n + e, bacc[j][e]);

@@ -259,10 +259,11 @@ def test_cnn_model_trains_through_the_reference_surface():
     eng = model.engine
     assert eng.cnn and eng.enc_layers == (500,) and eng.tensors["W_conv0"][1:3] == (9, 32)
     data = Dataset((X, y), batch_size=128)
-    model.define_train_step(0.002, data.epoch_len * 10)
-    losses = [model.train_op(None, data, 1.0) for _ in range(4)]
-    # (Adam at the CLI's 0.002 on four batches of 128 is not monotone from epoch to epoch)
-    assert np.isfinite(losses).all() and min(losses[1:]) < 0.9 * losses[0], losses
+    # Adam at the CLI's 0.002 on four batches of 128 sits at the edge of stability for this 8-layer encoder (the
+    # epoch loss can jump, in fp32 and bf16 alike: tools/cnn_surface_probe.py); a quarter of it descends steadily
+    model.define_train_step(0.0005, data.epoch_len * 10)
+    losses = [model.train_op(None, data, 1.0) for _ in range(5)]
+    assert np.isfinite(losses).all() and losses[-1] < 0.9 * losses[0] and max(losses) <= 1.02 * losses[0], losses
     acc = model.get_accuracy(None, Dataset((X, y), batch_size=128))
     assert 0.0 <= acc <= 1.0
 
