@@ -643,6 +643,7 @@ static int auto_group_m(int tiles_m, int tiles_n, int bm, int bn, double run = 0
     gm = std::max(gm, need);
     return std::max(1, std::min(gm, tiles_m));
 }
+static int g_conv_short = 1;                // tuning knob (dmvae_debug_set_knob 5): short-K conv tiles as 4-wave / 2-slot workgroups
 static int g_grouped_cls = 1;               // tuning knob (dmvae_debug_set_knob 4): XCD runs cut per tile-shape class (1) or per problem (0)
 static int g_grouped_mixed = 1;             // tuning knob (dmvae_debug_set_knob 2): 0 all 64x64, 1 planned per-problem tiles, 2 largest tile each shape divides
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4>
@@ -828,6 +829,7 @@ void gemm_bf16_set_knob(int which, int v) {
     if (which == 2) g_grouped_mixed = v;
     if (which == 3) g_deep = v;
     if (which == 4) g_grouped_cls = v;
+    if (which == 5) g_conv_short = v;
 }
 
 // Tile choice, BM*1000+BN.  These GEMMs run at the per-CU L2->LDS streaming rate, so the figure
@@ -871,7 +873,10 @@ static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split) {
             } else {
                 switch (t) {
                     case 128128: return launch_conv<128, 128, LAYOUT, EPI, 2, 8>(s, a, split);
-                    case 128064: return launch_conv<128, 64, LAYOUT, EPI, 3, 8>(s, a, split);
+                    case 128064:
+                        // short K (the 32-channel layers: 5 K tiles): a 2-slot ring and 4 waves -> three workgroups per CU
+                        if (a.K <= 640 && g_conv_short) return launch_conv<128, 64, LAYOUT, EPI, 2, 4>(s, a, split);
+                        return launch_conv<128, 64, LAYOUT, EPI, 3, 8>(s, a, split);
                     case 64128: return launch_conv<64, 128, LAYOUT, EPI, 3>(s, a, split);
                     default: return launch_conv<64, 64, LAYOUT, EPI, 4>(s, a, split);
                 }
