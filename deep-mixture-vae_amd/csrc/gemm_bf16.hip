@@ -643,7 +643,7 @@ static int auto_group_m(int tiles_m, int tiles_n, int bm, int bn, double run = 0
     gm = std::max(gm, need);
     return std::max(1, std::min(gm, tiles_m));
 }
-static int g_conv_short = 1;                // tuning knob (dmvae_debug_set_knob 5): short-K conv tiles as 4-wave / 2-slot workgroups
+static int g_conv_short = 2;                // tuning knob (dmvae_debug_set_knob 5): >= 1 short-K conv tiles as 4-wave / 2-slot workgroups, 2 also 3-slot rings for the 64x64 weight-gradient tiles (tools/cnn_knob.py: 3.539 / 3.290 / 3.270 ms)
 static int g_grouped_cls = 1;               // tuning knob (dmvae_debug_set_knob 4): XCD runs cut per tile-shape class (1) or per problem (0)
 static int g_grouped_mixed = 1;             // tuning knob (dmvae_debug_set_knob 2): 0 all 64x64, 1 planned per-problem tiles, 2 largest tile each shape divides
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4>
@@ -869,6 +869,7 @@ static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split) {
             a.group_m = auto_group_m(a.M / (t / 1000), a.N / (t % 1000), t / 1000, t % 1000);
             if constexpr (LAYOUT == DMVAE_GEMM_DW) {
                 if (t == 64128) return launch_conv<64, 128, LAYOUT, EPI, 3>(s, a, split);
+                if (g_conv_short == 2) return launch_conv<64, 64, LAYOUT, EPI, 3>(s, a, split);     // 48 KiB ring -> three workgroups per CU
                 return launch_conv<64, 64, LAYOUT, EPI, 4>(s, a, split);
             } else {
                 switch (t) {
