@@ -358,7 +358,8 @@ int dmvae_debug_set_tile(int bm, int bn);
  *             knob 2 = per-problem tile shapes in the grouped dW grid (0 = all 64x64, 1 = planned, 2 = largest),
  *             knob 3 = ring depth policy (-1 deep ring when <= 1 workgroup per CU, 0 never, 1 always),
  *             knob 4 = XCD runs of a grouped grid cut per tile-shape class (1) or per problem (0),
- *             knob 5 = short-K conv-mode tiles as 4-wave / 2-slot workgroups, three per CU (1) */
+ *             knob 5 = conv-mode tiles: >= 1 short-K tiles as 4-wave / 2-slot workgroups (three per CU),
+ *                      2 also 3-slot rings for the 64x64 weight-gradient tiles */
 int dmvae_debug_set_knob(int which, int value);
 
 int dmvae_abi_version(void);
