@@ -133,7 +133,7 @@ struct dmvae_plan {
     dmvae_config cfg;
     std::vector<PConv> conv;          // cfg.trunk == DMVAE_TRUNK_CNN only
     int flat = 0;                     // 4*4*128 = 2048: width of the flattened pool output feeding enc0
-    int64_t o_dflat = 0, o_wt = 0;
+    int64_t o_dflat = 0, o_wt = 0, o_c0part = 0;
     int64_t conv_param_end = 0;
     int Bp, Ip, Dp, Kp, Hp, Tp;   // padded batch / input / latent / classes / head / trunk
     int es;                        // bytes per activation element
@@ -278,6 +278,7 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
         if (!p->conv.empty()) {
             p->o_wt = take(wmax * es);
             p->o_dflat = take(Bp * p->flat * es);
+            p->o_c0part = take((int64_t)conv_first_dw_blocks(p->conv.front().hw, Bp) * 320 * 4);
         }
     }
     for (auto& L : p->enc) p->o_enc.push_back(take(Bp * L.out_pad * es));
@@ -455,7 +456,8 @@ static int conv_trunk_backward(dmvae_plan* p, hipStream_t s) {
         memset(&e, 0, sizeof(e));
         e.kind = DMVAE_EPI_ATOMIC_F32; e.ldo = L.cout_np; e.n_valid = L.cout;
         if (i == 0) {
-            TRY(conv_first_dw_launch(s, dt, WS(p, p->o_x), p->Ip, L.hw, p->Bp, dact, L.cout_ld, L.cout, p->buf.grad + L.w_off, L.cout_np, p->buf.grad + L.b_off));
+            TRY(conv_first_dw_launch(s, dt, WS(p, p->o_x), p->Ip, L.hw, p->Bp, dact, L.cout_ld, L.cout, p->buf.grad + L.w_off, L.cout_np, p->buf.grad + L.b_off,
+                                     reinterpret_cast<float*>(WS(p, p->o_c0part))));
             break;
         }
         const PConv& Lp = p->conv[i - 1];

@@ -62,12 +62,25 @@ __device__ __forceinline__ void load8(const bf16_t* p, float v[8]) {
 }
 
 // First layer (ONE input channel, 32 outputs, base_models.py:182): 9 multiply-adds per output -- no GEMM.  Direct
-// form over the padded pixel space: out[m][co] = relu(b[co] + sum_t x[b, y+ty-1, x+tx-1] * W[t][co]) for interior
-// pixels, zero for the border rows and the 32 pad channels (the whole zero-bordered activation in one pass).
+// form: out[b, y, x, co] = relu(b[co] + sum_t x[b, y+ty-1, x+tx-1] * W[t][co]), written into the interior of the
+// zero-bordered activation (its border and guard rows are zero from allocation and nothing ever writes them).
 // x = the batch as loaded, [B][bstride] with the H*H pixels of an image contiguous; W = [9][ldw], fp32 bias.
-// Thread = (pixel lane, 8 channels): its 72 weights and 8 biases live in registers across its pixels.
+// Thread = (4 consecutive pixels of an image row, 8 channels): one 3 x 6 input window, 72 weights and 8 biases in
+// registers; H is a multiple of 4.
 template <typename T>
-__global__ __launch_bounds__(256) void conv_first_fwd_kernel(const T* __restrict__ x, int64_t bstride, int H, int n_rows, const T* __restrict__ W, int ldw,
+__device__ __forceinline__ void first_window(const T* __restrict__ img, int H, int y, int x0, float (&xv)[3][6]) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = y + dy - 1;
+#pragma unroll
+        for (int dx = 0; dx < 6; ++dx) {
+            const int xx = x0 + dx - 1;
+            xv[dy][dx] = (yy >= 0 && yy < H && xx >= 0 && xx < H) ? to_f(img[yy * H + xx]) : 0.f;
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void conv_first_fwd_kernel(const T* __restrict__ x, int64_t bstride, int H, int n_units, const T* __restrict__ W, int ldw,
                                                              const float* __restrict__ bias, T* __restrict__ out, int ld) {
     const int c = (threadIdx.x & 3) * 8;
     float w[9][8], bv[8];
@@ -75,62 +88,60 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const T* __restrict
     for (int t = 0; t < 9; ++t) load8(W + t * ldw + c, w[t]);
 #pragma unroll
     for (int j = 0; j < 8; ++j) bv[j] = bias[c + j];
-    const float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int P = H + 2, R = P * P;
-    for (int m = blockIdx.x * 64 + (threadIdx.x >> 2); m < n_rows; m += gridDim.x * 64) {
-        const int b = m / R, r = m - b * R, yy = r / P, xx = r - yy * P;
-        float acc[8];
+    const int P = H + 2, S = H / 4, U = H * S;
+    for (int u = blockIdx.x * 64 + (threadIdx.x >> 2); u < n_units; u += gridDim.x * 64) {
+        const int b = u / U, r = u - b * U, y = r / S, x0 = (r - y * S) * 4;
+        float xv[3][6];
+        first_window(x + (int64_t)b * bstride, H, y, x0, xv);
+        T* o = out + ((int64_t)b * P * P + (int64_t)(y + 1) * P + x0 + 1) * ld + c;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-        if (yy >= 1 && yy <= H && xx >= 1 && xx <= H) {
+        for (int i = 0; i < 4; ++i) {
+            float acc[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = bv[j];
-            const T* img = x + (int64_t)b * bstride;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int y = yy - 1 + t / 3 - 1, xq = xx - 1 + t % 3 - 1;
-                const float xv = (y >= 0 && y < H && xq >= 0 && xq < H) ? to_f(img[y * H + xq]) : 0.f;
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, w[t][j], acc[j]);
-            }
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[t / 3][i + t % 3], w[t][j], acc[j]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+            store8(o + (int64_t)i * ld, acc);
         }
-        store8(out + (int64_t)m * ld + c, acc);
-        if (ld == 64) store8(out + (int64_t)m * ld + 32 + c, zero);       // rows stored 64 wide carry 32 zero pad channels
     }
 }
 
-// ... and its weight / bias gradient: dW[t][co] = sum over interior pixels x[pix + tap t] * dY[pix][co], db = sum dY.
-// A block walks a slab of padded rows: thread = (row lane, 8 channels) with 9 + 1 accumulators x 8 channels in
-// registers; reduced over the 16 row lanes of a wave by shuffles, over the 4 waves through LDS, then one fp32
-// atomic per (tap, channel) per block.
+// ... and its weight / bias gradient: dW[t][co] = sum over pixels x[pix + tap t] * dY[pix][co], db = sum dY.
+// A block walks a slab of units (4 pixels of a row each): thread = (unit lane, 8 channels) with 9 + 1 accumulators
+// x 8 channels in registers; reduced over the 16 unit lanes of a wave by shuffles, over the 4 waves through LDS,
+// then written as the block's partial [10][32]; a second tiny kernel adds the blocks in a fixed order, so this
+// layer's gradient is deterministic (no atomics).
 template <typename T>
-__global__ __launch_bounds__(256) void conv_first_dw_kernel(const T* __restrict__ x, int64_t bstride, int H, int n_rows, const T* __restrict__ dY,
-                                                            float* __restrict__ dW, int ldw, float* __restrict__ db, int rows_per_block, int ld) {
-    const int P = H + 2, R = P * P;
-    const int cq = threadIdx.x & 3, c = cq * 8, lane = threadIdx.x >> 2;      // 64 row lanes x 4 channel octets
+__global__ __launch_bounds__(256) void conv_first_dw_kernel(const T* __restrict__ x, int64_t bstride, int H, int n_units, const T* __restrict__ dY,
+                                                            float* __restrict__ part, int units_per_block, int ld) {
+    const int P = H + 2, S = H / 4, U = H * S;
+    const int cq = threadIdx.x & 3, c = cq * 8, lane = threadIdx.x >> 2;      // 64 unit lanes x 4 channel octets
     float acc[10][8];
 #pragma unroll
     for (int t = 0; t < 10; ++t)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
-    const int m_begin = blockIdx.x * rows_per_block, m_end = min(n_rows, m_begin + rows_per_block);
-    for (int m = m_begin + lane; m < m_end; m += 64) {
-        const int b = m / R, r = m - b * R, yy = r / P, xx = r - yy * P;
-        if (yy < 1 || yy > H || xx < 1 || xx > H) continue;
-        float g[8];
-        load8(dY + (int64_t)m * ld + c, g);
-        const T* img = x + (int64_t)b * bstride;
+    const int u_begin = blockIdx.x * units_per_block, u_end = min(n_units, u_begin + units_per_block);
+    for (int u = u_begin + lane; u < u_end; u += 64) {
+        const int b = u / U, r = u - b * U, y = r / S, x0 = (r - y * S) * 4;
+        float xv[3][6];
+        first_window(x + (int64_t)b * bstride, H, y, x0, xv);
+        const T* gp = dY + ((int64_t)b * P * P + (int64_t)(y + 1) * P + x0 + 1) * ld + c;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int y = yy - 1 + t / 3 - 1, xq = xx - 1 + t % 3 - 1;
-            const float xv = (y >= 0 && y < H && xq >= 0 && xq < H) ? to_f(img[y * H + xq]) : 0.f;
+        for (int i = 0; i < 4; ++i) {
+            float g[8];
+            load8(gp + (int64_t)i * ld, g);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[t][j] = fmaf(xv, g[j], acc[t][j]);
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[t][j] = fmaf(xv[t / 3][i + t % 3], g[j], acc[t][j]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[9][j] += g[j];
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[9][j] += g[j];
     }
     __shared__ float red[4][4][80];
     const int wave = threadIdx.x >> 6;
@@ -140,14 +151,34 @@ __global__ __launch_bounds__(256) void conv_first_dw_kernel(const T* __restrict_
         for (int j = 0; j < 8; ++j) {
             float v = acc[t][j];
 #pragma unroll
-            for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);      // over the 16 row lanes of this wave (lane bits 2..5)
+            for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);      // over the 16 unit lanes of this wave (lane bits 2..5)
             if ((threadIdx.x & 63) < 4) red[wave][cq][t * 8 + j] = v;
         }
     __syncthreads();
     for (int i = threadIdx.x; i < 4 * 80; i += 256) {
         const int q = i / 80, v = i % 80, t = v >> 3, co = q * 8 + (v & 7);
-        const float sum = red[0][q][v] + red[1][q][v] + red[2][q][v] + red[3][q][v];
-        atomicAdd(t < 9 ? dW + t * ldw + co : db + co, sum);
+        part[(int64_t)blockIdx.x * 320 + t * 32 + co] = red[0][q][v] + red[1][q][v] + red[2][q][v] + red[3][q][v];
+    }
+}
+// second stage: dW[t][co] / db[co] = sum over the blocks' partials [nblk][10][32] in a fixed order (deterministic).
+// Block t (10 of them) owns the 32 outputs of tap t (t = 9: the bias); its 1024 threads = 32 row lanes x 32 outputs.
+__global__ __launch_bounds__(1024) void conv_first_dw_reduce_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dW, int ldw, float* __restrict__ db) {
+    __shared__ float red[32][33];
+    const int t = blockIdx.x, co = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    float s0 = 0.f, s1 = 0.f;
+    int b = rl;
+    for (; b + 32 < nblk; b += 64) {
+        s0 += part[(int64_t)b * 320 + t * 32 + co];
+        s1 += part[(int64_t)(b + 32) * 320 + t * 32 + co];
+    }
+    if (b < nblk) s0 += part[(int64_t)b * 320 + t * 32 + co];
+    red[rl][co] = s0 + s1;
+    __syncthreads();
+    if (rl == 0) {
+        float sum = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) sum += red[r][co];
+        if (t < 9) dW[t * ldw + co] = sum; else db[co] = sum;
     }
 }
 
@@ -266,25 +297,28 @@ static inline int esize(int dtype) { return dtype == DMVAE_BF16 ? 2 : 4; }
 
 int conv_first_fwd_launch(hipStream_t s, int dtype, const void* x, int64_t bstride, int H, int64_t n_img, const void* W, int ldw,
                           const float* bias, int cout, void* out, int ld) {
-    const int64_t n_rows = n_img * (H + 2) * (H + 2);
-    if ((ld != 32 && ld != 64) || cout != 32 || n_rows >= (1ll << 31)) { set_error("conv_first_fwd: 32 channels in rows of 32 or 64 (ld=%d cout=%d rows=%lld)", ld, cout, (long long)n_rows); return DMVAE_EINVAL; }
-    ProfScope ps(s, "conv_first_fwd", 2.0 * n_img * H * H * 9 * cout, (double)n_rows * ld * esize(dtype));
-    const int nb = (int)std::min<int64_t>((n_rows + 63) / 64, 256 * 16);
-    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((conv_first_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, bstride, H, (int)n_rows, (const bf16_t*)W, ldw, bias, (bf16_t*)out, ld);
-    else hipLaunchKernelGGL((conv_first_fwd_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)x, bstride, H, (int)n_rows, (const float*)W, ldw, bias, (float*)out, ld);
+    const int64_t n_units = n_img * H * (H / 4);
+    if ((ld != 32 && ld != 64) || cout != 32 || H % 4 || n_units >= (1ll << 31)) { set_error("conv_first_fwd: 32 channels, side a multiple of 4 (ld=%d cout=%d H=%d)", ld, cout, H); return DMVAE_EINVAL; }
+    ProfScope ps(s, "conv_first_fwd", 2.0 * n_img * H * H * 9 * cout, (double)n_img * H * H * ld * esize(dtype));
+    const int nb = (int)std::min<int64_t>((n_units + 63) / 64, 256 * 16);
+    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((conv_first_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, bstride, H, (int)n_units, (const bf16_t*)W, ldw, bias, (bf16_t*)out, ld);
+    else hipLaunchKernelGGL((conv_first_fwd_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)x, bstride, H, (int)n_units, (const float*)W, ldw, bias, (float*)out, ld);
     return check_launch("conv_first_fwd");
 }
 
-// dW / db must be zero on entry (fp32 atomics, one per (tap, channel) per block)
+// few, long blocks: every block ends with a 80-value shuffle + LDS reduction (512 blocks: 157 us, 2048: 190 us at B = 4096)
+int conv_first_dw_blocks(int H, int64_t n_img) { return (int)std::min<int64_t>(512, (n_img * H * (H / 4) + 63) / 64); }
+// part: conv_first_dw_blocks() x 320 floats of scratch
 int conv_first_dw_launch(hipStream_t s, int dtype, const void* x, int64_t bstride, int H, int64_t n_img, const void* dY, int ld, int cout,
-                         float* dW, int ldw, float* db) {
-    const int64_t n_rows = n_img * (H + 2) * (H + 2);
-    if ((ld != 32 && ld != 64) || cout != 32 || n_rows >= (1ll << 31)) { set_error("conv_first_dw: 32 channels in rows of 32 or 64 (ld=%d cout=%d rows=%lld)", ld, cout, (long long)n_rows); return DMVAE_EINVAL; }
-    ProfScope ps(s, "conv_first_dw", 2.0 * n_img * H * H * 9 * cout, (double)n_rows * ld * esize(dtype));
-    const int nb = (int)std::min<int64_t>(2048, (n_rows + 255) / 256);
-    const int rpb = (int)((n_rows + nb - 1) / nb);
-    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((conv_first_dw_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, bstride, H, (int)n_rows, (const bf16_t*)dY, dW, ldw, db, rpb, ld);
-    else hipLaunchKernelGGL((conv_first_dw_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)x, bstride, H, (int)n_rows, (const float*)dY, dW, ldw, db, rpb, ld);
+                         float* dW, int ldw, float* db, float* part) {
+    const int64_t n_units = n_img * H * (H / 4);
+    if ((ld != 32 && ld != 64) || cout != 32 || H % 4 || n_units >= (1ll << 31) || !part) { set_error("conv_first_dw: 32 channels, side a multiple of 4, scratch (ld=%d cout=%d H=%d)", ld, cout, H); return DMVAE_EINVAL; }
+    ProfScope ps(s, "conv_first_dw", 2.0 * n_img * H * H * 9 * cout, (double)n_img * H * H * ld * esize(dtype));
+    const int nb = conv_first_dw_blocks(H, n_img);
+    const int upb = (int)((n_units + nb - 1) / nb);
+    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((conv_first_dw_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, bstride, H, (int)n_units, (const bf16_t*)dY, part, upb, ld);
+    else hipLaunchKernelGGL((conv_first_dw_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)x, bstride, H, (int)n_units, (const float*)dY, part, upb, ld);
+    hipLaunchKernelGGL(conv_first_dw_reduce_kernel, dim3(10), dim3(1024), 0, s, (const float*)part, nb, dW, ldw, db);
     return check_launch("conv_first_dw");
 }
 

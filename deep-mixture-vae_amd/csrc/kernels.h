@@ -46,8 +46,9 @@ void* gemm_bf16_stamps();
 // CNN trunk (conv.hip)
 int conv_first_fwd_launch(hipStream_t s, int dtype, const void* x, int64_t bstride, int H, int64_t n_img, const void* W, int ldw,
                           const float* bias, int cout, void* out, int ld);
+int conv_first_dw_blocks(int H, int64_t n_img);
 int conv_first_dw_launch(hipStream_t s, int dtype, const void* x, int64_t bstride, int H, int64_t n_img, const void* dY, int ld, int cout,
-                         float* dW, int ldw, float* db);
+                         float* dW, int ldw, float* db, float* part);
 int zero_border_launch(hipStream_t s, int dtype, void* a, int P, int ld, int64_t n_img);
 int maxpool2_fwd_launch(hipStream_t s, int dtype, const void* in, int H, int ld, int64_t n_img, void* out, int out_border);
 int maxpool2_bwd_relu_launch(hipStream_t s, int dtype, const void* in, const void* dout, int H, int ld, int64_t n_img, void* din, int dout_border);
