@@ -29,11 +29,26 @@ PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0       # HBM3E spec
 
 
+# BASELINE.json configs as presets (per-GPU sizes; cfg4 / cfg5 name a global batch of 65 536 over 8 GPUs = 8192 per GPU).
+PRESETS = {
+    "cfg1": dict(batch=100, latent_dim=10, n_clusters=10),
+    "cfg2": dict(batch=4096, latent_dim=64, n_clusters=10),
+    "cfg3": dict(batch=16384, latent_dim=128, n_clusters=10),
+    "cfg4": dict(batch=8192, latent_dim=256, n_clusters=50),
+    "cfg5": dict(batch=8192, latent_dim=512, n_clusters=256, input_dim=4096, enc_layers="4096,4096,4096,4096", head_dim=4096,
+                 dec_layers="4096,4096,4096,4096", lr=1e-4),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=3, help="the timed region (exactly --steps steps between barriers) is run this many "
+                    "times back to back; the line reports the MEDIAN region (SURVEY 8d), all regions in repeat_ms_per_step")
+    ap.add_argument("--config", default="", choices=[""] + sorted(PRESETS), help="a BASELINE.json config as a preset of the shape flags "
+                    "below (per-GPU batch; cfg4 = the north star's scaling point, 8192 per GPU, D=256, K=50); default = cfg2, the metric")
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch (cfg2: 4096)")
     ap.add_argument("--lr", type=float, default=0.002, help="Adam learning rate (train.py default 0.002; the 4096-wide cfg5 "
                     "stack overflows exp(log_var) after one step at that rate in fp32 and bf16 alike: use 1e-4 there)")
@@ -51,13 +66,28 @@ def parse():
     ap.add_argument("--deterministic", action="store_true", help="no float atomics (split-K off)")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--dp-dry-run", default="", choices=["", "overlap", "single"],
+    ap.add_argument("--cpu-steps", type=int, default=20, help="timed oracle steps at the bench batch (after 3 warm-up steps)")
+    ap.add_argument("--cpu-seconds", type=float, default=45.0, help="upper bound on the oracle's timed loop (larger configs stop early; the sample says so)")
+    ap.add_argument("--elbo-epochs", type=int, default=50, help="N = 1, the metric's config only: the metric's second half, ELBO@50ep -- this many "
+                    "epochs of bf16 training against the fp32 parity engine on identical batches and noise (0 = skip)")
+    ap.add_argument("--dp-dry-run", default="", choices=["", "overlap", "single", "sharded"],
                     help="N = 1 only: issue the data-parallel launch sequence (staged backward + stand-alone Adam, or whole "
                          "backward + Adam) with a no-op exchange, to price the N > 1 path's compute")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on one GPU)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config:
+        for k, v in PRESETS[args.config].items():
+            setattr(args, k, v)
+    return args
+
+
+def rocprof_name(name):
+    """the library reports a grouped launch as gemm_bf16_grouped_mixed_tiles<Ll, Ee> (it dispatches 128x128 / 128x64 /
+    64x64 tiles per problem); rocprofv3 prints the instantiation, whose template arguments are the smallest tile"""
+    import re
+    m = re.match(r"gemm_bf16_grouped_mixed_tiles<L(\d+), E(\d+)>", name)
+    return "gemm_bf16_grouped_kernel<64, 64, %s, %s, 4, 4>" % (m.group(1), m.group(2)) if m else name
 
 
 def flops_per_image(I, D, K, enc=(500, 500), head=2000, dec=(2000, 500, 500), cnn=False):
@@ -81,10 +111,13 @@ def flops_per_image(I, D, K, enc=(500, 500), head=2000, dec=(2000, 500, 500), cn
     return 2 * (3 * m - first)
 
 
-def cpu_baseline(args, seconds):
-    """The oracle timed on the host cores: float32 NumPy restatement of the same
-    step (reported baseline, not the optimisation target; the TensorFlow-1.x
-    reference itself cannot run in this image)."""
+def cpu_baseline(args):
+    """The oracle timed on the host cores: float32 NumPy restatement of the same step (a reported baseline, not
+    the optimisation target).  The TensorFlow-1.x reference itself cannot run in this image (TensorFlow is not
+    installed); SURVEY 8d names a torch-CPU restatement -- the oracle IS the restatement this repo pins against the
+    reference's golden vectors, it is NumPy on OpenBLAS with every host thread (the same sgemm torch-CPU would
+    call), so it is the one timed, labelled "port".  3 warm-up + --cpu-steps (20) timed steps at the bench batch,
+    then the reference's own batch size 100 (train.py:215-216)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import dmvae_oracle as O
@@ -94,7 +127,7 @@ def cpu_baseline(args, seconds):
     except Exception:
         cores = os.cpu_count() or 1
     out = {}
-    for B in (args.batch, 100):
+    for B, want, budget in ((args.batch, args.cpu_steps, args.cpu_seconds), (100, 50, 4.0)):
         cfg = O.Config(args.input_dim, args.latent_dim, args.n_clusters, tuple(int(v) for v in args.enc_layers.split(",")),
                        args.head_dim, tuple(int(v) for v in args.dec_layers.split(",")))
         p = O.init_params(cfg, 0, np.float32)
@@ -102,23 +135,77 @@ def cpu_baseline(args, seconds):
         X = O.synthetic_images(B, args.input_dim, seed=1)
         rng = np.random.RandomState(0)
         eps = rng.randn(B, args.latent_dim).astype(np.float32)
-        budget = seconds * (0.75 if B == args.batch else 0.25)
-        t, n, t0 = 1, 0, None
-        start = time.perf_counter()
-        while True:
-            O.train_step(p, m, v, t, cfg, X, eps)
+        t = 1
+        for _ in range(3):                  # warm-up (BLAS thread pool, page faults of the 4 parameter-sized arrays)
+            O.train_step(p, m, v, t, cfg, X, eps, lr=args.lr)
             t += 1
-            if t0 is None:
-                t0 = time.perf_counter()      # first step = warm-up
-                continue
+        n, t0 = 0, time.perf_counter()
+        while n < want and (n < 2 or time.perf_counter() - t0 < budget):
+            O.train_step(p, m, v, t, cfg, X, eps, lr=args.lr)
+            t += 1
             n += 1
-            if time.perf_counter() - start > budget or n >= 200:
-                break
         dt = time.perf_counter() - t0
-        out[B] = (B * n / dt, n)
-    return {"value": round(out[args.batch][0], 1), "unit": "images/sec", "cores": int(cores), "kind": "port",
-            "sample": "oracle/dmvae_oracle.py float32 NumPy step, batch %d, %d timed steps after 1 warm-up" % (args.batch, out[args.batch][1]),
-            "batch100_images_per_sec": round(out[100][0], 1)}
+        out[B] = (B * n / dt, n, dt)
+    v, n, dt = out[args.batch]
+    return {"value": round(v, 1), "unit": "images/sec", "cores": int(cores), "kind": "port",
+            "sample": "oracle/dmvae_oracle.py float32 NumPy/OpenBLAS step, batch %d, %d timed steps (%.1f s) after 3 warm-up steps%s"
+                      % (args.batch, n, dt, "" if n >= args.cpu_steps else " (stopped by --cpu-seconds)"),
+            "timed_steps": n, "batch100_images_per_sec": round(out[100][0], 1)}
+
+
+def elbo_leg(args, data, epochs, StepEngine):
+    """ELBO@50ep, the metric's second half: `epochs` epochs over the resident synthetic rows (no MNIST files in this
+    image), bf16 against the fp32 parity engine on IDENTICAL batches (per-epoch device permutations, seed 1) and the
+    IDENTICAL noise stream (device Philox: a draw depends on (seed, step, row, column), not on the arithmetic type).
+    ELBO = -(epoch-mean loss) in nats/image as VAE.train_op returns it (base_models.py:130)."""
+    rows, B = data.shape[0], args.batch
+    bpe = rows // B
+    pg = torch.Generator(device=data.device)
+    pg.manual_seed(1)
+    perms = [torch.randperm(rows, device=data.device, generator=pg).to(torch.int32) for _ in range(epochs)]
+    enc = tuple(int(v) for v in args.enc_layers.split(","))
+    dec = tuple(int(v) for v in args.dec_layers.split(","))
+    final, secs = {}, {}
+    for dtype in ("bf16", "fp32"):
+        eng = StepEngine(args.input_dim, args.latent_dim, args.n_clusters, enc_layers=enc, head_dim=args.head_dim, dec_layers=dec,
+                         dtype=dtype, max_batch=B, seed=1234)
+        eng.init_parameters(0)
+        eng.write_state(lr=args.lr)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for ep in range(epochs):
+            eng.reset_epoch(bpe, kl_ratio=1.0)
+            for _ in range(bpe):
+                eng.train_step(data, perms[ep], use_state_cursor=True)
+        torch.cuda.synchronize()
+        secs[dtype] = time.perf_counter() - t0
+        final[dtype] = float(eng.read_state().epoch_loss)
+        del eng
+    rel = abs(final["bf16"] - final["fp32"]) / abs(final["fp32"])
+    return {"epochs": epochs, "elbo_bf16": round(-final["bf16"], 4), "elbo_fp32_parity": round(-final["fp32"], 4),
+            "rel_diff": float("%.3e" % rel), "tolerance": 1e-3, "within_tolerance": bool(rel <= 1e-3),
+            "unit": "nats/image", "data": "synthetic 28x28 stand-in, %d rows, batch %d (no MNIST files in the image)" % (rows, B),
+            "reference": "unpinned: TensorFlow is not installed, the reference publishes no ELBO value (BASELINE.md)",
+            "wall_seconds": {k: round(v, 2) for k, v in secs.items()}}
+
+
+def respawn_ranks(args):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT torchrun: start the N ranks as fresh child processes through
+    torch.distributed.run -- before this process has touched the GPU -- relay their output and exit with their code.
+    (It used to run one rank and print n_gpus: 1.)"""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()        # counting devices does not initialise the GPU
+    if have < args.gpus:
+        print("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have), file=sys.stderr)
+        sys.exit(2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
 
 
 def main():
@@ -128,9 +215,16 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        os.dup2(json_fd, 1)             # the children inherit the real stdout; rank 0 prints the line
+        respawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and not (world == 1 and os.environ.get("DMVAE_DP_FORCE") == "1"):
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     # DMVAE_DP_FORCE=1 on a one-GPU box: a one-rank RCCL communicator, so the N > 1 launch sequence
     # runs with the real (identity) collectives -- a rehearsal, never the reported N = 1 number
     force_dp = world == 1 and os.environ.get("DMVAE_DP_FORCE") == "1"
@@ -147,8 +241,6 @@ def main():
         else:
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
     import dmvae_hip
     from dmvae_hip import StepEngine, GradExchange, prof_enable, prof_collect
@@ -197,21 +289,25 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    regions = []
+    for _ in range(max(1, args.repeats)):       # each region: EXACTLY --steps steps between barrier + synchronize
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)          # the slowest rank's clock
+            el = t.item()
+        regions.append(el)
+    elapsed = sorted(regions)[len(regions) // 2]               # the median region
     st = eng.read_state()
 
     # ---- per-kernel HIP-event timing: eager launches of the same step, event pair around each launch
@@ -255,46 +351,70 @@ def main():
         "step_mfma_frac_of_peak": round(fpi * B / (ms_step * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4),
         "last_loss": round(float(st.last_loss), 4),
     }
+    out["repeat_ms_per_step"] = [round(1e3 * r / args.steps, 4) for r in regions]
+    out["timing"] = "median of %d regions of %d steps, each bracketed by barrier + synchronize" % (len(regions), args.steps)
     if rows:
         ps = float(args.profile_steps)
+        # Event brackets are taken on EAGER launches (an event pair cannot be read back from inside a graph on this
+        # ROCm); besides the kernel each bracket holds its dispatch, so their sum exceeds the graph-replayed step the
+        # line reports (r01: 0.344 vs 0.308 ms).  Per-kernel durations are therefore SCALED so that they add up to
+        # the timed step -- the durations the replay actually runs at, and what rocprofv3 --kernel-trace reports
+        # for the same command (profiles/): `event_scale` is the factor, avg_us_event the raw bracket.
+        ev_sum = sum(r["total_ms"] for r in rows) / ps
+        scale = min(1.0, ms_step / ev_sum) if (ev_sum > 0 and sync is None and not args.no_graph) else 1.0
         table = []
         for r in rows:
-            ms = r["total_ms"] / ps
+            ms = scale * r["total_ms"] / ps
+            tot = scale * r["total_ms"]
             table.append({"kernel": r["name"], "launches_per_step": r["launches"] / ps, "ms_per_step": round(ms, 4),
-                          "avg_us": round(1e3 * r["total_ms"] / max(1, r["launches"]), 3),
-                          "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 2) if r["total_ms"] > 0 else 0.0,
-                          "gbs": round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1) if r["total_ms"] > 0 else 0.0})
+                          "avg_us": round(1e3 * tot / max(1, r["launches"]), 3),
+                          "avg_us_event": round(1e3 * r["total_ms"] / max(1, r["launches"]), 3),
+                          "tflops": round(r["flops"] / (tot * 1e-3) / 1e12, 2) if tot > 0 else 0.0,
+                          "gbs": round(r["bytes"] / (tot * 1e-3) / 1e9, 1) if tot > 0 else 0.0})
         dom = max(rows, key=lambda r: r["total_ms"])
+        dom_ms = scale * dom["total_ms"]
         # which roof bounds the dominant kernel: its algorithmic intensity against the ridge point
         # (dense MFMA peak / HBM peak = 312 flop/B for bf16).  The fused dW + Adam launch moves
         # ~300 MB for 41 GFLOP = 137 flop/B: HBM side of the ridge.
         peak_fl = 157.3 if args.dtype == "fp32" else PEAK_BF16_TFLOPS
         ai = dom["flops"] / max(dom["bytes"], 1.0)
         is_gemm = dom["name"].startswith("gemm") and ai >= peak_fl * 1e12 / (PEAK_HBM_GBS * 1e9)
-        ach = (dom["flops"] if is_gemm else dom["bytes"]) / (dom["total_ms"] * 1e-3) / (1e12 if is_gemm else 1e9)
+        ach = (dom["flops"] if is_gemm else dom["bytes"]) / (dom_ms * 1e-3) / (1e12 if is_gemm else 1e9)
         peak = peak_fl if is_gemm else PEAK_HBM_GBS
         traffic = None      # HBM bytes per launch from PMC counters: a separate rocprofv3 --pmc run (tools/pmc_traffic.sh)
         tp = os.path.join(ROOT, "profiles", "traffic.json")
+        rocname = rocprof_name(dom["name"])
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get(dom["name"], {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tp))
+                traffic = (tj.get(dom["name"]) or tj.get(rocname) or {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"kernel": dom["name"], "bound": "mfma" if is_gemm else "hbm", "achieved": round(ach, 2),
+        out["roofline"] = {"kernel": dom["name"], "rocprof_kernel": rocname,
+                           "bound": "mfma" if is_gemm else "hbm", "achieved": round(ach, 2),
                            "peak": peak, "unit": "TFLOP/s" if is_gemm else "GB/s", "frac": round(ach / peak, 4),
                            "traffic": traffic,
                            "launches_per_step": dom["launches"] / ps,
-                           "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 3),
+                           "avg_launch_us": round(1e3 * dom_ms / dom["launches"], 3),
+                           "avg_launch_us_event": round(1e3 * dom["total_ms"] / dom["launches"], 3),
+                           "event_scale": round(scale, 4),
                            "algorithmic_per_launch": (dom["flops"] if is_gemm else dom["bytes"]) / dom["launches"],
                            "flops_per_launch": dom["flops"] / dom["launches"], "bytes_per_launch": dom["bytes"] / dom["launches"],
                            "flop_per_byte": round(ai, 1),
-                           "mfma_frac": round(dom["flops"] / (dom["total_ms"] * 1e-3) / (peak_fl * 1e12), 4),
-                           "hbm_frac": round(dom["bytes"] / (dom["total_ms"] * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
-                           "method": "hipEvent pair around every launch, %d eager steps after the timed region" % args.profile_steps}
+                           "mfma_frac": round(dom["flops"] / (dom_ms * 1e-3) / (peak_fl * 1e12), 4),
+                           "hbm_frac": round(dom["bytes"] / (dom_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
+                           "method": "hipEvent pair around every launch of %d eager steps after the timed region, scaled by event_scale "
+                                     "so that the per-kernel durations sum to the timed (graph-replayed) step" % args.profile_steps}
+        assert out["roofline"]["frac"] <= 1.0, "roofline.frac %.4f > 1: the kernel's algorithmic bytes / flops are over-counted" % out["roofline"]["frac"]
         out["kernels"] = table
+        out["kernels_per_step"] = round(sum(t["launches_per_step"] for t in table), 2)
         out["kernel_ms_per_step_sum"] = round(sum(t["ms_per_step"] for t in table), 4)
+        out["kernel_ms_per_step_sum_event"] = round(ev_sum, 4)
+    if world == 1 and is_cfg2 and args.elbo_epochs > 0 and not args.dp_dry_run and not force_dp:
+        del eng, step
+        out["elbo50" if args.elbo_epochs == 50 else "elbo"] = elbo_leg(args, data, args.elbo_epochs, StepEngine)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(args)
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or force_dp:

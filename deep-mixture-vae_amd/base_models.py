@@ -131,6 +131,7 @@ class DeepMixtureVAE(VAE):
         self._session = session
         self._engine = None
         self._replay = None
+        self._replay_key = None
         self._perm = None
 
     # ------------------------------------------------------------------ graph
@@ -172,25 +173,17 @@ class DeepMixtureVAE(VAE):
 
     # ------------------------------------------------------------------ training
     def _epoch_perm(self, data, sess):
-        """the epoch's row order -> this rank's slice of every global batch, on the device"""
+        """the epoch's row order -> this rank's slice of every global batch, on the device.
+        Returns (perm, n_full, tail, epoch_weight) -- see dmvae_hip.parallel.epoch_plan: with more than
+        one rank only the full global batches are trained, the step count is the same on every rank."""
         import torch
-        from dmvae_hip import shard_range
-        order = data.reshuffle()
-        B = data.batch_size
-        if sess.world_size > 1:
-            lo, hi = shard_range(B, sess.rank, sess.world_size)
-            n_full = len(order) // B
-            mine = [order[i * B + lo: i * B + hi] for i in range(n_full)]
-            tail = order[n_full * B:]
-            tlo, thi = shard_range(len(tail), sess.rank, sess.world_size)
-            mine.append(tail[tlo:thi])
-            order = np.concatenate(mine)
+        from dmvae_hip.parallel import epoch_plan
+        order, n_full, tail, weight = epoch_plan(data.reshuffle(), data.batch_size, sess.rank, sess.world_size)
         t = torch.as_tensor(np.ascontiguousarray(order, dtype=np.int32))
         if self._perm is None or self._perm.numel() != t.numel():
             self._perm = torch.empty(t.numel(), dtype=torch.int32, device=sess.device)
-            self._replay = None          # the captured graph holds the old pointer
         self._perm.copy_(t)
-        return self._perm
+        return self._perm, n_full, tail, weight
 
     def train_op(self, session, data, kl_ratio=1.0):
         """One epoch, base_models.py:112-132: for every batch of data.get_batches()
@@ -209,14 +202,10 @@ class DeepMixtureVAE(VAE):
         if b != eng.max_batch:
             raise ValueError("per-rank batch %d != the size the model was built for (%d)" % (b, eng.max_batch))
         rows = data.device_rows(sess.device)
-        perm = self._epoch_perm(data, sess)
-        n_local = perm.numel()
-        n_full, tail = n_local // b, n_local % b
-        if world > 1:
-            tail = 0       # data parallel: the ragged last batch is dropped (shards would be unequal)
+        perm, n_full, tail, weight = self._epoch_perm(data, sess)
         ex = GradExchange()
         sync = ex if ex.enabled else None
-        eng.reset_epoch(n_full + (1 if tail else 0), kl_ratio=kl_ratio, epoch_weight=1.0 / data.epoch_len)
+        eng.reset_epoch(n_full + (1 if tail else 0), kl_ratio=kl_ratio, epoch_weight=weight)
         host_noise = self.noise == "host"
         if host_noise and world > 1:
             raise NotImplementedError("noise='host' replays the reference's single-process NumPy stream; use noise='device' with more than one rank")
@@ -234,9 +223,13 @@ class DeepMixtureVAE(VAE):
                 eps, g = host_feed(b)
                 eng.train_step(rows, perm, b, eps, g, first=i * b, grad_sync=sync, grad_scale=ex.grad_scale)
         else:
-            if self._replay is None and n_full > 0:
+            # the captured graph holds the device pointers of the rows and of the row order: recapture
+            # when either buffer (another Dataset, a re-upload) or the exchange changes
+            key = (rows.data_ptr(), perm.data_ptr(), b, sync is None)
+            if n_full > 0 and (self._replay is None or self._replay_key != key):
                 self._replay = eng.capture_step(rows, perm, grad_sync=sync, grad_scale=ex.grad_scale)
-                eng.reset_epoch(n_full + (1 if tail else 0), kl_ratio=kl_ratio, epoch_weight=1.0 / data.epoch_len)
+                self._replay_key = key
+                eng.reset_epoch(n_full + (1 if tail else 0), kl_ratio=kl_ratio, epoch_weight=weight)
             for _ in range(n_full):
                 self._replay()
         if tail:                                             # the short last batch (utils.py:462-463), issued eagerly
@@ -314,17 +307,34 @@ class DeepMixtureVAE(VAE):
         return os.path.join(self.path, stage, "parameters.npz") if self.path else None
 
     def _restore(self, stage):
+        """the reference wraps its restore in try / except and carries on (base_models.py:324-329, :354-359)"""
         path = self._ckpt(stage)
-        if path and os.path.exists(path):
-            self.load_state_dict(dict(np.load(path)))
+        if not (path and os.path.exists(path)):
+            return False
+        try:
+            with np.load(path, allow_pickle=False) as f:
+                self.load_state_dict({k: f[k] for k in f.files})
             return True
-        return False
+        except (OSError, ValueError, KeyError, RuntimeError) as e:
+            print("Could not read %s: %s" % (path, e))
+            return False
 
     def _save(self, stage):
+        """rank 0 writes (to a temporary file, then an atomic rename); the other ranks wait at a barrier
+        so that none of them reads a half-written archive"""
         path = self._ckpt(stage)
-        if path:
+        if not path:
+            return
+        sess = self._session
+        if sess is None or sess.rank == 0:
             os.makedirs(os.path.dirname(path), exist_ok=True)
-            np.savez(path, **self.state_dict())
+            tmp = path + ".tmp.npz"
+            np.savez(tmp, **self.state_dict())
+            os.replace(tmp, path)
+        if sess is not None and sess.world_size > 1:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                dist.barrier()
 
     def _pretrain_epoch(self, sess, data, stage):
         """one epoch of a pretraining stage: epsilon = 0 (so Z = mean), the stage's loss and
@@ -337,13 +347,11 @@ class DeepMixtureVAE(VAE):
         if data.batch_size % world or b != eng.max_batch:
             raise ValueError("batch_size %d does not match the model (%d per rank x %d ranks)" % (data.batch_size, eng.max_batch, world))
         rows = data.device_rows(sess.device)
-        perm = self._epoch_perm(data, sess)
-        n_local = perm.numel()
-        n_full, tail = n_local // b, (n_local % b if world == 1 else 0)
+        perm, n_full, tail, weight = self._epoch_perm(data, sess)
         ex = GradExchange()
         sync = ex if ex.enabled else None
         # recon-only objective = the full loss at kl_ratio 0: every KL gradient carries the factor r
-        eng.reset_epoch(n_full + (1 if tail else 0), kl_ratio=0.0 if stage == "vae" else 1.0, epoch_weight=1.0 / data.epoch_len)
+        eng.reset_epoch(n_full + (1 if tail else 0), kl_ratio=0.0 if stage == "vae" else 1.0, epoch_weight=weight)
         zeros = {}
 
         def noise(n):

@@ -11,6 +11,7 @@ CPU in the tests); the 1/world factor is folded into the Adam kernel
 """
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -21,6 +22,33 @@ def shard_range(n_rows, rank, world):
     base, rem = divmod(int(n_rows), int(world))
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def epoch_plan(order, global_batch, rank, world):
+    """The rows of one epoch this rank steps through, and how many steps that is.
+
+    order: the epoch's global row order (identical on every rank).  Returns (local_order, n_full,
+    tail, epoch_weight): `n_full` steps of global_batch / world rows each, then -- single process
+    only -- one short batch of `tail` rows (includes/utils.py:462-463); epoch_weight multiplies each
+    batch loss in the epoch mean (base_models.py:130: 1 / epoch_len).
+    world > 1: only the len(order) // global_batch FULL global batches are trained; the ragged tail
+    is dropped (its shards would be unequal), so n_full is derived from the GLOBAL row count and is
+    the same on every rank -- every rank issues the same number of collectives -- and the epoch mean
+    is over those n_full batches.  Raises when not even one full global batch exists."""
+    order = np.asarray(order)
+    B = int(global_batch)
+    if B % world:
+        raise ValueError("batch_size %d is not divisible by the world size %d" % (B, world))
+    n_full = len(order) // B
+    if world == 1:
+        tail = len(order) - n_full * B
+        return order, n_full, tail, 1.0 / max(1, n_full + (1 if tail else 0))
+    if n_full == 0:
+        raise ValueError("data parallel: %d rows do not fill one global batch of %d (the ragged tail is dropped when world > 1)"
+                         % (len(order), B))
+    lo, hi = shard_range(B, rank, world)
+    mine = np.concatenate([order[i * B + lo: i * B + hi] for i in range(n_full)])
+    return mine, n_full, 0, 1.0 / n_full
 
 
 class GradExchange:

@@ -2,7 +2,8 @@
 the reference (argparse :28-97, main :101-338) for --model dmvae, with the
 per-batch path on MI355X.  Run from this directory:  python train.py [flags]
 Multi-GPU (one process per GPU, RCCL gradient all-reduce):
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py --batch_size 65536
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py --batch_size 32768
+(with more than one rank only full global batches are trained: the batch must not exceed the row count)
 Flags that the reference accepts but that address models outside the DMVAE hot
 path (--model vade/dmoe/dvmoe/vademoe, --visdom) are parsed and rejected /
 ignored with a message, see SURVEY.md 2.1.  --plotting writes the reference's
@@ -21,43 +22,46 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-parser = argparse.ArgumentParser(description="Training file for DMVAE and DVMOE")
+parser = argparse.ArgumentParser(description="DMVAE training on MI355X (flag names and defaults of the reference's train.py:28-97)")
 
-parser.add_argument("--model", type=str, default="dmvae", help="Model to use [dmvae, vade, dmoe, dvmoe, vademoe]")
-parser.add_argument("--model_name", type=str, default="", help="Name of the model")
-parser.add_argument("--dataset", type=str, default="mnist", help="Dataset to use [mnist, spiral, cifar10]")
-parser.add_argument("--latent_dim", type=int, default=10, help="Number of dimensions for latent variable Z")
-parser.add_argument("--output_dim", type=int, default=1, help="Output dimension for regression variable for ME models")
-parser.add_argument("--n_clusters", type=int, default=-1, help="Number of clusters to use")
-parser.add_argument("--n_experts", type=int, default=5, help="Number of experts to use for MoE models")
-parser.add_argument("--classification", action="store_true", default=False,
-                    help="Whether the objective is classification or regression (ME models)")
-parser.add_argument("--n_epochs", type=int, default=500, help="Number of epochs for training the model")
-parser.add_argument("--pretrain_epochs_vae", type=int, default=200, help="Number of epochs for pretraining the vae model")
-parser.add_argument("--pretrain_epochs_prior", type=int, default=200, help="Number of epochs for pretraining the gmm model")
-parser.add_argument("--init_lr", type=float, default=0.002, help="Initial learning rate for training")
-parser.add_argument("--decay_rate", type=float, default=0.9,
-                    help="Decay rate for exponentially decaying learning rate (< 1.0)")
-parser.add_argument("--decay_epochs", type=int, default=25,
-                    help="Number of epochs between exponentially decay of learning rate")
-parser.add_argument("--pretrain", action="store_true", default=False, help="Whether to pretrain the model or not")
-parser.add_argument("--pretrain_vae_lr", type=float, default=0.0005, help="Initial learning rate for pretraining the vae")
-parser.add_argument("--pretrain_decay_rate", type=float, default=0.9,
-                    help="Decay rate for exponentially decaying learning rate (< 1.0) for pretraining")
-parser.add_argument("--pretrain_decay_epochs", type=int, default=25,
-                    help="Number of epochs between exponentially decay of learning rate for pretraining")
-parser.add_argument("--pretrain_prior_lr", type=float, default=0.0005, help="Initial learning rate for pretraining the prior")
-parser.add_argument("--kl_annealing", action="store_true", default=False,
-                    help="Whether to anneal the KL term while training or not")
-parser.add_argument("--anneal_step", type=float, default=0.1, help="Step size for annealing")
-parser.add_argument("--anneal_epochs", type=int, default=1000, help="Number of epochs before annealing the KL term")
-parser.add_argument("--plotting", action="store_true", default=False,
-                    help="Whether to generate sampling and regeneration plots")
-parser.add_argument("--plot_epochs", type=int, default=100, help="Nummber of epochs before generating plots")
-parser.add_argument("--save_epochs", type=int, default=10, help="Nummber of epochs before saving model")
-parser.add_argument("--debug", action="store_true", default=False, help="Whether to debug the models or not")
-parser.add_argument("--visdom", action="store_true", default=False, help="Using visdom for plotting")
-parser.add_argument("--featLearn", action="store_true", default=False, help="Whether to use feature learning in MOE")
+# (flag, type, default, what it does here).  Names and defaults are the reference's CLI contract; the
+# descriptions say what THIS implementation does with each flag.
+_FLAGS = [
+    ("model", str, "dmvae", "model family; only dmvae and vade are built (the MoE families are rejected)"),
+    ("model_name", str, "", "directory name under saved-models/<dataset>/ (default: the model family)"),
+    ("dataset", str, "mnist", "mnist | fashion-mnist | synthetic (idx files under data/<dataset>/, else a synthetic stand-in)"),
+    ("latent_dim", int, 10, "width D of the Gaussian latent z"),
+    ("output_dim", int, 1, "MoE regression target width (accepted, unused: MoE is out of scope)"),
+    ("n_clusters", int, -1, "mixture components K; -1 takes the dataset's class count"),
+    ("n_experts", int, 5, "MoE expert count (accepted, unused)"),
+    ("n_epochs", int, 500, "training epochs"),
+    ("pretrain_epochs_vae", int, 200, "epochs of the reconstruction-only pretraining stage"),
+    ("pretrain_epochs_prior", int, 200, "epochs of the prior stage (also max_iter of the GMM that seeds the prior tables)"),
+    ("init_lr", float, 0.002, "Adam learning rate (constant: the reference's decay is a no-op, SURVEY F3)"),
+    ("decay_rate", float, 0.9, "accepted and inert, as in the reference (global_step is the literal 0)"),
+    ("decay_epochs", int, 25, "accepted and inert, see --decay_rate"),
+    ("pretrain_vae_lr", float, 0.0005, "Adam learning rate of the reconstruction-only stage"),
+    ("pretrain_decay_rate", float, 0.9, "accepted and inert"),
+    ("pretrain_decay_epochs", int, 25, "accepted and inert"),
+    ("pretrain_prior_lr", float, 0.0005, "Adam learning rate of the prior stage"),
+    ("anneal_step", float, 0.1, "increment of the KL weight at each annealing point"),
+    ("anneal_epochs", int, 1000, "epochs between two increments of the KL weight"),
+    ("plot_epochs", int, 100, "epochs between two sets of sample / reconstruction grids"),
+    ("save_epochs", int, 10, "epochs between two --debug stops"),
+]
+_SWITCHES = [
+    ("classification", "MoE objective switch (accepted, unused)"),
+    ("pretrain", "run the two pretraining stages before training"),
+    ("kl_annealing", "start the KL weight at 0 and raise it by --anneal_step every --anneal_epochs"),
+    ("plotting", "write sampled.png / regenerated.png grids every --plot_epochs"),
+    ("debug", "stop in pdb on the first batch every --save_epochs"),
+    ("visdom", "accepted; no Visdom server is contacted"),
+    ("featLearn", "MoE feature-learning switch (accepted, unused)"),
+]
+for _name, _type, _default, _help in _FLAGS:
+    parser.add_argument("--" + _name, type=_type, default=_default, help=_help)
+for _name, _help in _SWITCHES:
+    parser.add_argument("--" + _name, action="store_true", default=False, help=_help)
 # ---- extensions (defaults reproduce the reference)
 parser.add_argument("--batch_size", type=int, default=100, help="GLOBAL batch size (reference hard-codes 100, train.py:215-216)")
 parser.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "fp32"], help="bf16 MFMA (throughput) or exact fp32 (parity)")
@@ -138,11 +142,12 @@ def main(argv):
         model.define_pretrain_step(argv.pretrain_vae_lr, argv.pretrain_prior_lr)
         model.pretrain(sess, train_data, argv.pretrain_epochs_vae, argv.pretrain_epochs_prior)
     ckpt_path = model.path + "/model/parameters.ckpt"
-    try:
-        model.load_state_dict(torch.load(ckpt_path, weights_only=False))
+    try:      # the checkpoint is an npz archive of the trainables (as the pretraining stages write): no pickle
+        with np.load(ckpt_path, allow_pickle=False) as f:
+            model.load_state_dict({k: f[k] for k in f.files})
         if rank == 0:
             print("Restored", ckpt_path)
-    except Exception:
+    except FileNotFoundError:
         if rank == 0:
             print("Could not load trained model")
     if world > 1:   # every rank starts from rank 0's parameters
@@ -168,7 +173,9 @@ def main(argv):
             if accTest > maxAcc:
                 maxAcc = accTest
                 if rank == 0:
-                    torch.save(model.state_dict(), ckpt_path)
+                    with open(ckpt_path + ".tmp", "wb") as f:
+                        np.savez(f, **model.state_dict())
+                    os.replace(ckpt_path + ".tmp", ckpt_path)
             if math.isnan(loss):
                 raise FloatingPointError("loss is NaN at epoch %d (the reference drops into pdb here, train.py:320-321)" % epoch)
             bar.set_postfix({"loss": "%.4f" % loss, "accTrain": "%.4f" % accTrain, "accTest": "%.4f" % accTest,

@@ -1,0 +1,267 @@
+"""GPU tests on the geometries of BASELINE.json's configs that tests/test_gpu_step.py does not reach:
+
+  cfg3  Fashion-MNIST shape, K=10, z_dim=128 (batch 16384 per GPU)
+  cfg5  4096-d inputs, K=256, z_dim=512, 4 x 4096 MLP encoder / decoder, head 4096 (batch 8192 per GPU)
+
+and FULL-SIZE property tests at the batch sizes the configs name (cfg2 4096, cfg3 16384, cfg4 8192 per GPU,
+cfg5 8192 per GPU), where the tile planner, the XCD run cutting and the supertile height choose differently than
+at the small batches the oracle comparisons run at.  Reference lines: code/base_models.py:218-302 (graph),
+:66-110 (loss, Adam), code/priors.py:104-147 (mixture KL).
+
+Tolerances (north star: "within a stated floating-point tolerance"):
+  fp32 engine vs float64 oracle : loss |delta| <= 1e-3 nats per 784 inputs (scaled by input_dim / 784 for the
+                                  4096-d config), every gradient tensor <= 1e-4 of its max
+  bf16 engine vs oracle / fp32  : loss <= 2e-3 relative, per-tensor gradient Frobenius error <= 8e-2
+  properties                    : bit-identical (torch.equal) -- no tolerance
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import dmvae_oracle as O
+
+CFG2 = dict(input_dim=784, latent_dim=64, n_classes=10)
+CFG3 = dict(input_dim=784, latent_dim=128, n_classes=10)
+CFG4 = dict(input_dim=784, latent_dim=256, n_classes=50)
+CFG5 = dict(input_dim=4096, latent_dim=512, n_classes=256, enc_layers=(4096,) * 4, head_dim=4096, dec_layers=(4096,) * 4)
+# (geometry, per-GPU batch, learning rate): cfg5 overflows exp(log_var) after one Adam step at train.py's 0.002
+FULL = {"cfg2": (CFG2, 4096, 0.002), "cfg3": (CFG3, 16384, 0.002), "cfg4": (CFG4, 8192, 0.002), "cfg5": (CFG5, 8192, 1e-4)}
+
+
+def make(kw, dtype, B, seed=0, lr=0.002, mode="exact"):
+    from dmvae_hip import StepEngine
+    eng = StepEngine(dtype=dtype, max_batch=B, mode=mode, deterministic=True, seed=77, **kw)
+    eng.init_parameters(seed)
+    eng.write_state(lr=lr)
+    return eng
+
+
+def oracle_cfg(kw):
+    return O.Config(kw["input_dim"], kw["latent_dim"], kw["n_classes"], kw.get("enc_layers", (500, 500)),
+                    kw.get("head_dim", 2000), kw.get("dec_layers", (2000, 500, 500)), "binary")
+
+
+def fp32_step_vs_oracle(kw, B, own_masks=False, p_override=None, seed=1):
+    """forward + loss + backward of the fp32 engine against the float64 oracle on the same parameters, batch
+    and noise; own_masks: the oracle uses ITS ReLU masks (the caller made every pre-activation clear zero)."""
+    eng = make(kw, "fp32", B)
+    cfg = oracle_cfg(kw)
+    rng = np.random.RandomState(seed)
+    if p_override is not None:
+        eng.set_parameters(p_override)
+    p = {k: v.astype(np.float64) for k, v in eng.get_parameters().items()}
+    I, D = cfg.input_dim, cfg.latent_dim
+    X = (rng.rand(B, I) * (rng.rand(B, I) < 0.3)).astype(np.float32)
+    eps = rng.randn(B, D).astype(np.float32)
+    eng.write_state(kl_ratio=0.8)
+    eng.load_batch(torch.as_tensor(X).cuda(), None, 0, B)
+    eng.forward_backward(B, torch.as_tensor(eps).cuda())
+    torch.cuda.synchronize()
+    a = O.forward(p, cfg, X.astype(np.float64), eps.astype(np.float64), 0.8)
+    acts = eng.hidden_activations(B)
+    masks = {k: (v > 0).cpu().numpy() for k, v in acts.items()}
+    flips = sum(int((masks[k] != (a[k] > 0)).sum()) for k in masks)
+    units = sum(mk.size for mk in masks.values())
+    if own_masks:
+        assert flips == 0, flips
+    else:
+        assert flips <= 1e-4 * units, (flips, units)
+    scale_I = max(1.0, I / 784.0)
+    for k in masks:
+        np.testing.assert_allclose(acts[k].float().cpu().numpy(), a[k], atol=3e-5 * scale_I, err_msg=k)
+    g = O.backward(p, cfg, a, None if own_masks else masks)
+    st = eng.read_state()
+    assert abs(st.last_loss - a["loss"]) <= 1e-3 * scale_I, (st.last_loss, a["loss"])
+    assert abs(st.last_recon - a["recon"]) <= 1e-3 * scale_I
+    assert abs(st.last_klz - a["kl_z"]) <= 1e-4 * max(1.0, abs(a["kl_z"]))
+    assert abs(st.last_klc - a["kl_c"]) <= 1e-5
+    np.testing.assert_allclose(eng.view("mean", B).cpu().numpy(), a["mean"], atol=2e-5 * scale_I)
+    np.testing.assert_allclose(eng.view("logits", B).cpu().numpy(), a["logits"], atol=2e-5 * scale_I)
+    gg = eng.get_gradients()
+    for k in g:
+        scale = np.abs(g[k]).max() + 1e-12
+        assert np.abs(gg[k] - g[k]).max() <= 1e-4 * scale, (k, np.abs(gg[k] - g[k]).max(), scale)
+    return eng, a, g
+
+
+def test_cfg3_geometry_fp32_step_matches_oracle():
+    fp32_step_vs_oracle(CFG3, 256)
+
+
+def test_cfg3_geometry_bf16_step_close_to_oracle():
+    kw, B = CFG3, 512
+    eng = make(kw, "bf16", B)
+    cfg = oracle_cfg(kw)
+    rng = np.random.RandomState(2)
+    p = {k: v.astype(np.float64) for k, v in eng.get_parameters().items()}
+    X = O.synthetic_images(B, 784, seed=3)
+    eps = rng.randn(B, 128).astype(np.float32)
+    eng.load_batch(torch.as_tensor(X).cuda(), None, 0, B)
+    eng.forward_backward(B, torch.as_tensor(eps).cuda())
+    torch.cuda.synchronize()
+    a = O.forward(p, cfg, X.astype(np.float64), eps.astype(np.float64))
+    g = O.backward(p, cfg, a)
+    st = eng.read_state()
+    assert abs(st.last_loss - a["loss"]) <= 2e-3 * abs(a["loss"]), (st.last_loss, a["loss"])
+    gg = eng.get_gradients()
+    for k in g:
+        rel = np.linalg.norm(gg[k] - g[k]) / (np.linalg.norm(g[k]) + 1e-30)
+        assert rel <= 8e-2, (k, rel)
+
+
+def test_cfg5_geometry_fp32_step_matches_oracle():
+    """4096-d inputs, 4 x 4096 trunk / decoder, head 4096, D=512, K=256 at B=128: 0.27 TFLOP in float64 NumPy.
+    The latent kernel streams its 1 MB prior tables through LDS in D-chunks here; every GEMM has K = 4096."""
+    eng, a, g = fp32_step_vs_oracle(CFG5, 128)
+    assert len(g) == 2 * (4 + 5 + 4 + 1) + 2
+
+
+def test_cfg5_geometry_bf16_tracks_fp32_engine_at_full_batch():
+    kw, B, lr = FULL["cfg5"]
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    X = torch.rand((B, 4096), device="cuda", generator=g) * (torch.rand((B, 4096), device="cuda", generator=g) < 0.19)
+    eps = torch.randn((B, 512), device="cuda", generator=g)
+    out = {}
+    for dt in ("fp32", "bf16"):
+        eng = make(kw, dt, B, lr=lr)
+        eng.load_batch(X, None, 0, B)
+        eng.forward_backward(B, eps)
+        torch.cuda.synchronize()
+        st = eng.read_state()
+        out[dt] = (st.last_loss, st.last_recon, st.last_klz, st.last_klc, {k: eng.grad_view(k).clone() for k in ("W_enc0", "W_zh", "W_mean", "W_logits", "W_dec0", "W_out", "prior_means", "prior_log_vars")})
+        del eng
+        torch.cuda.empty_cache()
+    assert abs(out["bf16"][0] - out["fp32"][0]) <= 2e-3 * abs(out["fp32"][0]), (out["bf16"][:4], out["fp32"][:4])
+    assert abs(out["bf16"][2] - out["fp32"][2]) <= 2e-2 * abs(out["fp32"][2]) + 1e-3
+    for k, gb in out["bf16"][4].items():
+        gf = out["fp32"][4][k]
+        rel = (gb - gf).norm().item() / (gf.norm().item() + 1e-30)
+        assert rel <= 0.15, (k, rel)          # bf16 activations through ten 4096-wide layers
+
+
+def _snap(eng):
+    st = eng.read_state()
+    return dict(param=eng.param.clone(), m=eng.m.clone(), v=eng.v.clone(), shadow=eng.param_bf16.clone(),
+                adam_t=st.adam_t, last_loss=st.last_loss, epoch_loss=st.epoch_loss, noise_step=st.noise_step, cursor=st.batch_cursor)
+
+
+def _same(a, b, what):
+    for k in ("param", "m", "v", "shadow"):
+        assert torch.equal(a[k], b[k]), (what, k, (a[k] != b[k]).sum().item())
+    for k in ("adam_t", "last_loss", "epoch_loss", "noise_step", "cursor"):
+        assert a[k] == b[k], (what, k, a[k], b[k])
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5"])
+def test_full_size_step_properties(name):
+    """At the batch size the config names, three steps (device Philox noise, batch cursor in the device state):
+      two eager runs are bit-identical; HIP-graph replay == eager; Adam fused into the dW launch == backward
+      then stand-alone Adam; the staged (data-parallel) backward == the whole one; and the bf16 loss stays
+      within 2e-3 relative of the fp32 engine on the same batch and noise."""
+    kw, B, lr = FULL[name]
+    I = kw["input_dim"]
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    N = 4 * B
+    data = torch.rand((N, I), device="cuda", generator=g)
+    data = data * (torch.rand((N, I), device="cuda", generator=g) < 0.19)
+    perm = torch.randperm(N, device="cuda", generator=g).to(torch.int32)
+    steps = 3
+
+    def run(form):
+        eng = make(kw, "bf16", B, seed=4, lr=lr)
+        eng.reset_epoch(N // B, kl_ratio=1.0)
+        grads = None
+        if form == "graph":
+            replay = eng.capture_step(data, perm)
+            for _ in range(steps):
+                replay()
+        else:
+            for s in range(steps):
+                if form == "fused":
+                    eng.train_step(data, perm, use_state_cursor=True)
+                elif form == "unfused":
+                    eng.train_step(data, perm, use_state_cursor=True, fused=False)
+                else:
+                    eng.load_batch(data, perm, 0, None, True)
+                    for stage in range(3):
+                        eng.forward_backward_stage(stage)
+                    eng.update(1.0)
+                if s == 0 and form in ("unfused", "staged"):
+                    torch.cuda.synchronize()
+                    grads = eng.grad.clone()
+        torch.cuda.synchronize()
+        snap = _snap(eng)
+        del eng
+        torch.cuda.empty_cache()
+        return snap, grads
+
+    a, _ = run("fused")
+    assert a["adam_t"] == steps and a["cursor"] == steps and np.isfinite(a["last_loss"])
+    b, _ = run("fused")
+    _same(a, b, "two eager runs")
+    del b
+    c, _ = run("graph")
+    _same(a, c, "graph replay vs eager")
+    del c
+    d, gd = run("unfused")
+    _same(a, d, "fused vs backward + stand-alone Adam")
+    del d
+    e, ge = run("staged")
+    _same(a, e, "staged vs whole backward")
+    assert torch.equal(gd, ge)
+    del e, gd, ge
+    torch.cuda.empty_cache()
+
+    # bf16 against the fp32 engine on one batch with caller-supplied noise
+    eps = torch.randn((B, kw["latent_dim"]), device="cuda", generator=g)
+    loss = {}
+    for dt in ("fp32", "bf16"):
+        eng = make(kw, dt, B, seed=4, lr=lr)
+        eng.load_batch(data, perm, 0, B)
+        eng.forward_backward(B, eps)
+        torch.cuda.synchronize()
+        loss[dt] = eng.read_state().last_loss
+        del eng
+        torch.cuda.empty_cache()
+    assert abs(loss["bf16"] - loss["fp32"]) <= 2e-3 * abs(loss["fp32"]), loss
+
+
+def test_fp32_step_with_the_oracles_own_relu_masks():
+    """the other fp32 comparisons hand the oracle's backward the GPU's ReLU masks.  Here the
+    biases are nudged until EVERY pre-activation of every ReLU layer is at least 1e-3 away from zero in
+    float64 (fp32 rounding is ~1e-5 at these widths), so both sides take the same side of every kink by
+    themselves: the oracle runs on its own masks and the mask sets must agree exactly."""
+    kw, B = dict(input_dim=784, latent_dim=10, n_classes=10), 100
+    cfg = oracle_cfg(kw)
+    rng = np.random.RandomState(1)
+    p = O.init_params(cfg, 5)
+    p = {k: v.astype(np.float32).astype(np.float64) for k, v in p.items()}
+    X = (rng.rand(B, 784) * (rng.rand(B, 784) < 0.3)).astype(np.float32)
+    eps = rng.randn(B, 10).astype(np.float32)
+    Xd, ed = X.astype(np.float64), eps.astype(np.float64)
+    margin = 1e-3
+    nudge = np.random.RandomState(7)
+
+    def clear(x, name):
+        W, b = p["W_" + name], p["b_" + name]
+        for _ in range(200):
+            pre = x @ W + b
+            bad = np.where(np.abs(pre).min(axis=0) < margin)[0]
+            if bad.size == 0:
+                return np.maximum(pre, 0)
+            b[bad] = (b[bad] + nudge.choice([-1.0, 1.0], bad.size) * nudge.uniform(0.004, 0.02, bad.size)).astype(np.float32)
+        raise AssertionError("could not clear layer " + name)
+    h = Xd
+    for i in range(len(cfg.enc_layers)):
+        h = clear(h, "enc%d" % i)
+    zh = clear(h, "zh")
+    clear(h, "ch")
+    mean = zh @ p["W_mean"] + p["b_mean"]
+    logvar = zh @ p["W_logvar"] + p["b_logvar"]
+    h = O.gaussian_reparam(mean, logvar, ed)
+    for i in range(len(cfg.dec_layers)):
+        h = clear(h, "dec%d" % i)
+    # same batch / noise stream as fp32_step_vs_oracle draws from seed 1
+    fp32_step_vs_oracle(kw, B, own_masks=True, p_override=p, seed=1)

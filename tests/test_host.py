@@ -225,6 +225,75 @@ def test_data_parallel_exchange_world2_gloo():
         assert m == pytest.approx([0.5, 2.0])
 
 
+def test_epoch_plan_gives_every_rank_the_same_step_count():
+    """the ragged tail of an epoch must not give one rank an extra step (its gradient all-reduce would
+    pair with another rank's loss all-reduce).  With world > 1 only full global batches are trained."""
+    from dmvae_hip.parallel import epoch_plan
+    order = np.random.RandomState(0).permutation(1999)
+    plans = [epoch_plan(order, 1000, r, 2) for r in range(2)]           # N % B = 999 > B - world
+    assert [p[1] for p in plans] == [1, 1] and [p[2] for p in plans] == [0, 0]
+    assert [len(p[0]) for p in plans] == [500, 500] and plans[0][3] == plans[1][3] == 1.0
+    np.testing.assert_array_equal(np.concatenate([plans[0][0], plans[1][0]]), order[:1000])
+    for world, N, B in ((2, 2500, 1000), (4, 65000, 4096), (8, 65000, 4096)):
+        order = np.arange(N)
+        ps = [epoch_plan(order, B, r, world) for r in range(world)]
+        assert len({p[1] for p in ps}) == 1 and ps[0][1] == N // B
+        assert all(len(p[0]) == (N // B) * (B // world) and p[2] == 0 and p[3] == 1.0 / (N // B) for p in ps)
+        got = np.sort(np.concatenate([p[0] for p in ps]))
+        np.testing.assert_array_equal(got, np.arange((N // B) * B))       # every row of the full batches exactly once
+    with pytest.raises(ValueError):                                       # N < B: not one full global batch
+        epoch_plan(np.arange(65000), 65536, 0, 8)
+    with pytest.raises(ValueError):
+        epoch_plan(np.arange(100), 30, 0, 4)                              # batch not divisible by the world size
+    o, n_full, tail, w = epoch_plan(np.arange(1999), 1000, 0, 1)          # single process: the short last batch stays
+    assert (len(o), n_full, tail, w) == (1999, 1, 999, 0.5)
+
+
+def _epoch_worker(rank, world, port, n_rows, batch, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "deep-mixture-vae_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dmvae_hip.parallel import epoch_plan, GradExchange
+    ex = GradExchange()
+    order = np.random.RandomState(3).permutation(n_rows)
+    try:
+        mine, n_full, tail, weight = epoch_plan(order, batch, rank, world)
+    except ValueError as e:
+        out.put((rank, "raised", str(e)))
+        dist.destroy_process_group()
+        return
+    grad = torch.zeros(8)
+    for step in range(n_full):          # one gradient exchange per step, exactly as train_op issues them
+        grad += float(mine[step * (batch // world)])
+        ex(grad)
+    loss = ex.mean_scalars([float(n_full)])[0]          # the end-of-epoch scalar exchange
+    out.put((rank, n_full, loss))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows,batch", [(1999, 1000), (600, 1000)])
+def test_epoch_loop_world2_gloo_collectives_pair_up(n_rows, batch):
+    """two ranks run the epoch's collective sequence on gloo: N % B > B - world completes with one step each
+    (it used to give rank 0 two steps and hang); N < B raises on every rank instead of silently training nothing."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_epoch_worker, args=(r, 2, port, n_rows, batch, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    if n_rows < batch:
+        assert [r[1] for r in res] == ["raised", "raised"]
+    else:
+        assert [(r[1], r[2]) for r in res] == [(1, 1.0), (1, 1.0)]
+
+
 def test_png_writer_roundtrip(tmp_path):
     """includes/visualization.py writes its figures with its own PNG encoder: decode it by hand."""
     import struct, zlib
