@@ -243,7 +243,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import dmvae_hip
-    from dmvae_hip import StepEngine, GradExchange, prof_enable, prof_collect
+    from dmvae_hip import StepEngine, make_exchange, prof_enable, prof_collect
 
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -254,7 +254,7 @@ def main():
                      seed=1234 + rank, deterministic=args.deterministic, cnn=args.cnn)
     eng.init_parameters(0)
     eng.write_state(lr=args.lr)
-    ex = GradExchange()
+    ex = make_exchange(4 * eng.param.numel())
     ex.broadcast_(eng.param)
     eng.refresh_shadow()
 

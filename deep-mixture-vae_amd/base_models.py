@@ -191,7 +191,7 @@ class DeepMixtureVAE(VAE):
         accumulated on the device and read back once per epoch."""
         assert(self.train_step is not None)
         import torch
-        from dmvae_hip import GradExchange
+        from dmvae_hip import make_exchange
         sess = session or self._session
         eng = self._engine
         world = sess.world_size
@@ -203,7 +203,7 @@ class DeepMixtureVAE(VAE):
             raise ValueError("per-rank batch %d != the size the model was built for (%d)" % (b, eng.max_batch))
         rows = data.device_rows(sess.device)
         perm, n_full, tail, weight = self._epoch_perm(data, sess)
-        ex = GradExchange()
+        ex = make_exchange(4 * eng.param.numel())
         sync = ex if ex.enabled else None
         eng.reset_epoch(n_full + (1 if tail else 0), kl_ratio=kl_ratio, epoch_weight=weight)
         host_noise = self.noise == "host"
@@ -340,7 +340,7 @@ class DeepMixtureVAE(VAE):
         """one epoch of a pretraining stage: epsilon = 0 (so Z = mean), the stage's loss and
         variable list; returns sum(batch_loss) / epoch_len like the reference's loops (:331-350, :395-414)."""
         import torch
-        from dmvae_hip import GradExchange
+        from dmvae_hip import make_exchange
         eng = self._engine
         world = sess.world_size
         b = data.batch_size // world
@@ -348,7 +348,7 @@ class DeepMixtureVAE(VAE):
             raise ValueError("batch_size %d does not match the model (%d per rank x %d ranks)" % (data.batch_size, eng.max_batch, world))
         rows = data.device_rows(sess.device)
         perm, n_full, tail, weight = self._epoch_perm(data, sess)
-        ex = GradExchange()
+        ex = make_exchange(4 * eng.param.numel())
         sync = ex if ex.enabled else None
         # recon-only objective = the full loss at kl_ratio 0: every KL gradient carries the factor r
         eng.reset_epoch(n_full + (1 if tail else 0), kl_ratio=0.0 if stage == "vae" else 1.0, epoch_weight=weight)

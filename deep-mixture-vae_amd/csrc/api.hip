@@ -95,11 +95,8 @@ static int gemm_checked(hipStream_t s, int dtype, int layout, int M, int N, int 
     return gemm_f32_dispatch(s, layout, a, split);
 }
 
-static int gemm_partials(int dtype, int M, int N) {
-    if (dtype == DMVAE_F32) return (M / 64) * (N / 64);
-    const int t = gemm_bf16_tile_m(M, N, 1);
-    return (M / (t / 1000)) * (N / (t % 1000));
-}
+// RECON loss partials live on the 64x64 cell grid of the output whatever tile a kernel uses
+static int gemm_partials(int, int M, int N) { return (M / 64) * (N / 64); }
 
 }  // namespace dmvae
 
@@ -343,6 +340,9 @@ extern "C" int dmvae_plan_bind(dmvae_plan* p, const dmvae_buffers* b) {
     DMVAE_REQUIRE(p->cfg.dtype == DMVAE_F32 || b->param_bf16, "dmvae_plan_bind: bf16 plan needs the bf16 parameter shadow");
     DMVAE_REQUIRE((uintptr_t)b->work % 256 == 0 && (uintptr_t)b->param % 256 == 0 && (uintptr_t)b->grad % 256 == 0, "dmvae_plan_bind: buffers must be 256-byte aligned");
     p->buf = *b;
+    if (p->buf.arena_elems == 0) p->buf.arena_elems = p->param_elems;
+    DMVAE_REQUIRE(p->buf.arena_elems >= p->param_elems && p->buf.arena_elems % 4 == 0, "dmvae_plan_bind: arena_elems %lld < the plan's %lld parameters (or not a multiple of 4)",
+                  (long long)p->buf.arena_elems, (long long)p->param_elems);
     p->bound = true;
     if (!p->side) {   // setup-time resources (never created while enqueueing)
         hipError_t e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
@@ -573,6 +573,7 @@ static int grad_dense(dmvae_plan* p, hipStream_t s, const void* X, int64_t ldx, 
                 if ((int)p->dw_queue.size() >= DMVAE_MAX_GROUP) TRY(launch_dw_queue(p, s, false));    // deep stacks: a full group goes out early
                 GemmArgs a;
                 TRY(gemm_checked(s, DMVAE_BF16, DMVAE_GEMM_DW, mm, nn, p->Bp, Xb + mo, ldx, dYb + no, ldy, &es, 1, &a));
+                a.ws = reinterpret_cast<float*>(WS(p, p->o_cs)); a.ws_elems = p->cs_elems;     // bias-gradient slab sums of a 256x256-tile problem
                 p->dw_queue.push_back(a);
             }
         }
@@ -801,8 +802,8 @@ extern "C" int dmvae_plan_update(dmvae_plan* p, void* stream, float grad_scale) 
 }
 extern "C" int dmvae_plan_update_range(dmvae_plan* p, void* stream, float grad_scale, int64_t lo, int64_t hi) {
     DMVAE_REQUIRE(p && p->bound, "dmvae_plan_update_range: plan not bound");
-    DMVAE_REQUIRE(lo >= 0 && hi > lo && hi <= p->param_elems && lo % 4 == 0 && hi % 4 == 0,
-                  "dmvae_plan_update_range: [%lld, %lld) must be a 4-aligned range of the %lld-element arena", (long long)lo, (long long)hi, (long long)p->param_elems);
+    DMVAE_REQUIRE(lo >= 0 && hi > lo && hi <= p->buf.arena_elems && lo % 4 == 0 && hi % 4 == 0,
+                  "dmvae_plan_update_range: [%lld, %lld) must be a 4-aligned range of the %lld-element arena", (long long)lo, (long long)hi, (long long)p->buf.arena_elems);
     hipStream_t s = (hipStream_t)stream;
     AdamArgs a;
     a.n = hi - lo; a.p = p->buf.param + lo; a.g = p->buf.grad + lo; a.m = p->buf.m + lo; a.v = p->buf.v + lo;
@@ -992,7 +993,7 @@ extern "C" int dmvae_debug_set_tile(int bm, int bn) {
 }
 
 extern "C" int dmvae_debug_set_knob(int which, int value) {
-    DMVAE_REQUIRE(which >= 0 && which <= 5, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, 3 = ring depth policy, 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles");
+    DMVAE_REQUIRE(which >= 0 && which <= 6, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, 3 = ring depth policy, 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy");
     gemm_bf16_set_knob(which, value);
     return 0;
 }

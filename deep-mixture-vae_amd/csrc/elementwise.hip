@@ -99,6 +99,8 @@ int colsum_prepare(int64_t max_n) {      // called from plan bind / first use, n
     return 0;
 }
 
+float* colsum_global_scratch(int64_t* elems) { *elems = g_colsum_ws_elems; return g_colsum_ws; }
+
 int colsum_launch(hipStream_t s, int in_dtype, const void* in, int64_t ld, int M, int N, float* out, float* ws, int64_t ws_elems) {
     const int strips = (N + 255) / 256;
     const double bytes = (double)M * N * (in_dtype == DMVAE_BF16 ? 2 : 4);

@@ -49,7 +49,7 @@
 #include <string>
 #include <vector>
 
-#include "kernels.h"
+#include "gemm_tile.h"
 
 __device__ unsigned long long g_mid[2048];           // DMVAE_ABLATE == 6 builds only: end of each workgroup's K loop
 // Measurement-only builds (tools/ablate.sh -> a separately named .so, never the product library):
@@ -59,154 +59,6 @@ __device__ unsigned long long g_mid[2048];           // DMVAE_ABLATE == 6 builds
 #endif
 
 namespace dmvae {
-
-constexpr int BK = 64;
-
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-
-// swizzled 16-byte chunk of a k-contiguous tile row (8 chunks per 128-B row)
-__device__ __forceinline__ int swz_kc(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
-// swizzled chunk of an n-contiguous tile row k; C = tile columns (128 -> 16 chunks, 64 -> 8 chunks)
-template <int C>
-__device__ __forceinline__ int swz_nc(int k, int chunk) {
-    if constexpr (C == 128) return chunk ^ ((((k & 3) | (((k >> 3) & 1) << 2))) << 1);
-    else return chunk ^ (((((k >> 1) & 1) | (((k >> 3) & 1) << 1))) << 1);
-}
-
-// Per-lane source BYTE offsets (relative to the tile origin) of the R/32 loads of one operand
-// tile; loop invariant, computed once.
-//   KC : tile [R rows][64 k]   : a wave instruction covers 8 rows x 128 B
-//   !KC: tile [64 k][R cols]   : R = 128: 4 k-rows x 256 B;  R = 64: 8 k-rows x 128 B
-// BKT = K depth of the tile: 64, or 32 for the n-contiguous (dW) operands only (half the k-rows).
-template <int R, bool KC, int NW, int BKT>
-__device__ __forceinline__ void stage_offsets(int64_t ld, int wave, int lane, unsigned (&off)[R * BKT / (512 * NW)]) {
-    static_assert(BKT == 64 || !KC, "a k-contiguous tile row is 64 elements");
-#pragma unroll
-    for (int i = 0; i < R * BKT / (512 * NW); ++i) {
-        int row, c;
-        if constexpr (KC) {
-            row = i * (8 * NW) + wave * 8 + (lane >> 3);
-            c = swz_kc(row, lane & 7);
-        } else if constexpr (R == 128) {
-            row = i * (4 * NW) + wave * 4 + (lane >> 4);
-            c = swz_nc<128>(row, lane & 15);
-        } else {
-            row = i * (8 * NW) + wave * 8 + (lane >> 3);
-            c = swz_nc<64>(row, lane & 7);
-        }
-        off[i] = 2u * (unsigned)(row * (int)ld + c * 8);
-    }
-}
-
-// LDS-DMA of one operand tile: NL wave instructions of 64 lanes x 16 B each,
-//   LDS[lds + stride*i + lane*16 ..) <- *(tile + off[i])        (i < NL; stride = 1 KiB x waves)
-// tile = wave-uniform pointer (SGPR pair), off = per-lane 32-bit byte offsets, lds = wave-uniform
-// LDS byte address of this wave's first chunk (a pass of all waves covers 1 KiB x waves for every
-// tile shape).  M0 (the DMA's LDS base) is compiler-reserved: saved/restored in the statement.
-__device__ __forceinline__ void glds_tile(const void* tile, const unsigned (&off)[1], unsigned lds, unsigned) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "s"(tile), "v"(off[0]), "s"(lds)
-        : "memory");
-}
-__device__ __forceinline__ void glds_tile(const void* tile, const unsigned (&off)[2], unsigned lds, unsigned stride) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
-        "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "s"(tile), "v"(off[0]), "v"(off[1]), "s"(lds), "s"(lds + stride)
-        : "memory");
-}
-__device__ __forceinline__ void glds_tile(const void* tile, const unsigned (&off)[4], unsigned lds, unsigned stride) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
-        "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
-        "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
-        "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "s"(tile), "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(lds), "s"(lds + stride), "s"(lds + 2u * stride), "s"(lds + 3u * stride)
-        : "memory");
-}
-
-// LDS element offsets of the fragment for index i0 + (lane & 15), k = ks*32 + 8*(lane >> 4) .. +7
-// inside its operand tile (loop invariant): {lo, hi}; a k-contiguous operand needs one
-// ds_read_b128 (lo only), an n-contiguous one two transposing reads.
-template <int R, bool KC>
-__device__ __forceinline__ void frag_offsets(int i0, int ks, int lane, unsigned short& lo, unsigned short& hi) {
-    const int li = lane & 15, g = lane >> 4;
-    if constexpr (KC) {
-        const int row = i0 + li;
-        lo = (unsigned short)(row * 64 + swz_kc(row, ks * 4 + g) * 8);
-        hi = 0;
-    } else {
-        const int q = li >> 2, p = li & 3;
-        const int k0 = ks * 32 + g * 8 + q, k1 = k0 + 4;
-        const int c = (i0 >> 3) + (p >> 1);
-        lo = (unsigned short)(k0 * R + swz_nc<R>(k0, c) * 8 + (p & 1) * 4);
-        hi = (unsigned short)(k1 * R + swz_nc<R>(k1, c) * 8 + (p & 1) * 4);
-    }
-}
-template <bool KC>
-__device__ __forceinline__ bf16x8 read_frag(const bf16_t* s, unsigned lo, unsigned hi) {
-    if constexpr (KC) {
-        const s16x8 v = *reinterpret_cast<const s16x8*>(s + lo);
-        return __builtin_bit_cast(bf16x8, v);
-    } else {
-        const s16x4 l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(s + lo));
-        const s16x4 h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(s + hi));
-        const s16x8 v = __builtin_shufflevector(l, h, 0, 1, 2, 3, 4, 5, 6, 7);
-        return __builtin_bit_cast(bf16x8, v);
-    }
-}
-
-// TF-Adam on four consecutive arena elements whose gradient g[0..3] is in registers
-// (DMVAE_EPI_ADAM, and the extra prior-table segment of the same launch).
-__device__ __forceinline__ void adam_quad(const dmvae_adam_ctx& c, int64_t off, const float (&g)[4]) {
-    const dmvae_state* st = reinterpret_cast<const dmvae_state*>(c.state);
-    const float lr_t = st->lr_t;
-    float4 p = *reinterpret_cast<const float4*>(c.param + off);
-    float4 m = *reinterpret_cast<const float4*>(c.m + off);
-    float4 v = *reinterpret_cast<const float4*>(c.v + off);
-    float* pp = &p.x; float* mp = &m.x; float* vp = &v.x;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) adam_elem(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);
-    *reinterpret_cast<float4*>(c.param + off) = p;
-    *reinterpret_cast<float4*>(c.m + off) = m;
-    *reinterpret_cast<float4*>(c.v + off) = v;
-    if (c.param_bf16) {
-        uint2 q;
-        q.x = pack2bf(p.x, p.y);
-        q.y = pack2bf(p.z, p.w);
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(c.param_bf16) + off) = q;
-    }
-    if (c.store_grad) *reinterpret_cast<float4*>(c.grad + off) = make_float4(g[0], g[1], g[2], g[3]);
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// XCD-aware order (speed only, never correctness): workgroups are dealt round-robin over the 8
-// XCDs, so ids b and b+8 share an L2.  Of the workgroup ids [gstart, gend), XCD x owns those with
-// id & 7 == x; give each XCD a CONTIGUOUS run of work items: returns the item index in
-// [0, gend - gstart) of workgroup gid (a bijection for any range).
-__device__ __forceinline__ int xcd_run_index(const int gid, const int gstart, const int gend) {
-    const int xcd = gid & 7;
-    int run0 = 0;                                        // items owned by the XCD labels below ours
-    for (int y = 0; y < xcd; ++y) {
-        const int first = gstart + ((y - gstart) & 7);
-        run0 += first < gend ? ((gend - 1 - first) >> 3) + 1 : 0;
-    }
-    return run0 + ((gid - (gstart + ((xcd - gstart) & 7))) >> 3);
-}
 
 // One output tile of one GEMM problem.  bid_raw = tile id within the problem, nwg = number of
 // workgroups of the launch when the launch is this single problem (XCD-aware remap), else 0.
@@ -525,7 +377,10 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
         float* red = reinterpret_cast<float*>(smem);
         lds_barrier();                                           // every wave is done reading the parked tile (no wait for the global stores)
         const float t = block_sum_waves<NW>(loss, red);
-        if (tid == 0) a.epi.partials[bid_raw] = t;
+        // partials live on the 64x64 cell grid of the output (dmvae_gemm_partials is tile independent): the tile's sum
+        // goes to its first cell, zeros to its others
+        constexpr int CM = BM / 64, CN = BN / 64;
+        if (tid < CM * CN) a.epi.partials[(tm * CM + tid / CN) * (a.N / 64) + tn * CN + tid % CN] = tid == 0 ? t : 0.f;
     }
 }
 
@@ -635,7 +490,7 @@ static int g_group_m = 0;                   // tuning knob (dmvae_debug_set_knob
 // supertiles gm tile-rows high, so its L2 sees ~gm A panels (BM x K each) and ~R/gm B panels
 // (BN x K each); fabric traffic ~ gm*BM + (R/gm)*BN is least at gm = sqrt(R*BN/BM).  Measured on
 // the step (tools/knob_ab.py 0 ...): fixed 8 -> 0.3356 ms, 4 (= this rule for N = 512) -> 0.3300 ms.
-static int auto_group_m(int tiles_m, int tiles_n, int bm, int bn, double run = 0.0) {
+int gemm_auto_group_m(int tiles_m, int tiles_n, int bm, int bn, double run) {
     if (g_group_m > 0) return g_group_m;
     const double R = run > 0.0 ? run : std::max(1.0, tiles_m * (double)tiles_n / 8.0);
     int gm = (int)(std::sqrt(R * bn / bm) + 0.5);
@@ -758,7 +613,7 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
         g.start[n] = total;
         g.kind[n] = kind;
         g.p[n] = probs[i];
-        g.p[n].group_m = auto_group_m(probs[i].M / (kind == 2 ? 64 : 128), probs[i].N / (kind == 0 ? 128 : 64),
+        g.p[n].group_m = gemm_auto_group_m(probs[i].M / (kind == 2 ? 64 : 128), probs[i].N / (kind == 0 ? 128 : 64),
                                       kind == 2 ? 64 : 128, kind == 0 ? 128 : 64);
         total += tiles(probs[i], kind);
         flops += 2.0 * probs[i].M * probs[i].N * (double)probs[i].K;
@@ -780,7 +635,7 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
                 g.cls_end[i] = g.start[hi];
                 const int kind = g.kind[i], bm = kind == 2 ? 64 : 128, bn = kind == 0 ? 128 : 64;
                 const int t = g.start[i + 1] - g.start[i];
-                g.p[i].group_m = auto_group_m(g.p[i].M / bm, g.p[i].N / bn, bm, bn, std::min<double>(t, run));
+                g.p[i].group_m = gemm_auto_group_m(g.p[i].M / bm, g.p[i].N / bn, bm, bn, std::min<double>(t, run));
             }
             lo = hi;
         }
@@ -823,7 +678,30 @@ int gemm_bf16_grouped(hipStream_t s, int layout, const GemmArgs* probs, int npro
     set_error("dmvae_gemm_grouped: layout %d with epilogue %d is not instantiated", layout, epi);
     return DMVAE_EUNSUPPORTED;
 }
-int gemm_bf16_grouped_dw(hipStream_t s, const GemmArgs* probs, int nprob) { return gemm_bf16_grouped(s, DMVAE_GEMM_DW, probs, nprob, nullptr); }
+// dW problems large enough for the 256x256 macro tile (gemm_bf16_256.hip) leave the group: each is a launch of its own
+// (its grid covers the chip by itself), with the bias gradient from slab column sums and -- under ctx -- its Adam
+// update.  Returns the problems that stay grouped.
+static int peel_large_dw(hipStream_t s, const GemmArgs* probs, int nprob, const dmvae_adam_ctx* ctx, std::vector<GemmArgs>& rest) {
+    for (int i = 0; i < nprob; ++i) {
+        const GemmArgs& p = probs[i];
+        if (p.k_split == p.K && gemm_bf16_256_ok(DMVAE_GEMM_DW, p.epi.kind, p.M, p.N, p.K, p.conv_c != 0)) {
+            const int rc = gemm_bf16_256_launch(s, DMVAE_GEMM_DW, p, ctx);
+            if (rc) return rc;
+        } else {
+            rest.push_back(p);
+        }
+    }
+    return 0;
+}
+int gemm_bf16_grouped_dw(hipStream_t s, const GemmArgs* probs, int nprob) {
+    if (nprob < 1 || nprob > DMVAE_MAX_GROUP) { set_error("dmvae_gemm_grouped_dw: 1..%d problems", DMVAE_MAX_GROUP); return DMVAE_EINVAL; }
+    std::vector<GemmArgs> rest;
+    for (int i = 0; i < nprob; ++i)
+        if (probs[i].epi.kind != DMVAE_EPI_STORE_F32) return gemm_bf16_grouped(s, DMVAE_GEMM_DW, probs, nprob, nullptr);   // (reports the error)
+    const int rc = peel_large_dw(s, probs, nprob, nullptr, rest);
+    if (rc) return rc;
+    return rest.empty() ? 0 : gemm_bf16_grouped(s, DMVAE_GEMM_DW, rest.data(), (int)rest.size(), nullptr);
+}
 // the dW group with the Adam update in the epilogue (every problem's epilogue kind = DMVAE_EPI_ADAM)
 int gemm_bf16_grouped_dw_adam(hipStream_t s, const GemmArgs* probs, int nprob, const dmvae_adam_ctx& ctx) {
     if (nprob < 1 || nprob > DMVAE_MAX_GROUP) { set_error("dmvae_gemm_grouped_dw_adam: 1..%d problems", DMVAE_MAX_GROUP); return DMVAE_EINVAL; }
@@ -833,7 +711,21 @@ int gemm_bf16_grouped_dw_adam(hipStream_t s, const GemmArgs* probs, int nprob, c
         set_error("dmvae_gemm_grouped_dw_adam: null arena / state, or a segment that is not a multiple of 4 elements");
         return DMVAE_EINVAL;
     }
-    return grouped_launch<DMVAE_GEMM_DW, DMVAE_EPI_ADAM>(s, probs, nprob, &ctx);
+    std::vector<GemmArgs> rest;
+    dmvae_adam_ctx c1 = ctx;
+    c1.seg_n = 0;                                   // the extra arena segment (prior tables) stays with the grouped launch
+    const int rc = peel_large_dw(s, probs, nprob, &c1, rest);
+    if (rc) return rc;
+    if (!rest.empty()) return grouped_launch<DMVAE_GEMM_DW, DMVAE_EPI_ADAM>(s, rest.data(), (int)rest.size(), &ctx);
+    if (ctx.seg_n > 0) {                            // nothing left to ride on: the segment's update as the stand-alone kernel (same bits)
+        AdamArgs a;
+        a.n = ctx.seg_n; a.p = ctx.param + ctx.seg_off; a.g = ctx.grad + ctx.seg_off; a.m = ctx.m + ctx.seg_off; a.v = ctx.v + ctx.seg_off;
+        a.pb = ctx.param_bf16 ? reinterpret_cast<bf16_t*>(ctx.param_bf16) + ctx.seg_off : nullptr;
+        a.lr = 0.f; a.b1 = ctx.beta1; a.b2 = ctx.beta2; a.eps = ctx.epsilon; a.gscale = ctx.grad_scale; a.zero_grad = 0;
+        a.t_host = ~0ull; a.st = reinterpret_cast<const dmvae_state*>(ctx.state);
+        return adam_launch(s, a);
+    }
+    return 0;
 }
 
 static int g_force_tile = 0;   // debug override (dmvae_debug_set_tile): BM*1000+BN, 0 = heuristic
@@ -847,6 +739,7 @@ void gemm_bf16_set_knob(int which, int v) {
     if (which == 3) g_deep = v;
     if (which == 4) g_grouped_cls = v;
     if (which == 5) g_conv_short = v;
+    if (which == 6) gemm_bf16_256_set_policy(v);
 }
 
 // Tile choice, BM*1000+BN.  These GEMMs run at the per-CU L2->LDS streaming rate, so the figure
@@ -883,7 +776,7 @@ static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split) {
                             (LAYOUT == DMVAE_GEMM_DW && EPI == DMVAE_EPI_ATOMIC_F32);
         if constexpr (ok) {
             if (LAYOUT == DMVAE_GEMM_DW) t = 64 * 1000 + (a.N % 128 == 0 ? 128 : 64);   // a tile row stays inside one tap
-            a.group_m = auto_group_m(a.M / (t / 1000), a.N / (t % 1000), t / 1000, t % 1000);
+            a.group_m = gemm_auto_group_m(a.M / (t / 1000), a.N / (t % 1000), t / 1000, t % 1000);
             if constexpr (LAYOUT == DMVAE_GEMM_DW) {
                 if (t == 64128) return launch_conv<64, 128, LAYOUT, EPI, 3>(s, a, split);
                 if (g_conv_short == 2) return launch_conv<64, 64, LAYOUT, EPI, 3>(s, a, split);     // 48 KiB ring -> three workgroups per CU
@@ -909,7 +802,8 @@ static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split) {
     //  17.1 vs 19.0 us; whole step at B = 16384: 1.0753 vs 1.0706 ms, at B = 8192 / D 256 / K 50: 0.8079 vs
     //  0.7922 ms.  Two resident workgroups overlapping their load / compute / store phases beat the
     //  smaller intake of one.)
-    a.group_m = auto_group_m(a.M / (t / 1000), a.N / (t % 1000), t / 1000, t % 1000);
+    if (split == 1 && gemm_bf16_256_ok(LAYOUT, EPI, a.M, a.N, a.K, false)) return gemm_bf16_256_launch(s, LAYOUT, a);
+    a.group_m = gemm_auto_group_m(a.M / (t / 1000), a.N / (t % 1000), t / 1000, t % 1000);
     const long wgs = (long)(a.M / (t / 1000)) * (a.N / (t % 1000)) * split;
     // one workgroup per CU at most -> a single deep ring (more bytes in flight); else two shallow ones
     const bool deep = g_deep < 0 ? wgs <= 320 : g_deep == 1;

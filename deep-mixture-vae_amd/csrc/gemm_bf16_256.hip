@@ -1,0 +1,348 @@
+// 256x256 macro-tile bf16 MFMA GEMM for gfx950 -- the large dense layers (M, N >= 2048: the 4096-wide
+// stack of BASELINE.json's configs[4], the 4096-column [z|c]-hidden layer of the MNIST-shaped configs).
+// Same three operand layouts and fused epilogues as gemm_bf16.hip (tf.layers.dense forward / dX / dW of
+// code/base_models.py:221-248,279-293 and their tf.gradients, :110).
+//
+// Why a second kernel: the 64..128-wide tiles of gemm_bf16.hip run at the CU's L2 -> LDS intake (~70 GB/s per CU,
+// DESIGN.md section 6); a 128x128 tile gives 64 flop per intake byte = a ~1.15 PFLOP/s ceiling.  A 256x256 tile
+// gives 128 flop/B.  It needs 128 KiB of LDS, so there is ONE workgroup per CU, and the load / compute overlap that
+// two resident workgroups gave has to happen INSIDE the workgroup:
+//
+//   * 8 waves = 2 (M) x 4 (N); wave (wr, wc) owns rows {ai*128 + wr*64 + 0..63 : ai = 0, 1} x cols wc*64 + 0..63
+//     (32 accumulator tiles of 16x16 = 128 VGPRs).  Waves w and w + 4 share a SIMD.
+//   * a K tile (64 deep) is FOUR half-tiles of 16 KiB: A-lo, B-lo, B-hi, A-hi (128 rows / columns each); LDS holds two
+//     K tiles (8 half-tile buffers).  One K tile = four PHASES per wave; phase p = the 16 MFMAs of one quadrant
+//     (64 rows x 32 cols x 64 k) behind the LDS fragment reads it needs:
+//         p0: read a <- A-lo (8 fragments), b0 <- B (4)   Q(0,0)        p2: read a <- A-hi (8)   Q(1,1)
+//         p1: read b1 <- B (4)                           Q(0,1)        p3: (b0 still in registers) Q(1,0)
+//     so A-hi is not needed before p2, and every phase issues ONE half-tile of LDS-DMA (2 instructions per wave),
+//     LOOKAHEAD = 6 half-tiles (96 KiB) ahead of its consumption.
+//   * the two wave groups (wr = 0 / wr = 1) run STAGGERED by one barrier: a phase is
+//         [fragment reads, DMA issue, counted vmcnt]  s_barrier  [16 MFMAs]  s_barrier
+//     and group 1 executes one extra barrier up front, so in every barrier interval one wave of each SIMD multiplies
+//     while its partner reads / issues / waits -- the matrix pipe of every SIMD alternates between its two waves.
+//
+// Hazards (g = global barrier count; group 0's phase q sits between barriers 2q-1 .. 2q+1, group 1's one later):
+//   RAW  half-tile s (stream order A-lo, B-lo, B-hi, A-hi per K tile) is first read in phase c(s) >= s - 2 (B-hi of
+//        tile t: c = 4t = s - 2).  Every wave retires its share of s with vmcnt in phase s - 3 BEFORE that phase's
+//        first barrier; both groups have passed that barrier before any read of phase s - 2 starts.  After the
+//        wait LOOKAHEAD - 3 half-tiles stay in flight: s_waitcnt vmcnt(6).
+//   WAR  s overwrites the buffer of s - 8, last read in phase c' <= s - 8; it is issued in phase s - 6, and the
+//        reads of phase c' are complete (lgkmcnt(0) in front of the MFMAs) before group 1 passes barrier 2c' + 2,
+//        which group 0 passes before its phase c' + 2 = s - 6 issues.
+//   The last 6 issues of a tile run past the K range: they re-load the last K tile into buffers nobody reads again
+//   (keeps the vmcnt arithmetic uniform; 96 KiB of L2 hits per 256x256 tile).
+// Epilogue: every wave parks a 64x64 fp32 block in its PRIVATE 16 KiB of the idle LDS (XOR-swizzled, conflict-free)
+// and re-reads it row-contiguous: 128..256-byte row segments per 16 lanes -> the fused epilogues of
+// gemm_epilogue.h, or the TF-Adam update on the gradient quad (DMVAE_EPI_ADAM).
+#include <algorithm>
+#include <string>
+#include <type_traits>
+
+#include "gemm_tile.h"
+
+namespace dmvae {
+
+constexpr int HALF_ELEMS = 128 * BK;     // one half-tile: 128 rows (or columns) x 64 k of bf16 = 16 KiB
+constexpr int LOOKAHEAD = 6;             // half-tiles issued ahead of the phase that consumes them
+template <int V> using IC = std::integral_constant<int, V>;
+
+// Bias gradient of a dW problem: db[n] = sum_k dY[k][n].  The smaller tiles get it from a ones-operand MFMA in the
+// first tile row (gemm_bf16.hip); with ONE 256x256 tile per CU that would make a sixteenth of the tiles 12 % longer
+// and the whole launch with them.  Here: colsum_slabs_kernel sums 64 row slabs of dY (16-B loads, fixed order) into
+// part[slab][n]; the dW launch's extra workgroups add the slabs in ascending order and store db / apply its Adam.
+struct BiasSeg {
+    const float* part; int nslab; int n;      // part[nslab][n]
+    float* out;                               // db in the gradient arena (ADAM: locates the arena offset; written only when store_grad)
+};
+
+__global__ __launch_bounds__(256) void colsum_slabs_kernel(const bf16_t* in, int64_t ld, int rows, int rows_per_slab, int N, float* part) {
+    __shared__ float red[4][512 + 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 512 + lane * 8;
+    const int r0 = blockIdx.y * rows_per_slab, r1 = min(rows, r0 + rows_per_slab);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (n < N)
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const uint4 q = *reinterpret_cast<const uint4*>(in + (int64_t)r * ld + n);
+            const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[2 * j] += __uint_as_float(w[j] << 16);
+                s[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = s[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 512; c += 256)
+        if (blockIdx.x * 512 + c < N)
+            part[(int64_t)blockIdx.y * N + blockIdx.x * 512 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+template <int LAYOUT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(GemmArgs a, dmvae_adam_ctx ac, int ntiles, BiasSeg bs) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[8 * HALF_ELEMS];       // 128 KiB: 2 K tiles x {A-lo, A-hi, B-lo, B-hi}
+    constexpr bool A_KC = (LAYOUT != DMVAE_GEMM_DW);
+    constexpr bool B_KC = (LAYOUT == DMVAE_GEMM_DX);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    if constexpr (LAYOUT == DMVAE_GEMM_DW) {
+        if ((int)blockIdx.x >= ntiles) {         // extra workgroups: the bias gradient from its slab partials (+ its Adam update)
+            for (int q = ((int)blockIdx.x - ntiles) * 512 + tid; q < bs.n / 4; q += ((int)gridDim.x - ntiles) * 512) {
+                float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int sl = 0; sl < bs.nslab; ++sl) {
+                    const float4 p4 = *reinterpret_cast<const float4*>(bs.part + (int64_t)sl * bs.n + 4 * q);
+                    g4.x += p4.x; g4.y += p4.y; g4.z += p4.z; g4.w += p4.w;
+                }
+                if constexpr (EPI == DMVAE_EPI_ADAM) {
+                    const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+                    adam_quad(ac, (bs.out - ac.grad) + 4 * q, gv);
+                } else {
+                    *reinterpret_cast<float4*>(bs.out + 4 * q) = g4;
+                }
+            }
+            return;
+        }
+    }
+
+    // XCD-aware tile order, as in gemm_bf16.hip: a contiguous run of tile ids per XCD, walked in supertiles
+    const int tiles_n = a.N / 256, tiles_m = a.M / 256;
+    const int bid = xcd_run_index((int)blockIdx.x, 0, ntiles);
+    int tm, tn;
+    {
+        const int gm_max = a.group_m;
+        const int gsz = gm_max * tiles_n, grp = bid / gsz, first = grp * gm_max;
+        const int gm = min(tiles_m - first, gm_max), in = bid - grp * gsz;
+        tm = first + in % gm;
+        tn = in / gm;
+    }
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int nk = a.K / BK;
+
+    const bf16_t* Ag = reinterpret_cast<const bf16_t*>(a.A) + (A_KC ? (int64_t)m0 * a.lda : (int64_t)m0);
+    const bf16_t* Bg = reinterpret_cast<const bf16_t*>(a.B) + (B_KC ? (int64_t)n0 * a.ldb : (int64_t)n0);
+    const int64_t stepA = A_KC ? (int64_t)BK : (int64_t)BK * a.lda;
+    const int64_t stepB = B_KC ? (int64_t)BK : (int64_t)BK * a.ldb;
+    const int64_t hiA = A_KC ? (int64_t)128 * a.lda : (int64_t)128;     // A-hi relative to A-lo
+    const int64_t hiB = B_KC ? (int64_t)128 * a.ldb : (int64_t)128;
+
+    // loop-invariant per-lane addressing
+    unsigned goA[2], goB[2];
+    stage_offsets<128, A_KC, 8, BK>(a.lda, wave, lane, goA);
+    stage_offsets<128, B_KC, 8, BK>(a.ldb, wave, lane, goB);
+    unsigned short foA[2][4][2], foB[2][4][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            frag_offsets<128, A_KC>(wr * 64 + i * 16, ks, lane, foA[ks][i][0], foA[ks][i][1]);
+            frag_offsets<128, B_KC>((wc & 1) * 64 + i * 16, ks, lane, foB[ks][i][0], foB[ks][i][1]);
+            // this wave's B half (columns wc*64.. lie in B-lo for wc < 2, in B-hi else) is folded into the offsets
+            foB[ks][i][0] = (unsigned short)(foB[ks][i][0] + (wc >> 1) * HALF_ELEMS);
+            foB[ks][i][1] = (unsigned short)(foB[ks][i][1] + (wc >> 1) * HALF_ELEMS);
+        }
+    }
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)((__attribute__((address_space(3))) bf16_t*)smem) + 1024u * (unsigned)wave);
+
+    f32x4 acc[2][4][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // LDS-DMA of half-tile J (stream order: 0 A-lo, 1 B-lo, 2 B-hi, 3 A-hi) of K tile ts into the buffers of parity PAR
+    auto issue = [&](auto Jc, auto PARc, int ts) {
+        constexpr int J = decltype(Jc)::value, PAR = decltype(PARc)::value;
+        const int tc = ts < nk ? ts : nk - 1;
+        constexpr unsigned buf = 2u * (unsigned)((PAR * 4 + (J == 0 ? 0 : J == 3 ? 1 : J == 1 ? 2 : 3)) * HALF_ELEMS);
+        if constexpr (J == 0) glds_tile(Ag + tc * stepA, goA, lds_w + buf, 8192u);
+        else if constexpr (J == 3) glds_tile(Ag + hiA + tc * stepA, goA, lds_w + buf, 8192u);
+        else if constexpr (J == 1) glds_tile(Bg + tc * stepB, goB, lds_w + buf, 8192u);
+        else glds_tile(Bg + hiB + tc * stepB, goB, lds_w + buf, 8192u);
+    };
+
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    // one phase of K tile t (buffer parity PAR): reads, DMA issue, counted wait | barrier | 16 MFMAs | barrier
+    auto phase = [&](auto Pc, auto PARc, int t) {
+        constexpr int P = decltype(Pc)::value, PAR = decltype(PARc)::value;
+        const bf16_t* At = smem + (PAR * 4 + (P >= 2 ? 1 : 0)) * HALF_ELEMS;
+        const bf16_t* Bt = smem + (PAR * 4 + 2) * HALF_ELEMS;
+        if constexpr (P == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fb0[j][ks] = read_frag<B_KC>(Bt, foB[ks][j][0], foB[ks][j][1]);
+        }
+        if constexpr (P == 1) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fb1[j][ks] = read_frag<B_KC>(Bt, foB[ks][2 + j][0], foB[ks][2 + j][1]);
+        }
+        if constexpr (P == 0 || P == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fa[i][ks] = read_frag<A_KC>(At, foA[ks][i][0], foA[ks][i][1]);
+        }
+        // half-tile (4t + P) + LOOKAHEAD: J = (P + 2) & 3 of K tile t + 1 (P < 2) / t + 2 (P >= 2)
+        issue(IC<(P + 2) & 3>{}, IC<(P < 2 ? 1 - PAR : PAR)>{}, t + (P < 2 ? 1 : 2));
+        wait_vmcnt<2 * (LOOKAHEAD - 3)>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int AI = P >= 2 ? 1 : 0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    // operands swapped (D[row = n][col = m]): a lane owns 4 consecutive n of one m
+                    if constexpr (P == 0 || P == 3)
+                        acc[AI][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[AI][i][j], 0, 0, 0);
+                    else
+                        acc[AI][i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[AI][i][2 + j], 0, 0, 0);
+                }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // prologue: half-tiles 0..5 (K tile 0 whole, A-lo and B-lo of K tile 1); A-lo, B-lo, B-hi of tile 0 landed
+    issue(IC<0>{}, IC<0>{}, 0); issue(IC<1>{}, IC<0>{}, 0); issue(IC<2>{}, IC<0>{}, 0); issue(IC<3>{}, IC<0>{}, 0);
+    issue(IC<0>{}, IC<1>{}, 1); issue(IC<1>{}, IC<1>{}, 1);
+    wait_vmcnt<2 * (LOOKAHEAD - 3)>();
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();       // the stagger: group 1 runs one barrier behind group 0
+    for (int t = 0; t < nk; t += 2) {
+        phase(IC<0>{}, IC<0>{}, t); phase(IC<1>{}, IC<0>{}, t); phase(IC<2>{}, IC<0>{}, t); phase(IC<3>{}, IC<0>{}, t);
+        if (t + 1 < nk) {
+            phase(IC<0>{}, IC<1>{}, t + 1); phase(IC<1>{}, IC<1>{}, t + 1); phase(IC<2>{}, IC<1>{}, t + 1); phase(IC<3>{}, IC<1>{}, t + 1);
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier
+    wait_vmcnt<0>();                                 // the trailing re-loads: every DMA write has landed ...
+    __builtin_amdgcn_s_barrier();                    // ... for every wave, before LDS is reused
+
+    // ---- epilogue: two 64 x 64 fp32 blocks per wave through the wave's private 16 KiB
+    float loss = 0.f;
+    float* st = reinterpret_cast<float*>(smem) + wave * 4096;
+    const int li = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = i * 16 + li, c = j * 4 + g;
+                *reinterpret_cast<f32x4*>(st + r * 64 + ((c ^ (r & 7)) << 2)) = acc[h][i][j];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave, in-order LDS: the block is written
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int r = it * 4 + g, c = li;
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(st + r * 64 + ((c ^ (r & 7)) << 2));
+            float v[4] = {t4[0], t4[1], t4[2], t4[3]};
+            const int m = m0 + h * 128 + wr * 64 + r, n = n0 + wc * 64 + c * 4;
+            if constexpr (EPI == DMVAE_EPI_ADAM) {
+                const int64_t off = (reinterpret_cast<const float*>(a.epi.out) - ac.grad) + (int64_t)m * a.epi.ldo + n;
+                adam_quad(ac, off, v);
+            } else {
+                epilogue_quad<EPI, bf16_t>(a.epi, m, n, v, loss);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next block overwrites
+    }
+    if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
+        float* red = reinterpret_cast<float*>(smem);
+        __syncthreads();
+        const float t = block_sum_waves<8>(loss, red);
+        if (tid < 16) a.epi.partials[(tm * 4 + tid / 4) * (a.N / 64) + tn * 4 + tid % 4] = tid == 0 ? t : 0.f;   // 64x64 cell grid, see gemm_bf16.hip
+    }
+}
+
+// ---------------------------------------------------------------- host side
+static int g_policy256 = 1;     // tuning knob (dmvae_debug_set_knob 6): 0 never, 1 when the grid fills the chip, 2 whenever the shape divides
+void gemm_bf16_256_set_policy(int v) { g_policy256 = v; }
+
+// The 256x256 kernel takes a problem when M, N divide by 256 and the grid covers (most of) the 256 CUs; below
+// that the smaller tiles' higher workgroup count wins (gemm_bf16.hip).  K >= 512: shorter K loops do not amortise
+// the 6-half-tile prologue and the epilogue of a one-workgroup-per-CU tile.
+bool gemm_bf16_256_ok(int layout, int epi, int M, int N, int K, bool conv) {
+    if (g_policy256 == 0 || conv) return false;
+    const bool inst = (layout == DMVAE_GEMM_FWD && (epi == DMVAE_EPI_BIAS_RELU || epi == DMVAE_EPI_BIAS_RECON || epi == DMVAE_EPI_STORE_F32)) ||
+                      (layout == DMVAE_GEMM_DX && (epi == DMVAE_EPI_RELU_MASK || epi == DMVAE_EPI_STORE_F32)) ||
+                      (layout == DMVAE_GEMM_DW && (epi == DMVAE_EPI_STORE_F32 || epi == DMVAE_EPI_ADAM));
+    if (!inst || M % 256 || N % 256 || K % BK) return false;
+    if (g_policy256 == 2) return true;
+    const long tiles = (long)(M / 256) * (N / 256);
+    return tiles >= 192 && K >= 512;
+}
+
+template <int LAYOUT, int EPI>
+static int launch256(hipStream_t s, const GemmArgs& a0, const dmvae_adam_ctx* ctx) {
+    GemmArgs a = a0;
+    const int tiles = (a.M / 256) * (a.N / 256);
+    a.group_m = gemm_auto_group_m(a.M / 256, a.N / 256, 256, 256, std::max(1.0, std::min(tiles, 256) / 8.0));
+    dmvae_adam_ctx c{};
+    if (ctx) c = *ctx;
+    BiasSeg bs{};
+    int extra = 0;
+    if (LAYOUT == DMVAE_GEMM_DW && a.epi.out2) {      // bias gradient: slab partials now, the sum (and its Adam) in the launch's extra workgroups
+        float* ws = a.ws;
+        int64_t ws_elems = a.ws_elems;
+        if (!ws) {
+            const int rc = colsum_prepare(a.N);
+            if (rc) return rc;
+            ws = colsum_global_scratch(&ws_elems);
+        }
+        constexpr int SLABS = 64;
+        int rps = std::max(8, (a.K + SLABS - 1) / SLABS);
+        const int nslab = (a.K + rps - 1) / rps;
+        if ((int64_t)nslab * a.N > ws_elems) { set_error("gemm_bf16_256: bias-gradient scratch too small (%lld < %lld floats)", (long long)ws_elems, (long long)nslab * a.N); return DMVAE_ESTATE; }
+        {
+            ProfScope ps(s, "colsum_slabs", (double)a.K * a.N, 2.0 * a.K * a.N + 4.0 * nslab * a.N);
+            hipLaunchKernelGGL(colsum_slabs_kernel, dim3((a.N + 511) / 512, nslab), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(a.B), a.ldb, a.K, rps, a.N, ws);
+        }
+        bs.part = ws; bs.nslab = nslab; bs.n = a.N; bs.out = reinterpret_cast<float*>(a.epi.out2);
+        extra = std::min(8, (a.N / 4 + 511) / 512);
+    }
+    static const std::string nm = [] {
+        char b[64];
+        snprintf(b, sizeof(b), "gemm_bf16_256_kernel<%d, %d>", LAYOUT, EPI);
+        return std::string(b);
+    }();
+    double bytes = 2.0 * ((double)a.M * a.K + (double)a.K * a.N);
+    if (EPI == DMVAE_EPI_ADAM) bytes += ((double)a.M * a.N + (double)bs.n) * (24.0 + (c.param_bf16 ? 2.0 : 0.0) + (c.store_grad ? 4.0 : 0.0));
+    else bytes += ((EPI == DMVAE_EPI_STORE_F32) ? 4.0 : 2.0) * a.M * a.N;
+    ProfScope ps(s, nm.c_str(), 2.0 * a.M * a.N * (double)a.K, bytes);
+    hipLaunchKernelGGL((gemm_bf16_256_kernel<LAYOUT, EPI>), dim3(tiles + extra), dim3(512), 0, s, a, c, tiles, bs);
+    return check_launch("gemm_bf16_256");
+}
+
+int gemm_bf16_256_launch(hipStream_t s, int layout, const GemmArgs& a, const dmvae_adam_ctx* ctx) {
+    const int epi = a.epi.kind;
+    if (a.k_split != a.K) { set_error("gemm_bf16_256: no split-K"); return DMVAE_EINVAL; }
+#define CASE256(L, E) \
+    if (layout == L && epi == E) return launch256<L, E>(s, a, ctx);
+    CASE256(DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_RELU)
+    CASE256(DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_RECON)
+    CASE256(DMVAE_GEMM_FWD, DMVAE_EPI_STORE_F32)
+    CASE256(DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK)
+    CASE256(DMVAE_GEMM_DX, DMVAE_EPI_STORE_F32)
+    CASE256(DMVAE_GEMM_DW, DMVAE_EPI_STORE_F32)
+    CASE256(DMVAE_GEMM_DW, DMVAE_EPI_ADAM)
+#undef CASE256
+    set_error("gemm_bf16_256: layout %d with epilogue %d is not instantiated", layout, epi);
+    return DMVAE_EUNSUPPORTED;
+}
+
+}  // namespace dmvae

@@ -26,6 +26,9 @@ struct GemmArgs {
     // (tap, channel) rows) the shift belongs to the tile's columns instead.
     int conv_p, conv_c;
     dmvae_epilogue epi;
+    // scratch for the bias-gradient column sums of a 256x256-tile dW problem (gemm_bf16_256.hip): >= 64 * N floats,
+    // the plan's own; nullptr = the library's lazily allocated global scratch (not capture-safe on first use)
+    float* ws = nullptr; int64_t ws_elems = 0;
 };
 
 // element offset of K position k (multiple of the tile depth) of a conv-mode A operand

@@ -21,6 +21,11 @@ int gemm_bf16_grouped(hipStream_t s, int layout, const GemmArgs* probs, int npro
 dmvae_finalize_args step_finalize_args(const float* rp, int nr, const float* lp, int nl, float inv_B, void* st, int bump_adam,
                                        float b1, float b2, const float* part, int nblk, int ncol, float* gout);
 int gemm_bf16_tile_m(int M, int N, int split);
+int gemm_auto_group_m(int tiles_m, int tiles_n, int bm, int bn, double run = 0.0);
+// 256x256 macro-tile kernel (gemm_bf16_256.hip): takes the large dense problems, one workgroup per CU
+bool gemm_bf16_256_ok(int layout, int epi, int M, int N, int K, bool conv);
+int gemm_bf16_256_launch(hipStream_t s, int layout, const GemmArgs& a, const dmvae_adam_ctx* ctx = nullptr);
+void gemm_bf16_256_set_policy(int v);
 void gemm_bf16_force_tile(int t);
 void gemm_bf16_set_knob(int which, int v);
 int gemm_f32_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split);
@@ -29,6 +34,7 @@ int latent_launch(hipStream_t s, const dmvae_latent_args* a);
 int adam_launch(hipStream_t s, const AdamArgs& a);
 int adam_finish_launch(hipStream_t s, void* st);
 int colsum_prepare(int64_t max_n);
+float* colsum_global_scratch(int64_t* elems);
 int colsum_launch(hipStream_t s, int in_dtype, const void* in, int64_t ld, int M, int N, float* out, float* ws, int64_t ws_elems);
 int recon_nblocks(int B_pad, int I_pad);
 int recon_launch(hipStream_t s, int act_dtype, int recon_kind, int B, int B_pad, int I, int I_pad, const float* logits, int64_t ldl,

@@ -5,7 +5,8 @@ ImportError if the library is absent.  Nothing in here computes on the CPU."""
 from . import _lib
 from ._lib import lib, check, DmvaeError, LIB_PATH
 from .runtime import Session, StepEngine, default_session, prof_enable, prof_collect, layer_table, latent_eval
-from .parallel import GradExchange, shard_range
+from .parallel import GradExchange, ShardedExchange, make_exchange, shard_range, epoch_plan
 
 __all__ = ["lib", "check", "DmvaeError", "LIB_PATH", "Session", "StepEngine", "default_session",
-           "prof_enable", "prof_collect", "layer_table", "GradExchange", "shard_range"]
+           "prof_enable", "prof_collect", "layer_table", "GradExchange", "ShardedExchange", "make_exchange",
+           "shard_range", "epoch_plan"]

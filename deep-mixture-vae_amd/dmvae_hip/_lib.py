@@ -120,7 +120,7 @@ class Sizes(C.Structure):
 
 class Buffers(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
-                ("param_bf16", C.c_void_p), ("work", C.c_void_p), ("state", C.c_void_p)]
+                ("param_bf16", C.c_void_p), ("work", C.c_void_p), ("state", C.c_void_p), ("arena_elems", C.c_int64)]
 
 
 class ProfRow(C.Structure):

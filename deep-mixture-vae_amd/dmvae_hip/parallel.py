@@ -4,10 +4,26 @@ reference is single-process).
 One process per GPU.  Every loss term is a batch mean of per-row quantities
 (base_models.py:74-79, priors.py:145,199), so with equal shards the global
 gradient is the mean of the per-rank gradients -- prior tables included.  The
-exchange is ONE collective per step on the flat fp32 gradient arena
-(torch.distributed: backend "nccl" = RCCL over xGMI on the GPU box, "gloo" on
-CPU in the tests); the 1/world factor is folded into the Adam kernel
-(grad_scale), so no separate scaling pass touches HBM.
+exchange runs on the flat fp32 gradient arena (torch.distributed: backend "nccl"
+= RCCL over xGMI on the GPU box, "gloo" on CPU in the tests); the 1/world factor
+is folded into the Adam kernel (grad_scale), so no separate scaling pass touches
+HBM.  Two forms (make_exchange picks; DMVAE_DP_MODE=sharded|allreduce overrides):
+
+  sharded    reduce-scatter(SUM) of the gradients -> TF-Adam on the OWNED 1/world
+             slice of the arena (m and v are only ever touched there) ->
+             all-gather of the updated fp32 parameters, bf16 shadow of the gathered
+             slices refreshed locally.  The default for world > 1: the optimizer's
+             HBM traffic (30 B per parameter) is divided by the world size, the wire
+             carries what a ring all-reduce carries.  SURVEY 8(e)'s preferred form.
+  allreduce  ONE all-reduce(SUM), every rank applies the whole update (replicated
+             Adam): the bit-simplest form, kept as the reference the sharded form is
+             tested against (identical bits on the owned slice).
+
+Both come bucketed (three segments of the backward pass, each collective started
+right behind its segment) or as one collective after the whole backward; the
+bucketed form pays three smaller dW grids + host hand-overs per step, so it is
+chosen only when the arena is large enough for the wire time to matter
+(>= 64 MiB, i.e. the 4096-wide configuration; DMVAE_DP_OVERLAP=0|1 overrides).
 """
 import os
 
@@ -79,8 +95,13 @@ class GradExchange:
     # already enqueued on the current stream, not for what comes after), finish() makes the current
     # stream wait for all of them before the update.  Only the last bucket (the trunk, 14 % of the
     # arena) is exposed.  DMVAE_DP_OVERLAP=0 falls back to the single all-reduce.
+    sharded = False
+    _overlap = None           # make_exchange sets it from the arena size; None = the environment switch alone
+
     @property
     def overlap(self):
+        if self._overlap is not None:
+            return self.enabled and self._overlap
         return self.enabled and os.environ.get("DMVAE_DP_OVERLAP", "1") != "0"
 
     def start(self, grad_slice):
@@ -110,3 +131,56 @@ class GradExchange:
             t = t.cuda()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return (t / self.world).tolist()
+
+
+class ShardedExchange(GradExchange):
+    """reduce-scatter -> Adam on the owned shard -> all-gather.  Every range it is given must have a
+    length divisible by 64 * world (StepEngine pads the arenas and rounds the bucket bounds, bucket_bounds)."""
+    sharded = True
+
+    def __init__(self, group=None):
+        super().__init__(group)
+        self.align = 64 * self.world
+
+    def padded(self, n):
+        return (int(n) + self.align - 1) // self.align * self.align
+
+    def bucket_bounds(self, bounds, n_alloc):
+        """bounds = [(lo, hi)] in completion order (StepEngine.grad_buckets: last part of the arena first).  The
+        interior boundaries are rounded UP to the alignment: a bucket then only grows into the part of the arena
+        that was complete EARLIER, so it is still final when its segment ends."""
+        cuts = sorted({lo for lo, _ in bounds} | {hi for _, hi in bounds})
+        rounded = [0] + [min(self.padded(c), n_alloc) for c in cuts[1:-1]] + [n_alloc]
+        out = []
+        for lo, hi in bounds:
+            i = cuts.index(lo)
+            out.append((rounded[i], rounded[i + 1]))
+        return [b for b in out if b[1] > b[0]]
+
+    def owned(self, lo, hi):
+        chunk = (hi - lo) // self.world
+        assert chunk * self.world == hi - lo and chunk % 4 == 0, (lo, hi, self.world)
+        return lo + self.rank * chunk, lo + (self.rank + 1) * chunk
+
+    def reduce_scatter(self, flat, lo, hi, async_op=False):
+        """sum over ranks of flat[lo:hi]; this rank's slice of the result lands IN PLACE at owned(lo, hi)"""
+        slo, shi = self.owned(lo, hi)
+        if not self.enabled:
+            return None
+        return dist.reduce_scatter_tensor(flat[slo:shi], flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def all_gather(self, flat, lo, hi, async_op=False):
+        """every rank's owned slice of flat[lo:hi] to every rank, in place"""
+        slo, shi = self.owned(lo, hi)
+        if not self.enabled:
+            return None
+        return dist.all_gather_into_tensor(flat[lo:hi], flat[slo:shi], group=self.group, async_op=async_op)
+
+
+def make_exchange(param_bytes=0, group=None):
+    """the exchange for this process group: None-like (enabled False) in a world of one"""
+    mode = os.environ.get("DMVAE_DP_MODE", "sharded")
+    ex = ShardedExchange(group) if mode == "sharded" else GradExchange(group)
+    ov = os.environ.get("DMVAE_DP_OVERLAP")
+    ex._overlap = (param_bytes >= 64 * 2 ** 20) if ov is None else ov != "0"
+    return ex

@@ -130,7 +130,10 @@ class StepEngine:
         check(lib.dmvae_plan_sizes(self._plan, C.byref(sz)), "dmvae_plan_sizes")
         self.sizes = sz
         self.batch_pad, self.input_pad = sz.batch_pad, sz.input_pad
-        n = sz.param_elems
+        # arenas padded to a multiple of 64 * world elements: the sharded exchange (parallel.ShardedExchange) cuts
+        # them into world equal slices; the pad stays zero (zero gradient -> zero Adam update)
+        gran = 64 * max(1, self.session.world_size)
+        n = (sz.param_elems + gran - 1) // gran * gran
         self.param = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -139,7 +142,7 @@ class StepEngine:
         self.work = torch.zeros(sz.work_bytes, dtype=torch.uint8, device=dev)
         self.state_t = torch.zeros(C.sizeof(_lib.State), dtype=torch.uint8, device=dev)
         b = _lib.Buffers(ptr(self.param), ptr(self.grad), ptr(self.m), ptr(self.v),
-                         ptr(self.param_bf16), ptr(self.work), ptr(self.state_t))
+                         ptr(self.param_bf16), ptr(self.work), ptr(self.state_t), n)
         check(lib.dmvae_plan_bind(self._plan, C.byref(b)), "dmvae_plan_bind")
         self.tensors = {}
         for i in range(sz.n_tensors):
@@ -297,9 +300,44 @@ class StepEngine:
         check(lib.dmvae_plan_update_range(self._plan, self._stream(), float(grad_scale), int(lo), int(hi)), "dmvae_plan_update_range")
 
     def _step_with_exchange(self, grad_sync, grad_scale, n_valid=None, eps=None, gumbel=None, inv_B=None):
-        """forward + backward + gradient exchange + Adam.  Bucketed and overlapped when the exchange
-        offers start()/wait(): each bucket is updated as soon as its all-reduce has landed, while the
-        later ones are still in flight; else one collective on the whole arena, then one Adam."""
+        """forward + backward + gradient exchange + Adam.  Bucketed and overlapped when the exchange says so
+        (`overlap`): each bucket's collective starts right behind the backward segment that completes it and its
+        Adam runs as soon as its sum has landed, while later buckets are still in flight; else one collective on
+        the whole arena.  Sharded exchange (parallel.ShardedExchange): reduce-scatter, Adam on the owned slice
+        only, all-gather of the updated parameters; else all-reduce + replicated Adam."""
+        n = self.param.numel()
+        if getattr(grad_sync, "sharded", False):
+            if grad_sync.overlap:
+                buckets = grad_sync.bucket_bounds(self.grad_buckets(), n)
+                # the plan's segments complete the UNROUNDED buckets in this order; rounding up keeps that true
+                handles = []
+                for stage in range(3):
+                    self.forward_backward_stage(stage, n_valid, eps, gumbel, inv_B)
+                    if stage < len(buckets):
+                        lo, hi = buckets[stage]
+                        handles.append(grad_sync.reduce_scatter(self.grad, lo, hi, async_op=True))
+                gathers = []
+                for h, (lo, hi) in zip(handles, buckets):
+                    grad_sync.wait(h)
+                    slo, shi = grad_sync.owned(lo, hi)
+                    self.update_range(slo, shi, grad_scale)
+                    gathers.append(grad_sync.all_gather(self.param, lo, hi, async_op=True))
+                grad_sync.finish(gathers)
+            else:
+                buckets = [(0, n)]
+                self.forward_backward(n_valid, eps, gumbel, inv_B)
+                grad_sync.reduce_scatter(self.grad, 0, n)
+                slo, shi = grad_sync.owned(0, n)
+                self.update_range(slo, shi, grad_scale)
+                grad_sync.all_gather(self.param, 0, n)
+            if self.param_bf16 is not None:      # the slices other ranks updated: refresh their bf16 shadow (the owned one is written by Adam)
+                for lo, hi in buckets:
+                    slo, shi = grad_sync.owned(lo, hi)
+                    for a, b in ((lo, slo), (shi, hi)):
+                        if b > a:
+                            check(lib.dmvae_cast_f32_to_bf16(self._stream(), ptr(self.param[a:b]), ptr(self.param_bf16[a:b]), b - a),
+                                  "dmvae_cast_f32_to_bf16")
+            return
         if getattr(grad_sync, "overlap", False):
             buckets = self.grad_buckets()
             handles = []
@@ -423,7 +461,7 @@ class StepEngine:
         # has its own cost.  So the data-parallel step is issued eagerly; DMVAE_DP_GRAPHS=1 keeps the
         # graph form (collectives outside capture) for re-measurement.
         import os
-        if os.environ.get("DMVAE_DP_GRAPHS", "0") != "1":
+        if os.environ.get("DMVAE_DP_GRAPHS", "0") != "1" or getattr(grad_sync, "sharded", False):
             def eager_step():
                 self.train_step(data, perm, None, None, None, 0, True, grad_sync, grad_scale, inv_B)
             self._graph = None

@@ -97,7 +97,8 @@ typedef struct dmvae_epilogue {
 int dmvae_gemm(void* stream, int dtype, int layout, int M, int N, int K,
                const void* A, int64_t lda, const void* B, int64_t ldb,
                const dmvae_epilogue* epi, int split_k);
-/* number of loss partials dmvae_gemm writes for an (M,N) RECON launch */
+/* number of loss partials dmvae_gemm writes for an (M,N) RECON launch: one per 64x64 cell of the output,
+ * whatever tile the kernel uses (a larger tile writes its sum to its first cell and zeros to the others) */
 int dmvae_gemm_partials(int dtype, int M, int N);
 
 /* Grouped weight-gradient GEMMs: n (<= 16) independent DMVAE_GEMM_DW problems
@@ -278,6 +279,9 @@ typedef struct dmvae_buffers {
     void* param_bf16;     /* bf16 shadow (may be NULL when dtype == DMVAE_F32) */
     void* work;           /* work_bytes, 256-byte aligned, zero-initialised by the caller */
     void* state;          /* dmvae_state on the device */
+    int64_t arena_elems;  /* elements allocated for each of param / grad / m / v (/ shadow): >= param_elems; a caller that
+                           * cuts the arenas into equal slices per rank (reduce-scatter -> sharded Adam -> all-gather) pads
+                           * them, and dmvae_plan_update_range then accepts ranges up to this size.  0 = param_elems */
 } dmvae_buffers;
 
 typedef struct dmvae_plan dmvae_plan;
@@ -359,7 +363,9 @@ int dmvae_debug_set_tile(int bm, int bn);
  *             knob 3 = ring depth policy (-1 deep ring when <= 1 workgroup per CU, 0 never, 1 always),
  *             knob 4 = XCD runs of a grouped grid cut per tile-shape class (1) or per problem (0),
  *             knob 5 = conv-mode tiles: >= 1 short-K tiles as 4-wave / 2-slot workgroups (three per CU),
- *                      2 also 3-slot rings for the 64x64 weight-gradient tiles */
+ *                      2 also 3-slot rings for the 64x64 weight-gradient tiles,
+ *             knob 6 = 256x256 macro-tile kernel (csrc/gemm_bf16_256.hip): 0 never, 1 when its grid covers the chip
+ *                      (default), 2 whenever M and N divide by 256 */
 int dmvae_debug_set_knob(int which, int value);
 
 int dmvae_abi_version(void);

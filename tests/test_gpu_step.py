@@ -273,33 +273,65 @@ def test_encode_decode_views():
     np.testing.assert_allclose(eng.view("recon", B).cpu().numpy(), 1 / (1 + np.exp(-xl)), atol=2e-5)
 
 
-def _dp_rank(rank, world, port, overlap, out):
+def _dp_rank(rank, world, port, overlap, out, mode="allreduce"):
     """one data-parallel rank on the shared GPU (gloo carries the collectives in this rehearsal)"""
     import torch.distributed as dist
     for p in (os.path.join(ROOT, "deep-mixture-vae_amd"), os.path.join(ROOT, "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      DMVAE_DP_OVERLAP="1" if overlap else "0")
+                      DMVAE_DP_OVERLAP="1" if overlap else "0", DMVAE_DP_MODE=mode)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import dmvae_oracle as Or
-    from dmvae_hip import StepEngine, GradExchange, shard_range
+    from dmvae_hip import StepEngine, make_exchange, shard_range
     kw, B = dict(input_dim=784, latent_dim=64, n_classes=10), 256
     rng = np.random.RandomState(21)
     X = Or.synthetic_images(B, 784, seed=8)
     lo, hi = shard_range(B, rank, world)
     eng = StepEngine(dtype="fp32", max_batch=hi - lo, mode="exact", **kw)
     eng.init_parameters(3)
-    ex = GradExchange()
-    assert ex.enabled and ex.overlap == overlap
+    ex = make_exchange()
+    assert ex.enabled and ex.overlap == overlap and ex.sharded == (mode == "sharded")
     Xd = torch.as_tensor(X[lo:hi]).cuda()
     for step in range(2):
         eps = rng.randn(B, 64).astype(np.float32)
         ed = torch.as_tensor(eps[lo:hi]).cuda()
         eng.train_step(Xd, None, hi - lo, ed, None, grad_sync=ex, grad_scale=ex.grad_scale, inv_B=world / float(B))
     torch.cuda.synchronize()
-    out.put((rank, eng.param.cpu().numpy(), eng.read_state().adam_t))
+    out.put((rank, eng.param.cpu().numpy(), eng.read_state().adam_t, eng.m.cpu().numpy()))
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_sharded_exchange_equals_allreduce_bit_for_bit(overlap):
+    """reduce-scatter -> Adam on the owned slice -> all-gather leaves, on every rank, exactly the parameters that
+    all-reduce + replicated Adam leaves (two ranks: a + b is the same float either way); the Adam moments are
+    maintained on the owned slice only and equal the replicated ones there."""
+    import socket
+    import torch.multiprocessing as mp
+    res = {}
+    for mode in ("allreduce", "sharded"):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        ctx = mp.get_context("spawn")
+        out = ctx.Queue()
+        procs = [ctx.Process(target=_dp_rank, args=(r, 2, port, overlap, out, mode)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res[mode] = sorted([out.get(timeout=300) for _ in procs], key=lambda t: t[0])
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    ar, sh = res["allreduce"], res["sharded"]
+    np.testing.assert_array_equal(sh[0][1], sh[1][1])            # replicas identical after the all-gather
+    np.testing.assert_array_equal(sh[0][1], ar[0][1])            # and equal to the replicated update
+    n = ar[0][3].size
+    owned_somewhere = np.zeros(n, bool)
+    for r in range(2):
+        touched = sh[r][3] != 0
+        np.testing.assert_array_equal(sh[r][3][touched], ar[r][3][touched])    # m on the slices this rank updated
+        owned_somewhere |= touched
+    assert (owned_somewhere | (ar[0][3] == 0)).all()             # every parameter with a gradient is owned by some rank
+    assert (sh[0][3] != 0).sum() < 0.75 * (ar[0][3] != 0).sum()  # ... and a rank does not maintain the others' moments
 
 
 @pytest.mark.parametrize("overlap", [True, False])
@@ -332,14 +364,14 @@ def test_two_ranks_equal_one_rank_to_fp32_roundoff(overlap):
         one.train_step(Xd, None, B, ed, None)
     torch.cuda.synchronize()
     ref = one.param.cpu().numpy()
-    d = np.abs(res[0][1] - ref)
+    d = np.abs(res[0][1][:ref.size] - ref)          # (the two-rank arenas are padded to 64 * world elements)
     # Adam moves every parameter by ~lr = 2e-3 per step; a round-off difference in a gradient near zero
     # can flip a sign of m/sqrt(v) only where |g| ~ 1e-9, so compare the bulk tightly and the tail loosely
     assert np.percentile(d, 99.9) <= 2e-6, np.percentile(d, 99.9)
     assert d.max() <= 4.1e-3
 
 
-def _rccl_rank(port, overlap, out):
+def _rccl_rank(port, overlap, out, mode="allreduce"):
     """a world of ONE rank on RCCL: every collective of the data-parallel step is the real library
     call (an identity), on the streams and buffers the N > 1 job uses"""
     import torch.distributed as dist
@@ -347,16 +379,16 @@ def _rccl_rank(port, overlap, out):
     if p not in sys.path:
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
-                      DMVAE_DP_FORCE="1", DMVAE_DP_OVERLAP="1" if overlap else "0")
+                      DMVAE_DP_FORCE="1", DMVAE_DP_OVERLAP="1" if overlap else "0", DMVAE_DP_MODE=mode)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    from dmvae_hip import StepEngine, GradExchange
+    from dmvae_hip import StepEngine, make_exchange
     kw, B = dict(input_dim=784, latent_dim=64, n_classes=10), 512
     g = torch.Generator(device="cuda"); g.manual_seed(5)
     data = torch.rand((4 * B, 784), device="cuda", generator=g)
     perm = torch.randperm(4 * B, device="cuda", generator=g).to(torch.int32)
-    ex = GradExchange()
-    assert ex.enabled and ex.world == 1 and ex.overlap == overlap
+    ex = make_exchange()
+    assert ex.enabled and ex.world == 1 and ex.overlap == overlap and ex.sharded == (mode == "sharded")
     res = []
     for sync in (ex, None):
         eng = StepEngine(dtype="bf16", max_batch=B, mode="exact", seed=77, **kw)
@@ -374,18 +406,19 @@ def _rccl_rank(port, overlap, out):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["sharded", "allreduce"])
 @pytest.mark.parametrize("overlap", [True, False])
-def test_rccl_exchange_on_one_rank_is_the_identity(overlap):
-    """The N > 1 step sequence (staged backward, bucketed asynchronous all-reduce on RCCL's stream,
-    per-bucket Adam) with a one-rank communicator must reproduce the single-process fused step bit
-    for bit: the collectives are identities, so any difference is a stream-ordering or
+def test_rccl_exchange_on_one_rank_is_the_identity(overlap, mode):
+    """The N > 1 step sequence (staged backward, bucketed asynchronous collectives on RCCL's stream -- reduce-scatter /
+    all-gather or all-reduce --, per-bucket Adam) with a one-rank communicator must reproduce the single-process
+    fused step bit for bit: the collectives are identities, so any difference is a stream-ordering or
     bucket-coverage fault in the data-parallel path."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    proc = ctx.Process(target=_rccl_rank, args=(port, overlap, out))
+    proc = ctx.Process(target=_rccl_rank, args=(port, overlap, out, mode))
     proc.start()
     (p_dp, t_dp, l_dp), (p_one, t_one, l_one) = out.get(timeout=300)
     proc.join(60)

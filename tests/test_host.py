@@ -31,7 +31,7 @@ def test_ctypes_structs_match_header_layout():
     # sizes computed from the C declarations (natural alignment, LP64)
     assert C.sizeof(_lib.State) == 8 + 8 + 4 + 4 + 4 * 4 + 4 * 4 + 4 * 4
     assert C.sizeof(_lib.Epilogue) == 24 + 12 * 8
-    assert C.sizeof(_lib.Buffers) == 7 * 8
+    assert C.sizeof(_lib.Buffers) == 8 * 8
     assert C.sizeof(_lib.TensorInfo) == 32 + 8 + 4 + 4 + 8
     assert C.sizeof(_lib.ProfRow) == 48 + 8 + 8 + 8 + 8
     assert C.sizeof(_lib.Config) == 4 * 3 + 4 + 32 + 4 + 4 + 32 + 4 * 4 + 4 * 4 + 8 + 4 + 4
@@ -292,6 +292,55 @@ def test_epoch_loop_world2_gloo_collectives_pair_up(n_rows, batch):
         assert [r[1] for r in res] == ["raised", "raised"]
     else:
         assert [(r[1], r[2]) for r in res] == [(1, 1.0), (1, 1.0)]
+
+
+def _sharded_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "deep-mixture-vae_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), DMVAE_DP_MODE="sharded")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dmvae_hip.parallel import make_exchange, ShardedExchange
+    ex = make_exchange(param_bytes=0)
+    assert isinstance(ex, ShardedExchange) and ex.enabled and ex.sharded and not ex.overlap and ex.align == 64 * world
+    n = ex.padded(1000)                                   # an "arena" of 1000 real elements
+    assert n % (64 * world) == 0 and n >= 1000
+    # plan-style buckets in completion order (decoder+priors, heads, trunk) with unaligned interior bounds
+    raw = [(700, 1000), (300, 700), (0, 300)]
+    b = ex.bucket_bounds(raw, n)
+    assert b[0][1] == n and b[-1][0] == 0 and all(b[i][0] == b[i + 1][1] for i in range(len(b) - 1))
+    assert all((hi - lo) % (64 * world) == 0 for lo, hi in b)
+    assert all(bl >= rl for (bl, _), (rl, _) in zip(b, raw))          # a bucket only grows into what was finished EARLIER
+    g = torch.Generator().manual_seed(7 + rank)
+    grad = torch.randn(n, generator=g)
+    ref = grad.clone()
+    dist.all_reduce(ref, op=dist.ReduceOp.SUM)            # what the all-reduce form would hold everywhere
+    param = torch.zeros(n)
+    for lo, hi in b:
+        ex.reduce_scatter(grad, lo, hi)
+        slo, shi = ex.owned(lo, hi)
+        assert torch.equal(grad[slo:shi], ref[slo:shi])   # two ranks: a + b either way
+        param[slo:shi] = -0.5 * grad[slo:shi]             # the "update" of the owned slice only
+        ex.all_gather(param, lo, hi)
+    out.put((rank, bool(torch.equal(param, -0.5 * ref)), [tuple(x) for x in b]))
+    dist.destroy_process_group()
+
+
+def test_sharded_exchange_world2_gloo():
+    """reduce-scatter -> owned-slice update -> all-gather over padded, rounded buckets reproduces all-reduce +
+    replicated update on every rank (SURVEY 8e's preferred collective; the GPU tests run the real Adam on it)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res) and res[0][2] == res[1][2]
 
 
 def test_png_writer_roundtrip(tmp_path):
