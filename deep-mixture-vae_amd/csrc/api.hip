@@ -142,8 +142,9 @@ struct dmvae_plan {
     // workspace byte offsets
     int64_t o_x, o_xf, o_hzc, o_mv, o_lg, o_Z, o_Zf, o_gmu, o_glv, o_clv, o_w, o_dlg, o_recon, o_dl, o_dmv, o_dhzc;
     std::vector<int64_t> o_enc, o_dec, o_denc, o_ddec;
-    int64_t o_rpart, o_lpart, o_dprior, o_cs;
-    int n_rpart, n_lblk;
+    int64_t o_rpart, o_lpart, o_dprior, o_cs, o_lws = 0;
+    int64_t lws_bytes = 0;            // scratch of the MFMA form of the latent contractions (0: the one-kernel form)
+    int n_rpart, n_lblk, n_pblk;      // loss-partial blocks of the latent kernel; rows of its prior-table gradient partials
     int64_t cs_elems;
     int64_t work_bytes;
     dmvae_buffers buf;
@@ -300,7 +301,10 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
     p->o_rpart = take((int64_t)p->n_rpart * 4);
     p->n_lblk = latent_nblocks(p->Bp, c->latent_dim, c->n_classes);
     p->o_lpart = take((int64_t)p->n_lblk * 2 * 4);
-    p->o_dprior = take((int64_t)p->n_lblk * 2 * KD * 4);
+    p->lws_bytes = latent_mfma_applies(c->latent_dim, c->n_classes, c->mode) ? latent_mfma_ws_bytes(p->Bp, c->latent_dim, c->n_classes) : 0;
+    p->n_pblk = p->lws_bytes ? 1 : p->n_lblk;          // the MFMA form delivers the prior-table gradient complete, in one row
+    p->o_dprior = take((int64_t)p->n_pblk * 2 * KD * 4);
+    if (p->lws_bytes) p->o_lws = take(p->lws_bytes);
     int maxN = std::max(std::max(2 * p->Hp, p->Ip), p->flat);
     for (auto& L : p->enc) maxN = std::max(maxN, L.out_pad);
     for (auto& L : p->dec) maxN = std::max(maxN, L.out_pad);
@@ -657,8 +661,11 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     const int KD2 = 2 * c.n_classes * c.latent_dim;
     const dmvae_finalize_args fin = step_finalize_args(reinterpret_cast<float*>(WS(p, p->o_rpart)), p->n_rpart, reinterpret_cast<float*>(WS(p, p->o_lpart)),
                                                        p->n_lblk, inv_B, p->buf.state, 1, c.beta1, c.beta2,
-                                                       reinterpret_cast<float*>(WS(p, p->o_dprior)), p->n_lblk, KD2, p->buf.grad + p->prior_off);
-    const bool fin_rides = all && dt == DMVAE_BF16 && p->finalize_rides;
+                                                       reinterpret_cast<float*>(WS(p, p->o_dprior)), p->n_pblk, KD2, p->buf.grad + p->prior_off);
+    // (wide heads -- the 4096-wide configuration -- take the 256x256 macro-tile kernel one by one instead of the grouped grid)
+    const bool heads_big = dt == DMVAE_BF16 && gemm_bf16_256_ok(DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK, p->Bp, p->Hp, 2 * p->Dp, false) &&
+                           gemm_bf16_256_ok(DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK, p->Bp, p->Hp, p->Kp, false);
+    const bool fin_rides = all && dt == DMVAE_BF16 && p->finalize_rides && !heads_big;
   if (all || stage == 0) {
     p->dw_queue.clear();
     TRY(encode_impl(p, s));
@@ -682,6 +689,7 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     la.dprior_partials = reinterpret_cast<float*>(WS(p, p->o_dprior));
     la.loss_partials = reinterpret_cast<float*>(WS(p, p->o_lpart));
     la.state = p->buf.state;
+    la.mfma_ws = p->lws_bytes ? WS(p, p->o_lws) : nullptr; la.mfma_ws_bytes = p->lws_bytes;
     TRY(latent_launch(s, &la));
 
     TRY(decode_hidden(p, s));
@@ -726,7 +734,7 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     TRY(grad_dense(p, s, act_off(p, p->o_hzc, p->Hp), 2 * p->Hp, p->Hp, WS(p, p->o_dlg), p->Kp, p->Kp, p->lg.w_off, p->lg.ldw, p->lg.b_off));
     {   // d(z-hidden) and d(c-hidden): independent siblings writing the two halves of dhzc -> one grouped grid (bf16)
         GemmArgs q[2];
-        const bool grp = dt == DMVAE_BF16;
+        const bool grp = dt == DMVAE_BF16 && !heads_big;
         TRY(dx_dense(p, s, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->Hp, WS(p, p->o_hzc), 2 * p->Hp, WS(p, p->o_dhzc), 2 * p->Hp,
                      grp ? &q[0] : nullptr));
         TRY(dx_dense(p, s, WS(p, p->o_dlg), p->Kp, p->Kp, p->lg.w_off, p->lg.ldw, p->Hp, act_off(p, p->o_hzc, p->Hp), 2 * p->Hp,
@@ -880,6 +888,9 @@ extern "C" int dmvae_gemm_grouped_dw_adam(void* stream, const dmvae_gemm_problem
 }
 
 extern "C" int dmvae_latent_nblocks(int B_pad, int D, int K) { return latent_nblocks(B_pad, D, K); }
+extern "C" int64_t dmvae_latent_ws_bytes(int B_pad, int D, int K, int mode) {
+    return (B_pad > 0 && B_pad % 64 == 0 && latent_mfma_applies(D, K, mode)) ? latent_mfma_ws_bytes(B_pad, D, K) : 0;
+}
 extern "C" int dmvae_latent_fwd(void* stream, const dmvae_latent_args* a) {
     DMVAE_REQUIRE(a && a->mean && a->log_var && a->logits && a->prior_means && a->prior_log_vars && a->Z_act && a->gmu && a->glv &&
                   a->clv && a->dlogits_act && a->dprior_partials && a->loss_partials, "dmvae_latent_fwd: null pointer");

@@ -283,8 +283,11 @@ bool gemm_bf16_256_ok(int layout, int epi, int M, int N, int K, bool conv) {
                       (layout == DMVAE_GEMM_DW && (epi == DMVAE_EPI_STORE_F32 || epi == DMVAE_EPI_ADAM));
     if (!inst || M % 256 || N % 256 || K % BK) return false;
     if (g_policy256 == 2) return true;
+    // K >= 1024: at K = 512 (the [z|c]-hidden layer of the MNIST-shaped configs) the two kernels tie (tools/gemm256_bench.py);
+    // the dX of the narrow heads (K = 2 D or the padded class count) is the exception: N = 4096 columns of pure output
+    // traffic, where the grouped 64x64 grid ran at 130 TFLOP/s
     const long tiles = (long)(M / 256) * (N / 256);
-    return tiles >= 192 && K >= 512;
+    return tiles >= 192 && (K >= 1024 || (layout == DMVAE_GEMM_DX && N >= 4096 && M >= 4096));
 }
 
 template <int LAYOUT, int EPI>

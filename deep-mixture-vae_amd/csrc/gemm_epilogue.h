@@ -29,6 +29,9 @@ struct GemmArgs {
     // scratch for the bias-gradient column sums of a 256x256-tile dW problem (gemm_bf16_256.hip): >= 64 * N floats,
     // the plan's own; nullptr = the library's lazily allocated global scratch (not capture-safe on first use)
     float* ws = nullptr; int64_t ws_elems = 0;
+    // f32 kernel, DMVAE_EPI_STORE_F32 with split-K: K slice y stores its partial product at out + y * slab_stride (deterministic
+    // split: the caller adds the slabs in a fixed order); 0 = plain store
+    int64_t slab_stride = 0;
 };
 
 // element offset of K position k (multiple of the tile depth) of a conv-mode A operand

@@ -131,6 +131,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
     __syncthreads();
 
     float loss = 0.f;
+    dmvae_epilogue epi = a.epi;
+    if constexpr (EPI == DMVAE_EPI_STORE_F32) epi.out = reinterpret_cast<float*>(epi.out) + (int64_t)blockIdx.y * a.slab_stride;   // K-slice slabs
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
             const int n = n0 + wn * 32 + j * 16 + g * 4;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (a.conv_c && n >= a.epi.n_valid) continue;      // conv mode: a 32-channel activation is stored 32 wide
-            epilogue_quad<EPI, float>(a.epi, m, n, v, loss);
+            epilogue_quad<EPI, float>(epi, m, n, v, loss);
         }
     if constexpr (DW) {
         if (do_bias && wm == 0 && li == 0) {

@@ -31,6 +31,10 @@ void gemm_bf16_set_knob(int which, int v);
 int gemm_f32_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split);
 int latent_nblocks(int B_pad, int D, int K);
 int latent_launch(hipStream_t s, const dmvae_latent_args* a);
+// MFMA form for large prior tables (latent_mfma.hip)
+bool latent_mfma_applies(int D, int K, int mode);
+int64_t latent_mfma_ws_bytes(int B_pad, int D, int K);
+int latent_mfma_launch(hipStream_t s, const dmvae_latent_args* a, float* ws, int64_t ws_bytes);
 int adam_launch(hipStream_t s, const AdamArgs& a);
 int adam_finish_launch(hipStream_t s, void* st);
 int colsum_prepare(int64_t max_n);

@@ -509,6 +509,8 @@ int latent_launch(hipStream_t s, const dmvae_latent_args* a) {
         set_error("dmvae_latent_fwd: K=%d D=%d needs %zu B of LDS (> 150 KiB); not supported yet", a->K, a->D, lb);
         return DMVAE_EUNSUPPORTED;
     }
+    if (a->mfma_ws && latent_mfma_applies(a->D, a->K, a->mode) && a->mfma_ws_bytes >= latent_mfma_ws_bytes(a->B_pad, a->D, a->K))
+        return latent_mfma_launch(s, a, reinterpret_cast<float*>(a->mfma_ws), a->mfma_ws_bytes);
     const int nblk = (a->B_pad + L.RB - 1) / L.RB;
     const double bytes = 4.0 * ((double)a->B * (6.0 * a->D + 3.0 * a->K) + 2.0 * a->K * a->D * (nblk + 1));
     ProfScope ps(s, a->mode == 0 ? "latent_fwd_exact" : "latent_fwd_relaxed", 6.0 * a->B * (double)a->K * a->D, bytes);

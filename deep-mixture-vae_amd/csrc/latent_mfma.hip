@@ -1,0 +1,333 @@
+// MFMA form of the latent kernel's (row, cluster, dimension) contractions -- exact mixture KL
+// (code/priors.py:131-145, cluster_sample False) for LARGE prior tables (K * D >~ 4000: BASELINE.json configs[3]
+// K=50 D=256, configs[4] K=256 D=512), where latent.hip's VALU loops over (row, k, d) dominate (150 us of a 0.8 ms
+// step; 2.5 ms of 14 ms).  With ip = exp(-prior_log_var), pm = prior_mean, e = exp(log_var), mu = mean, w = softmax:
+//
+//   A_bd  = sum_k w_bk ip_kd,  C_bd = sum_k w_bk pm_kd ip_kd          [A | C] = W . [ip | pm ip]            (G1)
+//           -> dKL/dmean = r/B (mu A - C),  dKL/dlog_var = r/2B (e A - 1)
+//   S_bk  = sum_d (e_bd + (mu_bd - pm_kd)^2) ip_kd
+//         = [e + mu^2 | mu] . [ip | -2 pm ip]^T + c2_k,   c2_k = sum_d pm^2 ip                              (G2)
+//           -> t_bk = S_bk + sum_d plv_kd - sum_d lv_bd - D,  KL_Z = mean_b 1/2 sum_k w_bk t_bk,  dKL/dw = r/2B t
+//   G     = W^T . [e + mu^2 | mu | 1]     (contraction over the batch)                                      (G3)
+//           -> d prior_mean = -r/B ip (G_mu - pm Wsum),  d prior_log_var = r/2B (Wsum - ip (G_e - 2 pm G_mu + pm^2 Wsum))
+//
+// three GEMMs in EXACT f32 (v_mfma_f32_16x16x4_f32 through gemm_f32.hip: the expanded squares cancel, bf16 operands
+// would not hold the 2e-5 relative KL tolerance) between two row-wise kernels:
+//   latent_pre   softmax, KL_C, reparameterisation (Z, its coefficient), W and [e + mu^2 | mu | 1] -- 16-byte accesses
+//   latent_post  the gradients wrt mean / log_var / logits, KL_Z; its extra workgroups sum the G slabs (fixed order)
+//                into the prior-table gradients.
+// The [B, K, D] tensor TensorFlow materialises is still never formed; the intermediates are [B, 2D] and [B, K].
+// No float atomics: G3's split over the batch writes slabs.  Device noise: one Philox block per four columns of a
+// row, keyed by the element index (a different, equally valid stream than latent.hip's geometry-keyed one).
+#include <string.h>
+
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace dmvae {
+
+static inline int pad64i(int x) { return (x + 63) / 64 * 64; }
+
+struct LatentMfmaWs {      // float offsets into the caller's scratch
+    int Dp, Kp, XW, nsplit;
+    int64_t T1, T2, c2, ck, Wm, X1, AC, S, RL, G, total;
+};
+static LatentMfmaWs latent_mfma_layout(int Bp, int D, int K) {
+    LatentMfmaWs w;
+    w.Dp = pad64i(D); w.Kp = pad64i(K); w.XW = 2 * w.Dp + 64;
+    const int tiles = (w.Kp / 64) * (w.XW / 64);
+    int ns = 1;
+    while (ns < 32 && tiles * ns < 512 && (Bp / 64) % (2 * ns) == 0) ns *= 2;      // slices of the batch: fill the chip, stay multiples of 64 rows
+    w.nsplit = ns;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { const int64_t r = o; o += (n + 63) / 64 * 64; return r; };
+    w.T1 = take((int64_t)w.Kp * 2 * w.Dp); w.T2 = take((int64_t)w.Kp * 2 * w.Dp);
+    w.c2 = take(w.Kp); w.ck = take(w.Kp);
+    w.Wm = take((int64_t)Bp * w.Kp); w.X1 = take((int64_t)Bp * w.XW);
+    w.AC = take((int64_t)Bp * 2 * w.Dp); w.S = take((int64_t)Bp * w.Kp); w.RL = take(Bp);
+    w.G = take((int64_t)ns * w.Kp * w.XW);
+    w.total = o;
+    return w;
+}
+
+bool latent_mfma_applies(int D, int K, int mode) { return mode == 0 && (int64_t)D * K >= 4096; }
+int64_t latent_mfma_ws_bytes(int B_pad, int D, int K) { return 4 * latent_mfma_layout(B_pad, D, K).total; }
+
+// ---- prior tables -> GEMM operands (tiny: K * D elements)
+__global__ __launch_bounds__(256) void latent_tables_kernel(const float* __restrict__ pm, const float* __restrict__ plv, int K, int D, int Kp, int Dp,
+                                                            float* __restrict__ T1, float* __restrict__ T2, float* __restrict__ c2, float* __restrict__ ck) {
+    const int k = blockIdx.x;          // one block per (padded) cluster row
+    __shared__ float red[8];
+    float s2 = 0.f, sl = 0.f;
+    for (int d = threadIdx.x; d < Dp; d += 256) {
+        float ip = 0.f, m = 0.f;
+        if (k < K && d < D) {
+            const float lv = plv[(int64_t)k * D + d];
+            m = pm[(int64_t)k * D + d];
+            ip = __expf(-lv);
+            s2 += m * m * ip;
+            sl += lv;
+        }
+        T1[(int64_t)k * 2 * Dp + d] = ip;
+        T1[(int64_t)k * 2 * Dp + Dp + d] = m * ip;
+        T2[(int64_t)k * 2 * Dp + d] = ip;
+        T2[(int64_t)k * 2 * Dp + Dp + d] = -2.f * m * ip;
+    }
+    const float a = block_sum_256(s2, red);
+    const float b = block_sum_256(sl, red + 4);
+    if (threadIdx.x == 0) { c2[k] = a; ck[k] = b; }
+}
+
+struct LatentMfmaArgs {
+    dmvae_latent_args a;
+    LatentMfmaWs w;
+    float* ws;
+    int RB;          // rows per workgroup: latent.hip's geometry, so that both paths write the same number of loss partials
+};
+
+// ---- rows, before the GEMMs.  16 lanes per row, 16 rows per 256-thread block; a lane owns quads of columns.
+__global__ __launch_bounds__(256) void latent_pre_kernel(LatentMfmaArgs L) {
+    const dmvae_latent_args& a = L.a;
+    const int lane16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
+    const int D = a.D, K = a.K, Dp = L.w.Dp, Kp = L.w.Kp, XW = L.w.XW;
+    const dmvae_state* st = reinterpret_cast<const dmvae_state*>(a.state);
+    const uint64_t nstep = st ? st->noise_step : a.noise_step;
+    __shared__ float red[16];
+    float kc_acc = 0.f;
+  for (int pass = 0; pass < L.RB / 16; ++pass) {
+    const int b = blockIdx.x * L.RB + pass * 16 + rsub;
+    const bool valid = b < a.B;
+    float* Wm = L.ws + L.w.Wm + (int64_t)b * Kp;
+    float* X1 = L.ws + L.w.X1 + (int64_t)b * XW;
+
+    // softmax over K (lane owns k = lane16 + 16 i), KL_C
+    float mx = -INFINITY;
+    for (int k = lane16; k < K; k += 16) mx = fmaxf(mx, valid ? a.logits[(int64_t)b * a.ld_logits + k] : 0.f);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+    float se = 0.f;
+    for (int k = lane16; k < K; k += 16) se += __expf((valid ? a.logits[(int64_t)b * a.ld_logits + k] : 0.f) - mx);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o, 16);
+    const float logK = __logf((float)K);
+    float kc = 0.f;
+    for (int k = lane16; k < Kp; k += 16) {
+        float q = 0.f;
+        if (valid && k < K) {
+            q = __expf(a.logits[(int64_t)b * a.ld_logits + k] - mx) / se;
+            kc += q * (__logf(q + 1e-20f) + logK);
+        }
+        Wm[k] = q;
+        if (a.weights && k < K) a.weights[(int64_t)b * a.ld_w + k] = q;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) kc += __shfl_xor(kc, o, 16);
+    kc_acc += kc;
+
+    // columns in quads: Z, reparameterisation coefficient, [e + mu^2 | mu]
+    const bool vec = (D % 4 == 0) && (a.ld_mean % 4 == 0) && (a.ld_log_var % 4 == 0) && (a.ld_g % 4 == 0) && (a.ld_Z % 4 == 0) &&
+                     (!a.eps || a.ld_eps % 4 == 0) && (!a.Z_f32 || a.ld_Zf % 4 == 0);
+    float lvsum = 0.f;
+    for (int q4 = lane16; q4 < Dp / 4; q4 += 16) {
+        const int d0 = 4 * q4;
+        float mu[4] = {0.f, 0.f, 0.f, 0.f}, lv[4] = {0.f, 0.f, 0.f, 0.f}, ep[4] = {0.f, 0.f, 0.f, 0.f};
+        if (valid && d0 < D) {
+            if (vec) {
+                const float4 m4 = *reinterpret_cast<const float4*>(a.mean + (int64_t)b * a.ld_mean + d0);
+                const float4 l4 = *reinterpret_cast<const float4*>(a.log_var + (int64_t)b * a.ld_log_var + d0);
+                mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
+                lv[0] = l4.x; lv[1] = l4.y; lv[2] = l4.z; lv[3] = l4.w;
+                if (a.eps) {
+                    const float4 e4 = *reinterpret_cast<const float4*>(a.eps + (int64_t)b * a.ld_eps + d0);
+                    ep[0] = e4.x; ep[1] = e4.y; ep[2] = e4.z; ep[3] = e4.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (d0 + j < D) {
+                        mu[j] = a.mean[(int64_t)b * a.ld_mean + d0 + j];
+                        lv[j] = a.log_var[(int64_t)b * a.ld_log_var + d0 + j];
+                        if (a.eps) ep[j] = a.eps[(int64_t)b * a.ld_eps + d0 + j];
+                    }
+            }
+            if (!a.eps) philox_normal4(a.seed, nstep, 0u, (uint64_t)b * (Dp / 4) + q4, ep);
+        }
+        float z[4], cl[4], x1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = valid && d0 + j < D;
+            const float e = __expf(lv[j]), sd = __expf(0.5f * lv[j]);
+            z[j] = ok ? mu[j] + sd * ep[j] : 0.f;
+            cl[j] = ok ? ep[j] * 0.5f * sd : 0.f;
+            x1[j] = ok ? e + mu[j] * mu[j] : 0.f;
+            if (!ok) mu[j] = 0.f;
+            lvsum += ok ? lv[j] : 0.f;
+        }
+        *reinterpret_cast<float4*>(X1 + d0) = make_float4(x1[0], x1[1], x1[2], x1[3]);
+        *reinterpret_cast<float4*>(X1 + Dp + d0) = make_float4(mu[0], mu[1], mu[2], mu[3]);
+        // outputs: Z (act dtype, pad columns up to ld_Z zeroed: they are K padding of the first decoder GEMM), f32 copy, coefficient
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = d0 + j;
+            if (d < a.ld_Z) {
+                if (a.act_dtype == DMVAE_BF16) reinterpret_cast<bf16_t*>(a.Z_act)[(int64_t)b * a.ld_Z + d] = f2bf(z[j]);
+                else reinterpret_cast<float*>(a.Z_act)[(int64_t)b * a.ld_Z + d] = z[j];
+            }
+            if (d < D) {
+                if (a.Z_f32) a.Z_f32[(int64_t)b * a.ld_Zf + d] = z[j];
+                a.clv[(int64_t)b * a.ld_g + d] = cl[j];
+            }
+        }
+    }
+    for (int d = Dp + lane16; d < a.ld_Z; d += 16) {      // (a Z buffer wider than D padded to 64)
+        if (a.act_dtype == DMVAE_BF16) reinterpret_cast<bf16_t*>(a.Z_act)[(int64_t)b * a.ld_Z + d] = 0;
+        else reinterpret_cast<float*>(a.Z_act)[(int64_t)b * a.ld_Z + d] = 0.f;
+    }
+    for (int c = lane16; c < 64; c += 16) X1[2 * Dp + c] = (c == 0 && valid) ? 1.f : 0.f;      // the ones column: G3 then also yields sum_b w_bk
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) lvsum += __shfl_xor(lvsum, o, 16);
+    if (lane16 == 0) L.ws[L.w.RL + b] = lvsum;
+  }
+    if (lane16 == 0) red[rsub] = kc_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float c = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c += red[i];
+        a.loss_partials[2 * blockIdx.x + 1] = c;
+    }
+}
+
+// ---- rows, after the GEMMs; workgroups >= nrow_blocks: the prior-table gradients from the G slabs
+__global__ __launch_bounds__(256) void latent_post_kernel(LatentMfmaArgs L, int nrow_blocks) {
+    const dmvae_latent_args& a = L.a;
+    const int D = a.D, K = a.K, Dp = L.w.Dp, Kp = L.w.Kp, XW = L.w.XW;
+    const dmvae_state* st = reinterpret_cast<const dmvae_state*>(a.state);
+    const float klr = st ? st->kl_ratio : a.kl_ratio;
+    const float rB = klr * a.inv_B, rB2 = 0.5f * rB;
+    if ((int)blockIdx.x >= nrow_blocks) {
+        const int64_t KD = (int64_t)K * D;
+        for (int64_t idx = (int64_t)((int)blockIdx.x - nrow_blocks) * 256 + threadIdx.x; idx < KD; idx += (int64_t)((int)gridDim.x - nrow_blocks) * 256) {
+            const int k = (int)(idx / D), d = (int)(idx - (int64_t)k * D);
+            float ge = 0.f, gm = 0.f, wsum = 0.f;
+            for (int s = 0; s < L.w.nsplit; ++s) {                     // slabs in ascending order
+                const float* g = L.ws + L.w.G + ((int64_t)s * Kp + k) * XW;
+                ge += g[d]; gm += g[Dp + d]; wsum += g[2 * Dp];
+            }
+            const float ip = L.ws[L.w.T1 + (int64_t)k * 2 * Dp + d];
+            const float pmv = a.prior_means[idx];
+            a.dprior_partials[idx] = -rB * ip * (gm - pmv * wsum);
+            a.dprior_partials[KD + idx] = rB2 * (wsum - ip * (ge - 2.f * pmv * gm + pmv * pmv * wsum));
+        }
+        return;
+    }
+    const int lane16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
+    __shared__ float red[16];
+    float klz_acc = 0.f;
+  for (int pass = 0; pass < L.RB / 16; ++pass) {
+    const int b = blockIdx.x * L.RB + pass * 16 + rsub;
+    const bool valid = b < a.B;
+    const float* AC = L.ws + L.w.AC + (int64_t)b * 2 * Dp;
+    const float* S = L.ws + L.w.S + (int64_t)b * Kp;
+    const float* Wm = L.ws + L.w.Wm + (int64_t)b * Kp;
+    const float* X1 = L.ws + L.w.X1 + (int64_t)b * XW;
+    // gradients wrt mean / log_var
+    for (int q4 = lane16; q4 < (D + 3) / 4; q4 += 16) {
+        const int d0 = 4 * q4;
+        const float4 A4 = *reinterpret_cast<const float4*>(AC + d0);
+        const float4 C4 = *reinterpret_cast<const float4*>(AC + Dp + d0);
+        const float4 M4 = *reinterpret_cast<const float4*>(X1 + Dp + d0);
+        const float A[4] = {A4.x, A4.y, A4.z, A4.w}, Cc[4] = {C4.x, C4.y, C4.z, C4.w}, mu[4] = {M4.x, M4.y, M4.z, M4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = d0 + j;
+            if (d < D) {
+                const float e = valid ? __expf(a.log_var[(int64_t)b * a.ld_log_var + d]) : 0.f;
+                a.gmu[(int64_t)b * a.ld_g + d] = valid ? rB * (mu[j] * A[j] - Cc[j]) : 0.f;
+                a.glv[(int64_t)b * a.ld_g + d] = valid ? rB2 * (e * A[j] - 1.f) : 0.f;
+            }
+        }
+    }
+    // KL_Z and the gradient wrt the logits
+    const float rl = L.ws[L.w.RL + b], logK = __logf((float)K);
+    float s_wdw = 0.f, s_qdq = 0.f, klz = 0.f;
+    for (int k = lane16; k < K; k += 16) {
+        const float w = Wm[k];
+        const float t = S[k] + L.ws[L.w.c2 + k] + L.ws[L.w.ck + k] - rl - (float)D;
+        klz += 0.5f * w * t;
+        const float dq = rB * (__logf(w + 1e-20f) + w / (w + 1e-20f) + logK);
+        s_wdw += w * (rB2 * t);
+        s_qdq += w * dq;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        s_wdw += __shfl_xor(s_wdw, o, 16); s_qdq += __shfl_xor(s_qdq, o, 16); klz += __shfl_xor(klz, o, 16);
+    }
+    for (int k = lane16; k < a.ld_dl; k += 16) {
+        float dl = 0.f;
+        if (k < K && valid) {
+            const float w = Wm[k];
+            const float t = S[k] + L.ws[L.w.c2 + k] + L.ws[L.w.ck + k] - rl - (float)D;
+            const float dq = rB * (__logf(w + 1e-20f) + w / (w + 1e-20f) + logK);
+            dl = w * (dq - s_qdq) + w * (rB2 * t - s_wdw);
+        }
+        if (a.act_dtype == DMVAE_BF16) reinterpret_cast<bf16_t*>(a.dlogits_act)[(int64_t)b * a.ld_dl + k] = f2bf(dl);
+        else reinterpret_cast<float*>(a.dlogits_act)[(int64_t)b * a.ld_dl + k] = dl;
+    }
+    klz_acc += valid ? klz : 0.f;
+  }
+    if (lane16 == 0) red[rsub] = klz_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float z = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) z += red[i];
+        a.loss_partials[2 * blockIdx.x] = z;
+    }
+}
+
+static int f32_gemm(hipStream_t s, int layout, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb, float* out, int64_t ldo,
+                    int split, int64_t slab_stride) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.k_split = K / split; g.group_m = 8; g.conv_p = 0; g.conv_c = 0;
+    memset(&g.epi, 0, sizeof(g.epi));
+    g.epi.kind = DMVAE_EPI_STORE_F32; g.epi.out = out; g.epi.ldo = ldo; g.epi.m_valid = M; g.epi.n_valid = N;
+    g.slab_stride = slab_stride;
+    return gemm_f32_dispatch(s, layout, g, split);
+}
+
+int latent_mfma_launch(hipStream_t s, const dmvae_latent_args* a, float* ws, int64_t ws_bytes) {
+    const LatentMfmaWs w = latent_mfma_layout(a->B_pad, a->D, a->K);
+    if (4 * w.total > ws_bytes) { set_error("dmvae_latent_fwd: MFMA-path scratch too small (%lld < %lld bytes)", (long long)ws_bytes, (long long)(4 * w.total)); return DMVAE_EINVAL; }
+    LatentMfmaArgs L;
+    L.a = *a; L.w = w; L.ws = ws;
+    L.RB = a->B_pad / latent_nblocks(a->B_pad, a->D, a->K);        // latent.hip's rows per workgroup (16, 32 or 64)
+    const int nrb = a->B_pad / L.RB;
+    const double BD = (double)a->B * a->D, BK = (double)a->B * a->K;
+    {
+        ProfScope ps(s, "latent_tables", 0.0, 16.0 * a->K * a->D);
+        hipLaunchKernelGGL(latent_tables_kernel, dim3(w.Kp), dim3(256), 0, s, a->prior_means, a->prior_log_vars, a->K, a->D, w.Kp, w.Dp, ws + w.T1, ws + w.T2, ws + w.c2, ws + w.ck);
+    }
+    {
+        ProfScope ps(s, "latent_pre", 0.0, 4.0 * (BD * (2.0 + (a->eps ? 1.0 : 0.0) + 2.0 + 2.0 + 1.0) + BK * 3.0));
+        hipLaunchKernelGGL(latent_pre_kernel, dim3(nrb), dim3(256), 0, s, L);
+    }
+    int rc = check_launch("latent_pre");
+    if (rc) return rc;
+    {
+        ProfScope ps(s, "latent_gemm_f32", 2.0 * a->B_pad * (double)w.Kp * (2.0 * w.Dp + 2.0 * w.Dp + w.XW), 4.0 * a->B_pad * (3.0 * w.Kp + 2.0 * w.XW + 2.0 * w.Dp));
+        rc = f32_gemm(s, DMVAE_GEMM_FWD, a->B_pad, 2 * w.Dp, w.Kp, ws + w.Wm, w.Kp, ws + w.T1, 2 * w.Dp, ws + w.AC, 2 * w.Dp, 1, 0);
+        if (!rc) rc = f32_gemm(s, DMVAE_GEMM_DX, a->B_pad, w.Kp, 2 * w.Dp, ws + w.X1, w.XW, ws + w.T2, 2 * w.Dp, ws + w.S, w.Kp, 1, 0);
+        if (!rc) rc = f32_gemm(s, DMVAE_GEMM_DW, w.Kp, w.XW, a->B_pad, ws + w.Wm, w.Kp, ws + w.X1, w.XW, ws + w.G, w.XW, w.nsplit, (int64_t)w.Kp * w.XW);
+    }
+    if (rc) return rc;
+    {
+        const int extra = (int)std::min<int64_t>(256, ((int64_t)a->K * a->D + 255) / 256);
+        ProfScope ps(s, "latent_post", 0.0, 4.0 * (BD * (2.0 + 1.0 + 1.0 + 2.0) + BK * 3.0) + 4.0 * w.nsplit * w.Kp * w.XW);
+        hipLaunchKernelGGL(latent_post_kernel, dim3(nrb + extra), dim3(256), 0, s, L, nrb);
+    }
+    return check_launch("latent_post");
+}
+
+}  // namespace dmvae

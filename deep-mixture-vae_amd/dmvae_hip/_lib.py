@@ -24,7 +24,7 @@ MAX_LAYERS = 8
 TRUNK_MLP, TRUNK_CNN = 0, 1
 
 EXPORTS = [
-    "dmvae_gemm", "dmvae_gemm_partials", "dmvae_gemm_grouped_dw", "dmvae_gemm_grouped", "dmvae_gemm_grouped_dw_adam", "dmvae_plan_train_step",
+    "dmvae_gemm", "dmvae_gemm_partials", "dmvae_gemm_grouped_dw", "dmvae_gemm_grouped", "dmvae_gemm_grouped_dw_adam", "dmvae_plan_train_step", "dmvae_latent_ws_bytes",
     "dmvae_plan_forward_backward_stage", "dmvae_plan_grad_buckets", "dmvae_plan_update_range",
 "dmvae_latent_nblocks", "dmvae_latent_fwd",
     "dmvae_recon_fwd_bwd", "dmvae_recon_nblocks", "dmvae_colsum", "dmvae_loss_finalize",
@@ -83,6 +83,7 @@ class LatentArgs(C.Structure):
         ("dlogits_act", C.c_void_p), ("ld_dl", C.c_int64),
         ("dprior_partials", C.c_void_p), ("loss_partials", C.c_void_p),
         ("state", C.c_void_p),
+        ("mfma_ws", C.c_void_p), ("mfma_ws_bytes", C.c_int64),
     ]
 
 
@@ -147,6 +148,7 @@ def _load():
         "dmvae_plan_grad_buckets": [vp, P(i64)],
         "dmvae_plan_update_range": [vp, vp, f32, i64, i64],
         "dmvae_latent_nblocks": [i32, i32, i32],
+        "dmvae_latent_ws_bytes": [i32, i32, i32, i32],
         "dmvae_latent_fwd": [vp, P(LatentArgs)],
         "dmvae_recon_fwd_bwd": [vp, i32, i32, i32, i32, i32, i32, vp, i64, vp, i64, f32, vp, i64, vp],
         "dmvae_recon_nblocks": [i32, i32],
@@ -184,6 +186,7 @@ def _load():
         fn.argtypes = args
         fn.restype = C.c_int
     lib.dmvae_last_error.restype = C.c_char_p
+    lib.dmvae_latent_ws_bytes.restype = C.c_int64
     lib.dmvae_plan_destroy.restype = None
     return lib
 

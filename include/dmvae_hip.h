@@ -164,8 +164,15 @@ typedef struct dmvae_latent_args {
     float* dprior_partials;                   /* [nblocks][2][K][D] f32 (deterministic two-pass) */
     float* loss_partials;                     /* [nblocks][2]: sum_b KL_Z_b, sum_b KL_C_b      */
     const void* state;                        /* optional dmvae_state* (device): kl_ratio, noise_step read from it */
+    /* Large prior tables (mode 0, K * D >= 4096: dmvae_latent_ws_bytes() > 0): scratch for the MFMA form of the
+     * (row, cluster, dimension) contractions -- three exact-f32 MFMA GEMMs between two row-wise kernels
+     * (csrc/latent_mfma.hip).  NULL (or too small a size) = the one-kernel form.  With the scratch, the loss partials
+     * are written for the same dmvae_latent_nblocks() blocks, but the prior-table gradient arrives COMPLETE in row 0
+     * of dprior_partials (rows 1.. are not touched), and on-device noise comes from a differently keyed Philox stream. */
+    void* mfma_ws; int64_t mfma_ws_bytes;
 } dmvae_latent_args;
 int dmvae_latent_nblocks(int B_pad, int D, int K);
+int64_t dmvae_latent_ws_bytes(int B_pad, int D, int K, int mode);   /* 0 when the MFMA form does not apply */
 int dmvae_latent_fwd(void* stream, const dmvae_latent_args* a);
 
 /* ---- stand-alone reconstruction loss (fused form: DMVAE_EPI_BIAS_RECON) --

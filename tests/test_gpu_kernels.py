@@ -254,7 +254,7 @@ def test_gemm_rejects_unaligned_shapes(hip):
 
 
 # ------------------------------------------------------------------ latent kernel
-def run_latent(L, mean, log_var, logits, eps, gumbel, pm, plv, mode, tau, kl_ratio, act_dtype, B_pad=None, ldpad=0):
+def run_latent(L, mean, log_var, logits, eps, gumbel, pm, plv, mode, tau, kl_ratio, act_dtype, B_pad=None, ldpad=0, mfma=False):
     B, D = mean.shape
     K = logits.shape[1]
     B_pad = B_pad or ((B + 63) // 64 * 64)
@@ -298,6 +298,11 @@ def run_latent(L, mean, log_var, logits, eps, gumbel, pm, plv, mode, tau, kl_rat
     a.gmu, a.glv, a.clv, a.ld_g = L.ptr(gmu).value, L.ptr(glv).value, L.ptr(clv).value, ldZ
     a.dlogits_act, a.ld_dl = L.ptr(dlg).value, ldl
     a.dprior_partials, a.loss_partials = L.ptr(dpri).value, L.ptr(lp).value
+    if mfma:          # the MFMA form of the contractions (csrc/latent_mfma.hip): the caller brings the scratch
+        nb = L.lib.dmvae_latent_ws_bytes(B_pad, D, K, mode)
+        assert nb > 0, "the MFMA form does not apply to this shape / mode"
+        ws = torch.full((nb // 4,), float("nan"), dtype=torch.float32, device="cuda")      # stale scratch must not matter
+        a.mfma_ws, a.mfma_ws_bytes = L.ptr(ws).value, nb
     L.check(L.lib.dmvae_latent_fwd(stream(), C.byref(a)), "dmvae_latent_fwd")
     torch.cuda.synchronize()
     dp = dpri.double().sum(0).cpu().numpy()
@@ -353,6 +358,50 @@ def test_latent_fwd_matches_oracle(hip, mode, shape):
     assert not g["dlogits"][:, K:].any() and not g["dlogits"][B:].any() and not g["gmu"][B:, :D].any()
     np.testing.assert_allclose(g["dpm"], o["dpm"], rtol=2e-4, atol=1e-5)
     np.testing.assert_allclose(g["dplv"], o["dplv"], rtol=2e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(130, 300, 50), (70, 96, 130), (128, 256, 50), (64, 512, 256), (1000, 64, 64), (333, 30, 200)])
+@pytest.mark.parametrize("noise", ["caller", "device"])
+def test_latent_mfma_form_matches_oracle(hip, shape, noise):
+    """K * D >= 4096, exact mode: the contractions as three f32 MFMA GEMMs between two row kernels.  Same oracle, same
+    tolerances as the one-kernel form (the expanded squares are computed in exact f32); with device noise the drawn
+    epsilon is recovered from Z and fed to the oracle."""
+    L = hip
+    B, D, K = shape
+    rng = np.random.RandomState(B + D + K)
+    mean, lv = rng.randn(B, D) * 1.2, rng.randn(B, D) * 0.5 - 0.2
+    logits = rng.randn(B, K) * 1.5
+    eps = rng.randn(B, D)
+    pm, plv = rng.randn(K, D), rng.randn(K, D) * 0.4
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    mean, lv, logits, eps, pm, plv = map(f32, (mean, lv, logits, eps, pm, plv))
+    g = run_latent(L, mean, lv, logits, eps if noise == "caller" else None, None, pm, plv, 0, 1.0, 0.6, 0, ldpad=4, mfma=True)
+    if noise == "device":
+        eps = (g["Zf"][:B].astype(np.float64) - mean) / np.exp(lv / 2)
+        assert abs(eps.mean()) < 0.05 and abs(eps.std() - 1.0) < 0.05
+        g2 = run_latent(L, mean, lv, logits, None, None, pm, plv, 0, 1.0, 0.6, 0, ldpad=4, mfma=True)
+        np.testing.assert_array_equal(g["Zf"], g2["Zf"])           # same (seed, step) -> same draw
+    o = oracle_latent(mean, lv, logits, eps, None, pm, plv, 0, 1.0, 0.6)
+    assert g["klz"] == pytest.approx(o["klz"], rel=2e-5, abs=1e-5)
+    assert g["klc"] == pytest.approx(o["klc"], rel=2e-5, abs=1e-6)
+    if noise == "caller":
+        np.testing.assert_allclose(g["Zf"][:B], o["Z"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(g["Z"][:B, :D], o["Z"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(g["clv"][:B, :D], o["clv"], rtol=1e-5, atol=1e-6)
+    assert not g["Z"][:, D:].any() and not g["Z"][B:].any()
+    np.testing.assert_allclose(g["w"][:B], o["w"], rtol=1e-5, atol=1e-7)
+    sc = 1.0 / B
+    np.testing.assert_allclose(g["gmu"][:B, :D], o["gmu"], rtol=2e-4, atol=2e-5 * sc)
+    np.testing.assert_allclose(g["glv"][:B, :D], o["glv"], rtol=2e-4, atol=2e-5 * sc)
+    np.testing.assert_allclose(g["dlogits"][:B, :K], o["dlogits"], rtol=5e-4, atol=5e-5 * sc)
+    assert not g["dlogits"][:, K:].any() and not g["dlogits"][B:].any() and not g["gmu"][B:, :D].any()
+    np.testing.assert_allclose(g["dpm"], o["dpm"], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(g["dplv"], o["dplv"], rtol=2e-4, atol=1e-5)
+    # and against the one-kernel form on the same inputs
+    if noise == "caller":
+        c = run_latent(L, mean, lv, logits, eps, None, pm, plv, 0, 1.0, 0.6, 0, ldpad=4)
+        assert g["klz"] == pytest.approx(c["klz"], rel=2e-5)
+        np.testing.assert_allclose(g["dlogits"][:B, :K], c["dlogits"][:B, :K], rtol=1e-3, atol=1e-4 * sc)
 
 
 def test_latent_fwd_against_reference_golden_vectors(hip, golden):

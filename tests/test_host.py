@@ -69,6 +69,24 @@ def test_plan_layout_without_gpu():
     _lib.lib.dmvae_plan_destroy(h)
 
 
+def test_plan_layout_under_address_sanitizer():
+    """the host-only code of the library (plan creation, arena layout, tensor table, argument checks,
+    geometry helpers) built with -fsanitize=address,undefined (hipcc --cuda-host-only: no device code, CPU only) and
+    driven through the C ABI in a child process with the ASan runtime preloaded.  Any heap / stack / UB report fails it."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("dmvae_build", os.path.join(ROOT, "deep-mixture-vae_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    so, rt = mod.build_host_asan()
+    assert os.path.exists(so) and rt, (so, rt)
+    env = dict(os.environ, LD_PRELOAD=rt, DMVAE_HIP_LIB=so, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=86",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", PYTHONPATH=os.path.join(ROOT, "deep-mixture-vae_amd"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "asan_plan_probe.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "asan probe ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+
+
 def test_product_path_has_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
