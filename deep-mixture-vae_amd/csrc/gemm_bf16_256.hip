@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void colsum_slabs_kernel(const bf16_t* in, int
     const int r0 = blockIdx.y * rows_per_slab, r1 = min(rows, r0 + rows_per_slab);
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (n < N)
-        for (int r = r0 + wave; r < r1; r += 4) {
+#pragma unroll 8
+        for (int r = r0 + wave; r < r1; r += 4) {      // (unrolled: eight 16-byte loads in flight per lane)
             const uint4 q = *reinterpret_cast<const uint4*>(in + (int64_t)r * ld + n);
             const unsigned w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll

@@ -30,7 +30,7 @@ namespace dmvae {
 static inline int pad64i(int x) { return (x + 63) / 64 * 64; }
 
 struct LatentMfmaWs {      // float offsets into the caller's scratch
-    int Dp, Kp, XW, nsplit;
+    int Dp, Kp, XW, nsplit, nsplit_s;      // K slices of G3 (over the batch) and of G2 (over 2D)
     int64_t T1, T2, c2, ck, Wm, X1, AC, S, RL, G, total;
 };
 static LatentMfmaWs latent_mfma_layout(int Bp, int D, int K) {
@@ -40,12 +40,16 @@ static LatentMfmaWs latent_mfma_layout(int Bp, int D, int K) {
     int ns = 1;
     while (ns < 32 && tiles * ns < 512 && (Bp / 64) % (2 * ns) == 0) ns *= 2;      // slices of the batch: fill the chip, stay multiples of 64 rows
     w.nsplit = ns;
+    // G2 = [B, 2D] x [2D, K]: with few clusters (N = K padded to 64) its grid is B / 64 workgroups of a long K loop -- cut 2D
+    int nss = 1;
+    while (nss < 8 && (Bp / 64) * (w.Kp / 64) * nss < 512 && (2 * w.Dp / 64) % (2 * nss) == 0) nss *= 2;
+    w.nsplit_s = nss;
     int64_t o = 0;
     auto take = [&](int64_t n) { const int64_t r = o; o += (n + 63) / 64 * 64; return r; };
     w.T1 = take((int64_t)w.Kp * 2 * w.Dp); w.T2 = take((int64_t)w.Kp * 2 * w.Dp);
     w.c2 = take(w.Kp); w.ck = take(w.Kp);
     w.Wm = take((int64_t)Bp * w.Kp); w.X1 = take((int64_t)Bp * w.XW);
-    w.AC = take((int64_t)Bp * 2 * w.Dp); w.S = take((int64_t)Bp * w.Kp); w.RL = take(Bp);
+    w.AC = take((int64_t)Bp * 2 * w.Dp); w.S = take((int64_t)nss * Bp * w.Kp); w.RL = take(Bp);
     w.G = take((int64_t)ns * w.Kp * w.XW);
     w.total = o;
     return w;
@@ -55,10 +59,9 @@ bool latent_mfma_applies(int D, int K, int mode) { return mode == 0 && (int64_t)
 int64_t latent_mfma_ws_bytes(int B_pad, int D, int K) { return 4 * latent_mfma_layout(B_pad, D, K).total; }
 
 // ---- prior tables -> GEMM operands (tiny: K * D elements)
-__global__ __launch_bounds__(256) void latent_tables_kernel(const float* __restrict__ pm, const float* __restrict__ plv, int K, int D, int Kp, int Dp,
-                                                            float* __restrict__ T1, float* __restrict__ T2, float* __restrict__ c2, float* __restrict__ ck) {
-    const int k = blockIdx.x;          // one block per (padded) cluster row
-    __shared__ float red[8];
+__device__ __forceinline__ void latent_tables_block(const int k, const float* __restrict__ pm, const float* __restrict__ plv, int K, int D, int Kp, int Dp,
+                                                    float* __restrict__ T1, float* __restrict__ T2, float* __restrict__ c2, float* __restrict__ ck, float* red) {
+    // one block per (padded) cluster row k
     float s2 = 0.f, sl = 0.f;
     for (int d = threadIdx.x; d < Dp; d += 256) {
         float ip = 0.f, m = 0.f;
@@ -87,8 +90,14 @@ struct LatentMfmaArgs {
 };
 
 // ---- rows, before the GEMMs.  16 lanes per row, 16 rows per 256-thread block; a lane owns quads of columns.
-__global__ __launch_bounds__(256) void latent_pre_kernel(LatentMfmaArgs L) {
+__global__ __launch_bounds__(256) void latent_pre_kernel(LatentMfmaArgs L, int nrow_blocks) {
     const dmvae_latent_args& a = L.a;
+    if ((int)blockIdx.x >= nrow_blocks) {        // extra workgroups: the prior tables as GEMM operands
+        __shared__ float tred[8];
+        latent_tables_block((int)blockIdx.x - nrow_blocks, a.prior_means, a.prior_log_vars, a.K, a.D, L.w.Kp, L.w.Dp, L.ws + L.w.T1, L.ws + L.w.T2,
+                            L.ws + L.w.c2, L.ws + L.w.ck, tred);
+        return;
+    }
     const int lane16 = threadIdx.x & 15, rsub = threadIdx.x >> 4;
     const int D = a.D, K = a.K, Dp = L.w.Dp, Kp = L.w.Kp, XW = L.w.XW;
     const dmvae_state* st = reinterpret_cast<const dmvae_state*>(a.state);
@@ -229,7 +238,9 @@ __global__ __launch_bounds__(256) void latent_post_kernel(LatentMfmaArgs L, int 
     const int b = blockIdx.x * L.RB + pass * 16 + rsub;
     const bool valid = b < a.B;
     const float* AC = L.ws + L.w.AC + (int64_t)b * 2 * Dp;
-    const float* S = L.ws + L.w.S + (int64_t)b * Kp;
+    const float* S0 = L.ws + L.w.S + (int64_t)b * Kp;
+    const int64_t sstr = (int64_t)a.B_pad * Kp;       // slab stride of G2's K slices
+    auto Ssum = [&](int k) { float v = S0[k]; for (int sl = 1; sl < L.w.nsplit_s; ++sl) v += S0[sl * sstr + k]; return v; };
     const float* Wm = L.ws + L.w.Wm + (int64_t)b * Kp;
     const float* X1 = L.ws + L.w.X1 + (int64_t)b * XW;
     // gradients wrt mean / log_var
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(256) void latent_post_kernel(LatentMfmaArgs L, int 
     float s_wdw = 0.f, s_qdq = 0.f, klz = 0.f;
     for (int k = lane16; k < K; k += 16) {
         const float w = Wm[k];
-        const float t = S[k] + L.ws[L.w.c2 + k] + L.ws[L.w.ck + k] - rl - (float)D;
+        const float t = Ssum(k) + L.ws[L.w.c2 + k] + L.ws[L.w.ck + k] - rl - (float)D;
         klz += 0.5f * w * t;
         const float dq = rB * (__logf(w + 1e-20f) + w / (w + 1e-20f) + logK);
         s_wdw += w * (rB2 * t);
@@ -268,7 +279,7 @@ __global__ __launch_bounds__(256) void latent_post_kernel(LatentMfmaArgs L, int 
         float dl = 0.f;
         if (k < K && valid) {
             const float w = Wm[k];
-            const float t = S[k] + L.ws[L.w.c2 + k] + L.ws[L.w.ck + k] - rl - (float)D;
+            const float t = Ssum(k) + L.ws[L.w.c2 + k] + L.ws[L.w.ck + k] - rl - (float)D;
             const float dq = rB * (__logf(w + 1e-20f) + w / (w + 1e-20f) + logK);
             dl = w * (dq - s_qdq) + w * (rB2 * t - s_wdw);
         }
@@ -305,20 +316,16 @@ int latent_mfma_launch(hipStream_t s, const dmvae_latent_args* a, float* ws, int
     L.RB = a->B_pad / latent_nblocks(a->B_pad, a->D, a->K);        // latent.hip's rows per workgroup (16, 32 or 64)
     const int nrb = a->B_pad / L.RB;
     const double BD = (double)a->B * a->D, BK = (double)a->B * a->K;
-    {
-        ProfScope ps(s, "latent_tables", 0.0, 16.0 * a->K * a->D);
-        hipLaunchKernelGGL(latent_tables_kernel, dim3(w.Kp), dim3(256), 0, s, a->prior_means, a->prior_log_vars, a->K, a->D, w.Kp, w.Dp, ws + w.T1, ws + w.T2, ws + w.c2, ws + w.ck);
-    }
-    {
-        ProfScope ps(s, "latent_pre", 0.0, 4.0 * (BD * (2.0 + (a->eps ? 1.0 : 0.0) + 2.0 + 2.0 + 1.0) + BK * 3.0));
-        hipLaunchKernelGGL(latent_pre_kernel, dim3(nrb), dim3(256), 0, s, L);
+    {   // the prior-table operands ride as Kp extra workgroups of the row kernel (one launch less)
+        ProfScope ps(s, "latent_pre", 0.0, 4.0 * (BD * (2.0 + (a->eps ? 1.0 : 0.0) + 2.0 + 2.0 + 1.0) + BK * 3.0) + 16.0 * a->K * a->D);
+        hipLaunchKernelGGL(latent_pre_kernel, dim3(nrb + w.Kp), dim3(256), 0, s, L, nrb);
     }
     int rc = check_launch("latent_pre");
     if (rc) return rc;
     {
         ProfScope ps(s, "latent_gemm_f32", 2.0 * a->B_pad * (double)w.Kp * (2.0 * w.Dp + 2.0 * w.Dp + w.XW), 4.0 * a->B_pad * (3.0 * w.Kp + 2.0 * w.XW + 2.0 * w.Dp));
         rc = f32_gemm(s, DMVAE_GEMM_FWD, a->B_pad, 2 * w.Dp, w.Kp, ws + w.Wm, w.Kp, ws + w.T1, 2 * w.Dp, ws + w.AC, 2 * w.Dp, 1, 0);
-        if (!rc) rc = f32_gemm(s, DMVAE_GEMM_DX, a->B_pad, w.Kp, 2 * w.Dp, ws + w.X1, w.XW, ws + w.T2, 2 * w.Dp, ws + w.S, w.Kp, 1, 0);
+        if (!rc) rc = f32_gemm(s, DMVAE_GEMM_DX, a->B_pad, w.Kp, 2 * w.Dp, ws + w.X1, w.XW, ws + w.T2, 2 * w.Dp, ws + w.S, w.Kp, w.nsplit_s, (int64_t)a->B_pad * w.Kp);
         if (!rc) rc = f32_gemm(s, DMVAE_GEMM_DW, w.Kp, w.XW, a->B_pad, ws + w.Wm, w.Kp, ws + w.X1, w.XW, ws + w.G, w.XW, w.nsplit, (int64_t)w.Kp * w.XW);
     }
     if (rc) return rc;

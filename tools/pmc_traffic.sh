@@ -3,9 +3,9 @@
 # separate --pmc passes (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2), kernel-trace only;
 # gfx950 correction: FETCH_SIZE reports HALF of the bytes of wide coalesced reads -> doubled;
 # WRITE_SIZE is exact for 16-B/lane stores.  Units: KiB.  Writes profiles/traffic.json and
-# profiles/r01_pmc_traffic.txt.   Run on the GPU box:  tools/pmc_traffic.sh
+# gpurun_out/pmc_traffic.txt.   Run on the GPU box:  tools/pmc_traffic.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --profile-steps 0 --no-graph"
+CMD="python3 bench.py --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --elbo-epochs 0 --profile-steps 0 --no-graph"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_tr/f -- $CMD > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_tr/w -- $CMD > /dev/null 2>&1
 python3 - <<'PY'
@@ -28,6 +28,6 @@ for k in sorted(fe, key=lambda k: -sum(fe[k])):
     lines.append("%-60s launches %4d  fetch(x2) %10.2f MB  write %9.2f MB  total %10.2f MB/launch" % (name[:60], len(fe[k]), f / 1e6, w / 1e6, (f + w) / 1e6))
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/traffic.json", "w"), indent=1)
-open("gpurun_out/r01_pmc_traffic.txt", "w").write("\n".join(lines) + "\n")
+open("gpurun_out/pmc_traffic.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[:16]))
 PY
