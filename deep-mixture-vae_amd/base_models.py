@@ -436,6 +436,108 @@ class DeepMixtureVAE(VAE):
         self._engine.set_parameters(sd)
 
 
-class VaDE(VAE):
-    def __init__(self, *a, **k):
-        raise NotImplementedError("VaDE (base_models.py:435-670) is a different model, outside the DMVAE hot path (SURVEY.md 2.1)")
+class VaDE(DeepMixtureVAE):
+    """code/base_models.py:435-670 on the same HIP kernels: one encoder of FullyConnected layers
+    784 -> 2000 -> 500 -> 500 (:490-499), mean / log_var linear straight off it (:501-507), q(c|x) := p(c|z) =
+    get_cluster_probs(Z) (:526-527, priors.py:91-102) as the mixture weights of the exact KL and as the probabilities of
+    the categorical KL, decoder D -> 500 -> 500 -> 2000 -> input (:530-547).  The per-batch step is the DMVAE step plan
+    with dmvae_config.model = DMVAE_MODEL_VADE: no head hidden layers / logits, latent stage = dmvae_latent_fwd mode 2
+    (csrc/latent_vade.hip), whose gradients include the path through the responsibilities into Z and the prior tables.
+    cnn=True (the reference's convolutional variant, :456-488, ends in fc 2048 -> 128) is not built."""
+
+    def __init__(self, name, input_type, input_dim, latent_dim, n_classes, activation=None, initializer=None, cnn=False, *,
+                 batch_size=100, dtype="bf16", enc_layers=(2000, 500, 500), dec_layers=(500, 500, 2000), noise="device", seed=0,
+                 deterministic=True, session=None):
+        if cnn:
+            raise NotImplementedError("VaDE(cnn=True): the convolutional VaDE encoder (base_models.py:456-488) is not built; "
+                                      "the CNN trunk exists for DeepMixtureVAE (cnn=True)")
+        DeepMixtureVAE.__init__(self, name, input_type, input_dim, latent_dim, n_classes, activation=activation, initializer=initializer,
+                                cnn=False, batch_size=batch_size, dtype=dtype, enc_layers=enc_layers, head_dim=64, dec_layers=dec_layers,
+                                gumbel=False, temperature=1.0, noise=noise, seed=seed, deterministic=deterministic, session=session)
+
+    def build_graph(self):
+        from dmvae_hip import StepEngine, default_session
+        sess = self._session or default_session()
+        self._session = sess
+        enc_spec, prev = [], self.input_dim                   # the two DeepNetwork spec lists exactly as the reference writes them
+        for w in self.enc_layers:
+            enc_spec.append(("fc", {"input_dim": prev, "output_dim": w}))
+            prev = w
+        dec_spec, prev = [], self.latent_dim
+        for w in self.dec_layers:
+            dec_spec.append(("fc", {"input_dim": prev, "output_dim": w}))
+            prev = w
+        self.encoder_network = DeepNetwork("layers", enc_spec, activation="relu", initializer="xavier")
+        self.decoder_network = DeepNetwork("layers", dec_spec, activation="relu", initializer="xavier")
+        self._engine = StepEngine(self.input_dim, self.latent_dim, self.n_classes, enc_layers=self.enc_layers, head_dim=64,
+                                  dec_layers=self.dec_layers, input_type=self.input_type, dtype=self.dtype, max_batch=self.batch_size,
+                                  mode="exact", seed=self.seed + 7919 * sess.rank, deterministic=self.deterministic, session=sess,
+                                  model="vade")
+        self._engine.init_parameters(self.seed)
+        self.X, self.epsilon = "X", "epsilon"
+        self.mean, self.log_var, self.cluster_probs, self.Z = "mean", "log_var", "cluster_probs", "Z"
+        self.decoded_X, self.reconstructed_X = "decoded_X", "reconstructed_X"
+        self.latent_variables = dict()
+        self.latent_variables.update({
+            "Z": (priors.NormalMixtureFactorial("representation", self.latent_dim, self.n_classes, engine=self._engine), self.epsilon,
+                  {"mean": self.mean, "log_var": self.log_var, "cluster_sample": False, "weights": self.cluster_probs}),
+        })
+        self.latent_variables.update({
+            "C": (priors.DiscreteFactorial("cluster", 1, self.n_classes), None, {"probs": self.cluster_probs}),
+        })
+        return self
+
+    def encode(self, X):
+        """(mean, log_var) of q(z|x), base_models.py:501-507 (VaDE has no logits: q(c|x) comes from the sample)."""
+        mean, log_var, _ = DeepMixtureVAE.encode(self, X)
+        return mean, log_var
+
+    def reconstruct(self, X, epsilon=None):
+        mean, log_var = self.encode(X)
+        Z = mean if epsilon is None else mean + np.exp(log_var / 2) * np.asarray(epsilon)
+        return self.decode(Z)
+
+    def cluster_probabilities(self, X, epsilon):
+        """fetching `cluster_probs` with X and epsilon fed (base_models.py:659-663)"""
+        mean, log_var = self.encode(X)
+        Z = mean + np.exp(log_var / 2) * np.asarray(epsilon, dtype=np.float32)
+        return self.latent_variables["Z"][0].get_cluster_probs(Z)
+
+    # ------------------------------------------------------------------ pretraining (base_models.py:573-652)
+    def define_pretrain_step(self, vae_lr, _prior_lr=None):
+        self.define_train_loss()
+        self.vae_loss = "recon"
+        self._vae_lr, self._prior_lr = float(vae_lr), None
+        self.vae_train_step = "adam_tf(recon_loss)"
+        self.prior_train_step = None
+
+    def pretrain_prior(self, session, data, n_epochs):
+        """base_models.py:611-646: only the GMM initialisation of the prior tables (n_init = 5), no Adam stage."""
+        if not self._restore("prior"):
+            print("Could not load pretrained prior parameters")
+            if n_epochs > 0:
+                from sklearn.mixture import GaussianMixture
+                Z = self.encode(data.data)[0]
+                gmm_model = GaussianMixture(n_components=self.n_classes, covariance_type="diag", max_iter=n_epochs,
+                                            n_init=5, weights_init=np.ones(self.n_classes) / self.n_classes)
+                gmm_model.fit(Z)
+                self._engine.set_parameters({"prior_means": gmm_model.means_,
+                                             "prior_log_vars": np.log(gmm_model.covariances_ + 1e-20)})
+                self._save("prior")
+
+    def pretrain(self, session, data, n_epochs_vae, n_epochs_prior):
+        assert(self.vae_train_step is not None)
+        self.pretrain_vae(session, data, n_epochs_vae)
+        self.pretrain_prior(session, data, n_epochs_prior)
+        self._engine.reset_optimizer(getattr(self, "_lr", None))
+
+    def get_accuracy(self, session, data, k=10):
+        """base_models.py:654-670: cluster_probs averaged over k noise draws (the reference's NumPy stream, one
+        sample_reparametrization_variables(n, ["Z"]) per draw over the whole set), then the clustering accuracy."""
+        X = data.data
+        weights = []
+        for _ in range(k):
+            feed = self.sample_reparametrization_variables(len(X), variables=["Z"])
+            weights.append(self.cluster_probabilities(X, feed[self.epsilon]))
+        weights = np.mean(np.array(weights), axis=0)
+        return get_clustering_accuracy(weights, data.classes)

@@ -158,6 +158,7 @@ struct dmvae_plan {
     bool split_odd_dw = false;        // DMVAE_DW_SPLIT=1: 128-aligned part + remainder strip as two dW problems (see grad_dense)
     bool overlap_dw = true;
     bool finalize_rides = true;       // DMVAE_FINALIZE_INLINE=1: step_finalize as its own launch (A/B)
+    bool vade = false;                // cfg.model == DMVAE_MODEL_VADE: no head hidden layers, no logits; latent mode 2
 };
 
 static void add_tensor(dmvae_plan* p, const std::string& name, int64_t off, int rows, int cols, int64_t ld) {
@@ -170,7 +171,9 @@ static void add_tensor(dmvae_plan* p, const std::string& name, int64_t off, int 
 
 extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
     DMVAE_REQUIRE(c && out, "dmvae_plan_create: null argument");
-    DMVAE_REQUIRE(c->input_dim > 0 && c->latent_dim > 0 && c->n_classes > 0 && c->head_dim > 0, "dmvae_plan_create: bad dims");
+    DMVAE_REQUIRE(c->input_dim > 0 && c->latent_dim > 0 && c->n_classes > 0 && (c->head_dim > 0 || c->model == DMVAE_MODEL_VADE), "dmvae_plan_create: bad dims");
+    DMVAE_REQUIRE(c->model == DMVAE_MODEL_DMVAE || (c->model == DMVAE_MODEL_VADE && c->trunk == DMVAE_TRUNK_MLP && c->mode == 0),
+                  "dmvae_plan_create: model %d (0 DMVAE, 1 VaDE; VaDE runs the MLP branch with the exact KL)", c->model);
     DMVAE_REQUIRE(c->n_enc >= 1 && c->n_enc <= DMVAE_MAX_LAYERS && c->n_dec >= 1 && c->n_dec <= DMVAE_MAX_LAYERS, "dmvae_plan_create: 1..%d layers", DMVAE_MAX_LAYERS);
     DMVAE_REQUIRE(c->dtype == DMVAE_F32 || c->dtype == DMVAE_BF16, "dmvae_plan_create: bad dtype");
     DMVAE_REQUIRE(c->max_batch > 0, "dmvae_plan_create: max_batch must be > 0");
@@ -182,7 +185,8 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
     p->Ip = pad64(c->input_dim);
     p->Dp = pad64(c->latent_dim);
     p->Kp = pad64(c->n_classes);
-    p->Hp = pad64(c->head_dim);
+    p->vade = c->model == DMVAE_MODEL_VADE;
+    p->Hp = pad64(p->vade ? 64 : c->head_dim);
     int64_t off = 0;
     auto place = [&](PLayer& L, const std::string& name, int in, int out_, int in_pad, int out_pad) {
         L.name = name; L.in = in; L.out = out_; L.in_pad = in_pad; L.out_pad = out_pad; L.ldw = out_pad;
@@ -222,19 +226,25 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
         prev = c->enc[i]; prev_pad = L.out_pad;
     }
     p->Tp = prev_pad;
-    place(p->zc, "zc", prev, 2 * p->Hp, p->Tp, 2 * p->Hp);
-    add_tensor(p, "W_zh", p->zc.w_off, prev, c->head_dim, p->zc.ldw);
-    add_tensor(p, "b_zh", p->zc.b_off, 1, c->head_dim, 2 * p->Hp);
-    add_tensor(p, "W_ch", p->zc.w_off + p->Hp, prev, c->head_dim, p->zc.ldw);
-    add_tensor(p, "b_ch", p->zc.b_off + p->Hp, 1, c->head_dim, 2 * p->Hp);
-    place(p->mv, "mv", c->head_dim, 2 * p->Dp, p->Hp, 2 * p->Dp);
-    add_tensor(p, "W_mean", p->mv.w_off, c->head_dim, c->latent_dim, p->mv.ldw);
+    if (!p->vade) {
+        place(p->zc, "zc", prev, 2 * p->Hp, p->Tp, 2 * p->Hp);
+        add_tensor(p, "W_zh", p->zc.w_off, prev, c->head_dim, p->zc.ldw);
+        add_tensor(p, "b_zh", p->zc.b_off, 1, c->head_dim, 2 * p->Hp);
+        add_tensor(p, "W_ch", p->zc.w_off + p->Hp, prev, c->head_dim, p->zc.ldw);
+        add_tensor(p, "b_ch", p->zc.b_off + p->Hp, 1, c->head_dim, 2 * p->Hp);
+    }
+    // [mean | log_var]: off the z-hidden layer (DMVAE, base_models.py:234-239) or straight off the trunk (VaDE, :501-507)
+    const int mv_in = p->vade ? prev : c->head_dim, mv_in_pad = p->vade ? p->Tp : p->Hp;
+    place(p->mv, "mv", mv_in, 2 * p->Dp, mv_in_pad, 2 * p->Dp);
+    add_tensor(p, "W_mean", p->mv.w_off, mv_in, c->latent_dim, p->mv.ldw);
     add_tensor(p, "b_mean", p->mv.b_off, 1, c->latent_dim, 2 * p->Dp);
-    add_tensor(p, "W_logvar", p->mv.w_off + p->Dp, c->head_dim, c->latent_dim, p->mv.ldw);
+    add_tensor(p, "W_logvar", p->mv.w_off + p->Dp, mv_in, c->latent_dim, p->mv.ldw);
     add_tensor(p, "b_logvar", p->mv.b_off + p->Dp, 1, c->latent_dim, 2 * p->Dp);
-    place(p->lg, "logits", c->head_dim, c->n_classes, p->Hp, p->Kp);
-    add_tensor(p, "W_logits", p->lg.w_off, c->head_dim, c->n_classes, p->lg.ldw);
-    add_tensor(p, "b_logits", p->lg.b_off, 1, c->n_classes, p->Kp);
+    if (!p->vade) {
+        place(p->lg, "logits", c->head_dim, c->n_classes, p->Hp, p->Kp);
+        add_tensor(p, "W_logits", p->lg.w_off, c->head_dim, c->n_classes, p->lg.ldw);
+        add_tensor(p, "b_logits", p->lg.b_off, 1, c->n_classes, p->Kp);
+    }
     prev = c->latent_dim; prev_pad = p->Dp;
     for (int i = 0; i < c->n_dec; ++i) {
         PLayer L;
@@ -299,9 +309,9 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
     for (auto& L : p->enc) p->o_denc.push_back(take(Bp * L.out_pad * es));
     p->n_rpart = gemm_partials(c->dtype, p->Bp, p->Ip);
     p->o_rpart = take((int64_t)p->n_rpart * 4);
-    p->n_lblk = latent_nblocks(p->Bp, c->latent_dim, c->n_classes);
+    p->n_lblk = p->vade ? latent_vade_nblocks(p->Bp) : latent_nblocks(p->Bp, c->latent_dim, c->n_classes);
     p->o_lpart = take((int64_t)p->n_lblk * 2 * 4);
-    p->lws_bytes = latent_mfma_applies(c->latent_dim, c->n_classes, c->mode) ? latent_mfma_ws_bytes(p->Bp, c->latent_dim, c->n_classes) : 0;
+    p->lws_bytes = (!p->vade && latent_mfma_applies(c->latent_dim, c->n_classes, c->mode)) ? latent_mfma_ws_bytes(p->Bp, c->latent_dim, c->n_classes) : 0;
     p->n_pblk = p->lws_bytes ? 1 : p->n_lblk;          // the MFMA form delivers the prior-table gradient complete, in one row
     p->o_dprior = take((int64_t)p->n_pblk * 2 * KD * 4);
     if (p->lws_bytes) p->o_lws = take(p->lws_bytes);
@@ -495,6 +505,8 @@ static int encode_impl(dmvae_plan* p, hipStream_t s) {
         TRY(fwd_dense(p, s, in, ld, kd, L, L.out_pad, 0, DMVAE_EPI_BIAS_RELU, WS(p, p->o_enc[i]), L.out_pad));
         in = WS(p, p->o_enc[i]); ld = L.out_pad; kd = L.out_pad;
     }
+    if (p->vade)      // VaDE: [mean | log_var] straight off the trunk (base_models.py:501-507), no logits
+        return fwd_dense(p, s, in, ld, kd, p->mv, 2 * p->Dp, 0, DMVAE_EPI_BIAS_F32, WS(p, p->o_mv), 2 * p->Dp);
     TRY(fwd_dense(p, s, in, ld, kd, p->zc, 2 * p->Hp, 0, DMVAE_EPI_BIAS_RELU, WS(p, p->o_hzc), 2 * p->Hp));
     // the two head layers [mean|log_var] = hz.Wmv and logits = hc.Wl are independent siblings:
     // bf16 issues them as one grouped grid (each alone is 64..128 workgroups)
@@ -665,14 +677,14 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     // (wide heads -- the 4096-wide configuration -- take the 256x256 macro-tile kernel one by one instead of the grouped grid)
     const bool heads_big = dt == DMVAE_BF16 && gemm_bf16_256_ok(DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK, p->Bp, p->Hp, 2 * p->Dp, false) &&
                            gemm_bf16_256_ok(DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK, p->Bp, p->Hp, p->Kp, false);
-    const bool fin_rides = all && dt == DMVAE_BF16 && p->finalize_rides && !heads_big;
+    const bool fin_rides = all && dt == DMVAE_BF16 && p->finalize_rides && !heads_big && !p->vade;
   if (all || stage == 0) {
     p->dw_queue.clear();
     TRY(encode_impl(p, s));
 
     dmvae_latent_args la;
     memset(&la, 0, sizeof(la));
-    la.B = n_valid; la.B_pad = p->Bp; la.D = c.latent_dim; la.K = c.n_classes; la.mode = c.mode; la.act_dtype = dt;
+    la.B = n_valid; la.B_pad = p->Bp; la.D = c.latent_dim; la.K = c.n_classes; la.mode = p->vade ? 2 : c.mode; la.act_dtype = dt;
     la.kl_ratio = 1.f; la.temperature = c.temperature; la.inv_B = inv_B; la.seed = c.seed; la.noise_step = 0;
     la.mean = reinterpret_cast<float*>(WS(p, p->o_mv)); la.ld_mean = 2 * p->Dp;
     la.log_var = la.mean + p->Dp; la.ld_log_var = 2 * p->Dp;
@@ -728,7 +740,12 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     }
     TRY(flush_dw(p, s, 0));   // decoder dW group (launched here only when staged / DMVAE_DW_OVERLAP)
   }
-  if (all || stage == 1) {
+  if ((all || stage == 1) && p->vade) {
+    // ---- backward: VaDE's heads are the one linear layer [mean | log_var] off the trunk
+    TRY(grad_dense(p, s, WS(p, p->o_enc[ne - 1]), p->Tp, p->Tp, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->mv.b_off));
+    TRY(dx_dense(p, s, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->Tp, WS(p, p->o_enc[ne - 1]), p->Tp, WS(p, p->o_denc[ne - 1]), p->Tp));
+    TRY(flush_dw(p, s, 1));
+  } else if (all || stage == 1) {
     // ---- backward: heads
     TRY(grad_dense(p, s, WS(p, p->o_hzc), 2 * p->Hp, p->Hp, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->mv.b_off));
     TRY(grad_dense(p, s, act_off(p, p->o_hzc, p->Hp), 2 * p->Hp, p->Hp, WS(p, p->o_dlg), p->Kp, p->Kp, p->lg.w_off, p->lg.ldw, p->lg.b_off));
@@ -746,8 +763,9 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     TRY(flush_dw(p, s, 1));   // heads dW group ([mean|log_var], logits, [zh|ch])
   }
   if (all || stage == 2) {
-    TRY(dx_dense(p, s, WS(p, p->o_dhzc), 2 * p->Hp, 2 * p->Hp, p->zc.w_off, p->zc.ldw, p->Tp, WS(p, p->o_enc[ne - 1]), p->Tp,
-                 WS(p, p->o_denc[ne - 1]), p->Tp));
+    if (!p->vade)
+        TRY(dx_dense(p, s, WS(p, p->o_dhzc), 2 * p->Hp, 2 * p->Hp, p->zc.w_off, p->zc.ldw, p->Tp, WS(p, p->o_enc[ne - 1]), p->Tp,
+                     WS(p, p->o_denc[ne - 1]), p->Tp));
     for (int i = ne - 1; i >= 0; --i) {
         const PLayer& L = p->enc[i];
         const bool cnn = !p->conv.empty();
@@ -785,7 +803,7 @@ extern "C" int dmvae_plan_forward_backward_stage(dmvae_plan* p, void* stream, in
 extern "C" int dmvae_plan_grad_buckets(const dmvae_plan* p, int64_t bounds[4]) {
     DMVAE_REQUIRE(p && bounds, "dmvae_plan_grad_buckets: null pointer");
     bounds[0] = 0;                                   // stage 2 completes [bounds[0], bounds[1])  (trunk)
-    bounds[1] = p->zc.w_off;                         // stage 1 completes [bounds[1], bounds[2])  (heads)
+    bounds[1] = p->vade ? p->mv.w_off : p->zc.w_off; // stage 1 completes [bounds[1], bounds[2])  (heads)
     bounds[2] = p->dec.empty() ? p->out.w_off : p->dec[0].w_off;   // stage 0 completes [bounds[2], bounds[3])  (decoder, prior tables)
     bounds[3] = p->param_elems;
     return 0;
@@ -836,7 +854,7 @@ extern "C" int dmvae_plan_view(const dmvae_plan* p, const char* name, void** ptr
     else if (n == "x") { *ptr = base + p->o_xf; *ld = p->Ip; }
     else if (n == "Z") { *ptr = base + (p->cfg.dtype == DMVAE_BF16 ? p->o_Zf : p->o_Z); *ld = p->Dp; }
     else if (n == "dxlogits") { *ptr = base + p->o_dl; *ld = p->Ip; *dtype = p->cfg.dtype; }
-    else if (n == "hzc") { *ptr = base + p->o_hzc; *ld = 2 * p->Hp; *dtype = p->cfg.dtype; }   // [z-hidden | c-hidden], halves Hp apart
+    else if (n == "hzc" && !p->vade) { *ptr = base + p->o_hzc; *ld = 2 * p->Hp; *dtype = p->cfg.dtype; }   // [z-hidden | c-hidden], halves Hp apart
     else if (n.rfind("enc", 0) == 0 && n.size() == 4 && n[3] - '0' < (int)p->enc.size()) {
         const int i = n[3] - '0';
         *ptr = base + p->o_enc[i]; *ld = p->enc[i].out_pad; *dtype = p->cfg.dtype;
@@ -888,14 +906,15 @@ extern "C" int dmvae_gemm_grouped_dw_adam(void* stream, const dmvae_gemm_problem
 }
 
 extern "C" int dmvae_latent_nblocks(int B_pad, int D, int K) { return latent_nblocks(B_pad, D, K); }
+extern "C" int dmvae_latent_nblocks_vade(int B_pad) { return latent_vade_nblocks(B_pad); }
 extern "C" int64_t dmvae_latent_ws_bytes(int B_pad, int D, int K, int mode) {
     return (B_pad > 0 && B_pad % 64 == 0 && latent_mfma_applies(D, K, mode)) ? latent_mfma_ws_bytes(B_pad, D, K) : 0;
 }
 extern "C" int dmvae_latent_fwd(void* stream, const dmvae_latent_args* a) {
-    DMVAE_REQUIRE(a && a->mean && a->log_var && a->logits && a->prior_means && a->prior_log_vars && a->Z_act && a->gmu && a->glv &&
-                  a->clv && a->dlogits_act && a->dprior_partials && a->loss_partials, "dmvae_latent_fwd: null pointer");
-    DMVAE_REQUIRE(a->mode == 0 || a->mode == 1, "dmvae_latent_fwd: bad mode %d", a->mode);
-    DMVAE_REQUIRE(a->ld_Z >= a->D && a->ld_dl >= a->K && a->ld_g >= a->D, "dmvae_latent_fwd: leading dimension too small");
+    DMVAE_REQUIRE(a && a->mode >= 0 && a->mode <= 2, "dmvae_latent_fwd: bad mode %d", a ? a->mode : -1);
+    DMVAE_REQUIRE(a->mean && a->log_var && (a->logits || a->mode == 2) && a->prior_means && a->prior_log_vars && a->Z_act && a->gmu && a->glv &&
+                  a->clv && (a->dlogits_act || a->mode == 2) && a->dprior_partials && a->loss_partials, "dmvae_latent_fwd: null pointer");
+    DMVAE_REQUIRE(a->ld_Z >= a->D && (a->ld_dl >= a->K || a->mode == 2) && a->ld_g >= a->D, "dmvae_latent_fwd: leading dimension too small");
     return latent_launch((hipStream_t)stream, a);
 }
 extern "C" int dmvae_recon_nblocks(int B_pad, int I_pad) { return recon_nblocks(B_pad, I_pad); }

@@ -31,6 +31,9 @@ void gemm_bf16_set_knob(int which, int v);
 int gemm_f32_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split);
 int latent_nblocks(int B_pad, int D, int K);
 int latent_launch(hipStream_t s, const dmvae_latent_args* a);
+// VaDE's latent stage (latent_vade.hip): mode 2
+int latent_vade_nblocks(int B_pad);
+int latent_vade_launch(hipStream_t s, const dmvae_latent_args* a);
 // MFMA form for large prior tables (latent_mfma.hip)
 bool latent_mfma_applies(int D, int K, int mode);
 int64_t latent_mfma_ws_bytes(int B_pad, int D, int K);

@@ -509,6 +509,7 @@ int latent_launch(hipStream_t s, const dmvae_latent_args* a) {
         set_error("dmvae_latent_fwd: K=%d D=%d needs %zu B of LDS (> 150 KiB); not supported yet", a->K, a->D, lb);
         return DMVAE_EUNSUPPORTED;
     }
+    if (a->mode == 2) return latent_vade_launch(s, a);
     if (a->mfma_ws && latent_mfma_applies(a->D, a->K, a->mode) && a->mfma_ws_bytes >= latent_mfma_ws_bytes(a->B_pad, a->D, a->K))
         return latent_mfma_launch(s, a, reinterpret_cast<float*>(a->mfma_ws), a->mfma_ws_bytes);
     const int nblk = (a->B_pad + L.RB - 1) / L.RB;

@@ -22,9 +22,10 @@ GEMM_FWD, GEMM_DX, GEMM_DW = 0, 1, 2
  EPI_STORE_F32, EPI_ATOMIC_F32, EPI_BIAS_SIGMOID, EPI_ADAM) = range(9)
 MAX_LAYERS = 8
 TRUNK_MLP, TRUNK_CNN = 0, 1
+MODEL_DMVAE, MODEL_VADE = 0, 1
 
 EXPORTS = [
-    "dmvae_gemm", "dmvae_gemm_partials", "dmvae_gemm_grouped_dw", "dmvae_gemm_grouped", "dmvae_gemm_grouped_dw_adam", "dmvae_plan_train_step", "dmvae_latent_ws_bytes",
+    "dmvae_gemm", "dmvae_gemm_partials", "dmvae_gemm_grouped_dw", "dmvae_gemm_grouped", "dmvae_gemm_grouped_dw_adam", "dmvae_plan_train_step", "dmvae_latent_ws_bytes", "dmvae_latent_nblocks_vade",
     "dmvae_plan_forward_backward_stage", "dmvae_plan_grad_buckets", "dmvae_plan_update_range",
 "dmvae_latent_nblocks", "dmvae_latent_fwd",
     "dmvae_recon_fwd_bwd", "dmvae_recon_nblocks", "dmvae_colsum", "dmvae_loss_finalize",
@@ -106,6 +107,7 @@ class Config(C.Structure):
         ("input_type", C.c_int32), ("dtype", C.c_int32), ("max_batch", C.c_int32), ("mode", C.c_int32),
         ("temperature", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
         ("seed", C.c_uint64), ("deterministic", C.c_int32), ("trunk", C.c_int32),
+        ("model", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -148,6 +150,7 @@ def _load():
         "dmvae_plan_grad_buckets": [vp, P(i64)],
         "dmvae_plan_update_range": [vp, vp, f32, i64, i64],
         "dmvae_latent_nblocks": [i32, i32, i32],
+        "dmvae_latent_nblocks_vade": [i32],
         "dmvae_latent_ws_bytes": [i32, i32, i32, i32],
         "dmvae_latent_fwd": [vp, P(LatentArgs)],
         "dmvae_recon_fwd_bwd": [vp, i32, i32, i32, i32, i32, i32, vp, i64, vp, i64, f32, vp, i64, vp],

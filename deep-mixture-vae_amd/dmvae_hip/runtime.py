@@ -61,6 +61,22 @@ CONV_STACK = (("conv0", 1, 32, 28, False), ("conv1", 32, 32, 28, True), ("conv2"
 CONV_FLAT = 4 * 4 * 128
 
 
+def vade_layer_table(input_dim, latent_dim, enc_layers, dec_layers):
+    """VaDE (base_models.py:490-547): FullyConnected encoder / decoder layers (xavier bias), tf.layers.dense mean /
+    log_var straight off the trunk and output layer (zero bias)."""
+    t, prev = [], input_dim
+    for i, h in enumerate(enc_layers):
+        t.append(("enc%d" % i, prev, h, "xavier"))
+        prev = h
+    t += [("mean", prev, latent_dim, "zero"), ("logvar", prev, latent_dim, "zero")]
+    prev = latent_dim
+    for i, h in enumerate(dec_layers):
+        t.append(("dec%d" % i, prev, h, "xavier"))
+        prev = h
+    t.append(("out", prev, input_dim, "zero"))
+    return t
+
+
 def layer_table(input_dim, latent_dim, n_classes, enc_layers, head_dim, dec_layers, cnn=False):
     """[(name, fan_in, fan_out, bias_kind)] in graph-construction order
     (base_models.py:218-293).  bias_kind: 'zero' = tf.layers.dense default,
@@ -91,8 +107,11 @@ class StepEngine:
     def __init__(self, input_dim, latent_dim, n_classes, enc_layers=(500, 500), head_dim=2000,
                  dec_layers=(2000, 500, 500), input_type="binary", dtype="bf16", max_batch=100,
                  mode="exact", temperature=1.0, seed=0, deterministic=False, session=None,
-                 beta1=0.9, beta2=0.999, adam_eps=1e-8, cnn=False):
+                 beta1=0.9, beta2=0.999, adam_eps=1e-8, cnn=False, model="dmvae"):
         self.cnn = bool(cnn)
+        self.model = model
+        if model not in ("dmvae", "vade"):
+            raise ValueError("model must be 'dmvae' or 'vade'")
         self.session = session or default_session()
         dev = self.session.device
         self.device = dev
@@ -122,6 +141,7 @@ class StepEngine:
         cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         cfg.deterministic = 1 if deterministic else 0
         cfg.trunk = _lib.TRUNK_CNN if self.cnn else _lib.TRUNK_MLP
+        cfg.model = _lib.MODEL_VADE if model == "vade" else _lib.MODEL_DMVAE
         self._cfg = cfg
         h = C.c_void_p()
         check(lib.dmvae_plan_create(C.byref(cfg), C.byref(h)), "dmvae_plan_create")
@@ -206,8 +226,9 @@ class StepEngine:
                 p["W_" + name] = rng.uniform(-lim, lim, size=(9 * ci, co))
                 lb = math.sqrt(6.0 / (co + co))
                 p["b_" + name] = rng.uniform(-lb, lb, size=(co,))
-        for name, fi, fo, bk in layer_table(self.input_dim, self.latent_dim, self.n_classes,
-                                            self.enc_layers, self.head_dim, self.dec_layers, self.cnn):
+        table = (vade_layer_table(self.input_dim, self.latent_dim, self.enc_layers, self.dec_layers) if self.model == "vade" else
+                 layer_table(self.input_dim, self.latent_dim, self.n_classes, self.enc_layers, self.head_dim, self.dec_layers, self.cnn))
+        for name, fi, fo, bk in table:
             lim = math.sqrt(6.0 / (fi + fo))
             p["W_" + name] = rng.uniform(-lim, lim, size=(fi, fo))
             if bk == "zero":
@@ -400,8 +421,14 @@ class StepEngine:
     def hidden_activations(self, rows=None):
         """{layer name: activation [rows, width]} of the ReLU layers of the last
         forward pass, under the names the parameters use (enc<i>, zh, ch, dec<i>)."""
-        hp = self.view("hzc", rows).shape[1] // 2
         out = {}
+        if self.model == "vade":
+            for i, w in enumerate(self.enc_layers):
+                out["enc%d" % i] = self.view("enc%d" % i, rows, w)
+            for i, w in enumerate(self.dec_layers):
+                out["dec%d" % i] = self.view("dec%d" % i, rows, w)
+            return out
+        hp = self.view("hzc", rows).shape[1] // 2
         if self.cnn:                          # [rows, H, W, channels] relu outputs of the conv layers
             for i, (name, _, co, hw, _) in enumerate(CONV_STACK):
                 out[name] = self.view(name, rows)
@@ -532,12 +559,12 @@ def latent_eval(mean, log_var, logits, prior_means, prior_log_vars, eps=None, gu
     w = torch.zeros((Bp, K), dtype=torch.float32, device=dev)
     gmu, glv, clv = (torch.zeros((Bp, ldD), dtype=torch.float32, device=dev) for _ in range(3))
     dlg = torch.zeros((Bp, ldK), dtype=torch.float32, device=dev)
-    nblk = lib.dmvae_latent_nblocks(Bp, D, K)
+    nblk = lib.dmvae_latent_nblocks_vade(Bp) if mode == "vade" else lib.dmvae_latent_nblocks(Bp, D, K)
     dpri = torch.zeros((nblk, 2 * K * D), dtype=torch.float32, device=dev)
     lp = torch.zeros((nblk, 2), dtype=torch.float32, device=dev)
     a = _lib.LatentArgs()
     a.B, a.B_pad, a.D, a.K = B, Bp, D, K
-    a.mode, a.act_dtype = {"exact": 0, "relaxed": 1}[mode], _lib.F32
+    a.mode, a.act_dtype = {"exact": 0, "relaxed": 1, "vade": 2}[mode], _lib.F32
     a.kl_ratio, a.temperature, a.inv_B = float(kl_ratio), float(temperature), 1.0 / B
     a.mean, a.ld_mean = md.data_ptr(), ldD
     a.log_var, a.ld_log_var = lvd.data_ptr(), ldD

@@ -121,8 +121,13 @@ class NormalMixtureFactorial(LatentVariable):
                             self.means, self.log_vars, eps=epsilon)["Z"]
 
     def get_cluster_probs(self, Z):
-        raise NotImplementedError("get_cluster_probs is used by VaDE only (base_models.py:526-527); "
-                                  "VaDE is outside the DMVAE hot path (SURVEY.md 2.1)")
+        """priors.py:91-102: softmax_k of -1/2 [sum_d (z - mu_k)^2 / sigma_k^2 + sum_d log sigma_k^2] -- what VaDE uses as
+        q(c|x) (base_models.py:526-527).  Evaluated by the VaDE mode of the HIP latent kernel (dmvae_latent_fwd mode 2,
+        csrc/latent_vade.hip) with mean = Z and epsilon = 0, so that its sample IS Z."""
+        Z = np.asarray(Z, dtype=np.float32)
+        zeros = np.zeros_like(Z)
+        return _latent_eval(Z, zeros, np.zeros((len(Z), self.n_classes), np.float32), self.means, self.log_vars,
+                            eps=zeros, mode="vade")["weights"]
 
     def kl_from_prior(self, parameters, eps=1e-20):
         assert(

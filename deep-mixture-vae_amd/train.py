@@ -5,7 +5,7 @@ Multi-GPU (one process per GPU, RCCL gradient all-reduce):
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py --batch_size 32768
 (with more than one rank only full global batches are trained: the batch must not exceed the row count)
 Flags that the reference accepts but that address models outside the DMVAE hot
-path (--model vade/dmoe/dvmoe/vademoe, --visdom) are parsed and rejected /
+path (--model dmoe/dvmoe/vademoe, --visdom) are parsed and rejected /
 ignored with a message, see SURVEY.md 2.1.  --plotting writes the reference's
 two figures (regenerated.png, sampled.png) as PNG grids.  --pretrain runs the two
 pretraining stages of base_models.py:304-423 (recon-only Adam at epsilon = 0,
@@ -94,9 +94,9 @@ def main(argv):
     np.random.seed(argv.seed)
 
     model_str, model_name = argv.model, argv.model_name
-    if model_str[-3:] == "moe" or model_str == "vade":
-        raise NotImplementedError("--model %s: only the DMVAE ELBO path is built (SURVEY.md 2.1, 8)" % model_str)
-    if model_str != "dmvae":
+    if model_str[-3:] == "moe":
+        raise NotImplementedError("--model %s: only the ELBO path of the clustering VAEs (dmvae, vade) is built (SURVEY.md 2.1, 8)" % model_str)
+    if model_str not in ("dmvae", "vade"):
         raise NotImplementedError
     plotting = argv.plotting and rank == 0 and argv.dataset == "mnist"   # train.py:157-163: plots exist for the image sets
     if argv.visdom and rank == 0:
@@ -116,14 +116,22 @@ def main(argv):
         raise ValueError("--batch_size must be divisible by the number of ranks")
 
     sess = Session()
-    model = base_models.DeepMixtureVAE(
-        model_name, dataset.input_type, dataset.input_dim, argv.latent_dim, n_clusters,
-        activation="relu", initializer="xavier", cnn=argv.cnn,
-        batch_size=argv.batch_size // world, dtype=argv.dtype,
-        enc_layers=[int(v) for v in argv.enc_layers.split(",")], head_dim=argv.head_dim,
-        dec_layers=[int(v) for v in argv.dec_layers.split(",")], gumbel=argv.gumbel, temperature=argv.temperature,
-        noise="host" if argv.host_noise else "device", seed=argv.seed, session=sess
-    ).build_graph()
+    if model_str == "vade":           # train.py:199-203; its layer widths are literals of the class (2000,500,500 / 500,500,2000)
+        model = base_models.VaDE(
+            model_name, dataset.input_type, dataset.input_dim, argv.latent_dim, n_clusters,
+            activation="relu", initializer="xavier", cnn=argv.cnn,
+            batch_size=argv.batch_size // world, dtype=argv.dtype,
+            noise="host" if argv.host_noise else "device", seed=argv.seed, session=sess
+        ).build_graph()
+    else:
+        model = base_models.DeepMixtureVAE(
+            model_name, dataset.input_type, dataset.input_dim, argv.latent_dim, n_clusters,
+            activation="relu", initializer="xavier", cnn=argv.cnn,
+            batch_size=argv.batch_size // world, dtype=argv.dtype,
+            enc_layers=[int(v) for v in argv.enc_layers.split(",")], head_dim=argv.head_dim,
+            dec_layers=[int(v) for v in argv.dec_layers.split(",")], gumbel=argv.gumbel, temperature=argv.temperature,
+            noise="host" if argv.host_noise else "device", seed=argv.seed, session=sess
+        ).build_graph()
 
     # dmvae trains on train + test rows (train.py:205-213)
     train_data = np.concatenate([dataset.train_data, dataset.test_data], axis=0)

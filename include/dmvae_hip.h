@@ -137,7 +137,7 @@ int dmvae_gemm_grouped_dw_adam(void* stream, const dmvae_gemm_problem* probs, in
 /* ---- latent kernel: softmax + reparameterisation + mixture KL + all KL gradients
  * replaces priors.py:86-89 (Z), :104-147 (KL_Z exact / relaxed), :170-181
  * (Gumbel-Softmax), :183-201 (KL_C), base_models.py:249 (softmax) and their
- * tf.gradients.  mode 0 = exact (cluster_sample False, live), 1 = relaxed. */
+ * tf.gradients.  mode 0 = exact (cluster_sample False, live), 1 = relaxed, 2 = VaDE (below). */
 typedef struct dmvae_latent_args {
     int32_t B;            /* rows that are real; rows [B, B_pad) are written as zeros */
     int32_t B_pad;
@@ -172,6 +172,10 @@ typedef struct dmvae_latent_args {
     void* mfma_ws; int64_t mfma_ws_bytes;
 } dmvae_latent_args;
 int dmvae_latent_nblocks(int B_pad, int D, int K);
+/* mode 2 (VaDE, csrc/latent_vade.hip): weights = get_cluster_probs(Z) of the SAMPLE (priors.py:91-102) for both KL terms,
+ * gradients through them included; logits / gumbel / dlogits_act are ignored (may be NULL); `weights` receives the
+ * responsibilities.  It writes dmvae_latent_nblocks_vade(B_pad) = B_pad / 16 blocks of partials. */
+int dmvae_latent_nblocks_vade(int B_pad);
 int64_t dmvae_latent_ws_bytes(int B_pad, int D, int K, int mode);   /* 0 when the MFMA form does not apply */
 int dmvae_latent_fwd(void* stream, const dmvae_latent_args* a);
 
@@ -248,6 +252,13 @@ int dmvae_cast_bf16_to_f32(void* stream, const void* in, float* out, int64_t n);
  * "W_conv<i>" [9*Cin][Cout] = the HWIO kernel flattened (ld = Cout padded to 64) and "b_conv<i>" [Cout]. */
 #define DMVAE_TRUNK_MLP 0
 #define DMVAE_TRUNK_CNN 1
+/* Model.  DMVAE: base_models.py:150-302 (trunk, z-head and c-head with a hidden layer each, q(c|x) = softmax(logits)).
+ * VaDE: base_models.py:435-562 -- n_enc FullyConnected trunk layers, mean / log_var linear straight off the trunk (no
+ * head hidden layers, no logits: head_dim is ignored), q(c|x) := p(c|z) = get_cluster_probs(Z) (priors.py:91-102) as the
+ * mixture weights AND the categorical probabilities; the latent stage is dmvae_latent_fwd mode 2.  Tensor table: W_enc<i>,
+ * b_enc<i>, W_mean, b_mean, W_logvar, b_logvar, W_dec<i>, b_dec<i>, W_out, b_out, prior_means, prior_log_vars. */
+#define DMVAE_MODEL_DMVAE 0
+#define DMVAE_MODEL_VADE 1
 
 typedef struct dmvae_config {
     int32_t input_dim, latent_dim, n_classes;
@@ -263,6 +274,8 @@ typedef struct dmvae_config {
     uint64_t seed;
     int32_t deterministic;                           /* 1: no float atomics anywhere             */
     int32_t trunk;                                   /* DMVAE_TRUNK_MLP (default) or DMVAE_TRUNK_CNN */
+    int32_t model;                                   /* DMVAE_MODEL_DMVAE (default) or DMVAE_MODEL_VADE */
+    int32_t reserved;
 } dmvae_config;
 
 typedef struct dmvae_tensor_info {

@@ -484,6 +484,139 @@ def backward(p, cfg, a, masks=None):
 
 
 # --------------------------------------------------------------------------
+# VaDE (base_models.py:435-562): one encoder 784 -> 2000 -> 500 -> 500 of FullyConnected layers,
+# mean / log_var heads straight off the trunk, q(c|x) := p(c|z) = get_cluster_probs(Z)
+# --------------------------------------------------------------------------
+
+
+class VadeConfig:
+    """Shapes of VaDE's MLP branch (base_models.py:490-499, :530-547): encoder and decoder are DeepNetworks of
+    ("fc", ...) specs = FullyConnected layers, whose (1, out) bias is xavier-initialised like the weight
+    (includes/layers.py:24-28); the mean / log_var / output layers are tf.layers.dense (zero bias)."""
+
+    def __init__(self, input_dim=784, latent_dim=10, n_classes=10, enc_layers=(2000, 500, 500), dec_layers=(500, 500, 2000),
+                 input_type="binary"):
+        self.input_dim, self.latent_dim, self.n_classes = int(input_dim), int(latent_dim), int(n_classes)
+        self.enc_layers = tuple(int(v) for v in enc_layers)
+        self.dec_layers = tuple(int(v) for v in dec_layers)
+        self.input_type = input_type
+        self.cnn = False
+
+    def layer_table(self):
+        t, prev = [], self.input_dim
+        for i, h in enumerate(self.enc_layers):
+            t.append(("enc%d" % i, prev, h, "xavier"))
+            prev = h
+        t.append(("mean", prev, self.latent_dim, "zero"))
+        t.append(("logvar", prev, self.latent_dim, "zero"))
+        prev = self.latent_dim
+        for i, h in enumerate(self.dec_layers):
+            t.append(("dec%d" % i, prev, h, "xavier"))
+            prev = h
+        t.append(("out", prev, self.input_dim, "zero"))
+        return t
+
+    def conv_table(self):
+        return ()
+
+    def n_params(self):
+        return sum(fi * fo + fo for _, fi, fo, _ in self.layer_table()) + 2 * self.n_classes * self.latent_dim
+
+
+def vade_forward(p, cfg, X, epsilon, kl_ratio=1.0):
+    """base_models.py:443-562 + :66-93: Z = mean + exp(log_var/2) eps; cluster_probs = get_cluster_probs(Z)
+    (priors.py:91-102) are the mixture weights of the exact KL (priors.py:131-145, cluster_sample False) AND the
+    probabilities of the categorical KL (priors.py:183-201, "probs" branch)."""
+    a = {"x": X, "eps": epsilon}
+    h = X
+    for i in range(len(cfg.enc_layers)):
+        h = _dense(h, p["W_enc%d" % i], p["b_enc%d" % i], True)
+        a["enc%d" % i] = h
+    a["mean"] = _dense(h, p["W_mean"], p["b_mean"], False)
+    a["logvar"] = _dense(h, p["W_logvar"], p["b_logvar"], False)
+    a["Z"] = gaussian_reparam(a["mean"], a["logvar"], epsilon)
+    decode(p, cfg, a["Z"], a)
+    a["w"] = cluster_probs(a["Z"], p["prior_means"], p["prior_log_vars"])
+    a["kl_z"] = kl_mixture_exact(a["mean"], a["logvar"], a["w"], p["prior_means"], p["prior_log_vars"])
+    q = a["w"]
+    a["kl_c"] = np.mean(np.sum(q * (np.log(q + 1e-20) - np.log(1.0 / cfg.n_classes)), axis=1))
+    a["recon"] = recon_loss(cfg, X, a["xlogits"])
+    a["latent"] = a["kl_c"] + a["kl_z"]
+    a["loss"] = a["recon"] + kl_ratio * a["latent"]
+    a["kl_ratio"] = kl_ratio
+    return a
+
+
+def vade_latent_backward(cfg, a, p, dZ_dec):
+    """Hand-derived gradient of kl_ratio * (KL_C + KL_Z) for VaDE, where the weights gamma = softmax_k(u),
+    u_k = -1/2 [sum_d (z_d - pm_kd)^2 ip_kd + sum_d plv_kd] depend on Z (hence on mean, log_var, eps) and on the prior
+    tables.  Returns dmean, dlogvar, dprior_means, dprior_log_vars, and the two latent outputs the kernel hands to
+    the dZ GEMM epilogue: gmu' = dKL/dmean (direct + through Z), glv' = dKL/dlog_var (direct + through Z)."""
+    mu, lv, eps, Z, g = a["mean"], a["logvar"], a["eps"], a["Z"], a["w"]
+    pm, plv = p["prior_means"], p["prior_log_vars"]
+    B, K, r, e0 = mu.shape[0], cfg.n_classes, a["kl_ratio"], 1e-20
+    e, ip = np.exp(lv), np.exp(-plv)
+    diff = mu[:, None, :] - pm[None]                                   # (B,K,D)
+    T = np.sum(plv[None] - lv[:, None, :] - 1 + (e[:, None, :] + diff ** 2) * ip[None], axis=2)
+    G = (r / B) * (0.5 * T + np.log(g + e0) + g / (g + e0) + math.log(K))          # dL/dgamma
+    du = g * (G - np.sum(g * G, axis=1, keepdims=True))                 # softmax backward -> dL/du
+    zd = Z[:, None, :] - pm[None]
+    dZl = -np.sum(du[:, :, None] * zd * ip[None], axis=1)               # through gamma(Z)
+    gmu = (r / B) * np.sum(g[:, :, None] * diff * ip[None], axis=1)
+    glv = (r / (2 * B)) * (e * (g @ ip) - 1)
+    dpm = -(r / B) * np.sum(g[:, :, None] * diff * ip[None], axis=0) + np.sum(du[:, :, None] * zd * ip[None], axis=0)
+    dplv = (r / (2 * B)) * np.sum(g[:, :, None] * (1 - (e[:, None, :] + diff ** 2) * ip[None]), axis=0) \
+        + np.sum(du[:, :, None] * 0.5 * (zd ** 2 * ip[None] - 1), axis=0)
+    clv = eps * 0.5 * np.exp(lv / 2)
+    gmu2, glv2 = gmu + dZl, glv + dZl * clv
+    return dZ_dec + gmu2, dZ_dec * clv + glv2, dpm, dplv, gmu2, glv2
+
+
+def vade_backward(p, cfg, a, masks=None):
+    """gradient of a["loss"] w.r.t. every trainable of the VaDE graph (what optimizer.minimize derives)"""
+    if masks is not None:
+        a = dict(a)
+        for k, mk in masks.items():
+            a[k] = np.where(mk, np.maximum(a[k], 1e-300), 0.0)
+    g = {}
+    X = a["x"]
+    B = X.shape[0]
+    dl = ((1.0 / (1.0 + np.exp(-a["xlogits"])) - X) if cfg.input_type == "binary" else (a["xlogits"] - X)) / B
+    nd = len(cfg.dec_layers)
+    g["W_out"] = a["dec%d" % (nd - 1)].T @ dl
+    g["b_out"] = dl.sum(0)
+    dh = dl @ p["W_out"].T
+    for i in reversed(range(nd)):
+        dy = dh * (a["dec%d" % i] > 0)
+        xin = a["dec%d" % (i - 1)] if i > 0 else a["Z"]
+        g["W_dec%d" % i] = xin.T @ dy
+        g["b_dec%d" % i] = dy.sum(0)
+        dh = dy @ p["W_dec%d" % i].T
+    dmean, dlogvar, dpm, dplv, _, _ = vade_latent_backward(cfg, a, p, dh)
+    g["prior_means"], g["prior_log_vars"] = dpm, dplv
+    ne = len(cfg.enc_layers)
+    trunk = a["enc%d" % (ne - 1)]
+    g["W_mean"], g["b_mean"] = trunk.T @ dmean, dmean.sum(0)
+    g["W_logvar"], g["b_logvar"] = trunk.T @ dlogvar, dlogvar.sum(0)
+    dh = dmean @ p["W_mean"].T + dlogvar @ p["W_logvar"].T
+    for i in reversed(range(ne)):
+        dy = dh * (a["enc%d" % i] > 0)
+        xin = a["enc%d" % (i - 1)] if i > 0 else X
+        g["W_enc%d" % i] = xin.T @ dy
+        g["b_enc%d" % i] = dy.sum(0)
+        if i > 0:
+            dh = dy @ p["W_enc%d" % i].T
+    return g
+
+
+def vade_train_step(p, m, v, t, cfg, X, epsilon, kl_ratio=1.0, lr=0.002):
+    a = vade_forward(p, cfg, X, epsilon, kl_ratio)
+    g = vade_backward(p, cfg, a)
+    adam_tf(p, g, m, v, t, lr)
+    return a, g
+
+
+# --------------------------------------------------------------------------
 # Optimizer and epoch semantics
 # --------------------------------------------------------------------------
 

@@ -34,7 +34,7 @@ def test_ctypes_structs_match_header_layout():
     assert C.sizeof(_lib.Buffers) == 8 * 8
     assert C.sizeof(_lib.TensorInfo) == 32 + 8 + 4 + 4 + 8
     assert C.sizeof(_lib.ProfRow) == 48 + 8 + 8 + 8 + 8
-    assert C.sizeof(_lib.Config) == 4 * 3 + 4 + 32 + 4 + 4 + 32 + 4 * 4 + 4 * 4 + 8 + 4 + 4
+    assert C.sizeof(_lib.Config) == 4 * 3 + 4 + 32 + 4 + 4 + 32 + 4 * 4 + 4 * 4 + 8 + 4 + 4 + 4 + 4
 
 
 def test_plan_layout_without_gpu():
