@@ -146,6 +146,22 @@ class DeepMixtureVAE(VAE):
             prev = w
         self.decoder_network = DeepNetwork("layers", spec, activation="relu", initializer="xavier")
         assert self.decoder_network.widths() == self.dec_layers
+        if self.cnn:
+            # the encoder as the reference specifies it (base_models.py:179-205): the DeepNetwork spec list drives the plan's
+            # CNN trunk -- the plan implements exactly this stack, any other list is refused here rather than silently ignored
+            from dmvae_hip.runtime import CONV_STACK, CONV_FLAT
+            enc_spec = [("cn", {"n_kernels": 32, "prev_n_kernels": 1, "kernel": (3, 3)}),
+                        ("cn", {"n_kernels": 32, "prev_n_kernels": 32, "kernel": (3, 3)}), ("mp", {"k": 2}),
+                        ("cn", {"n_kernels": 64, "prev_n_kernels": 32, "kernel": (3, 3)}),
+                        ("cn", {"n_kernels": 64, "prev_n_kernels": 64, "kernel": (3, 3)}), ("mp", {"k": 2}),
+                        ("cn", {"n_kernels": 128, "prev_n_kernels": 64, "kernel": (3, 3)}),
+                        ("cn", {"n_kernels": 128, "prev_n_kernels": 128, "kernel": (3, 3)}), ("mp", {"k": 2}),
+                        ("fc", {"input_dim": 2048, "output_dim": self.enc_layers[0]})]
+            self.encoder_network = DeepNetwork("layers", enc_spec, activation="relu", initializer="xavier")
+            stack, side = self.encoder_network.conv_stack(28)
+            if stack != tuple((ci, co, hw, pool) for _, ci, co, hw, pool in CONV_STACK) or side * side * stack[-1][1] != CONV_FLAT:
+                raise NotImplementedError("the plan's CNN trunk is the stack of base_models.py:181-202; got %r" % (stack,))
+            assert self.encoder_network.widths() == self.enc_layers
         self._engine = StepEngine(self.input_dim, self.latent_dim, self.n_classes, enc_layers=self.enc_layers,
                                   head_dim=self.head_dim, dec_layers=self.dec_layers, input_type=self.input_type,
                                   dtype=self.dtype, max_batch=self.batch_size, mode="relaxed" if self.gumbel else "exact",

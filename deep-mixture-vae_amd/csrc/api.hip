@@ -105,6 +105,8 @@ using namespace dmvae;
 // ====================================================================== plan
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+static int conv_dw_split(int64_t K, int tiles);
+
 struct PLayer {
     std::string name;
     int in, out, in_pad, out_pad;
@@ -130,7 +132,7 @@ struct dmvae_plan {
     dmvae_config cfg;
     std::vector<PConv> conv;          // cfg.trunk == DMVAE_TRUNK_CNN only
     int flat = 0;                     // 4*4*128 = 2048: width of the flattened pool output feeding enc0
-    int64_t o_dflat = 0, o_wt = 0, o_c0part = 0;
+    int64_t o_dflat = 0, o_wt = 0, o_c0part = 0, o_cslab = 0;     // o_cslab: K-slice slabs of the conv weight gradients (cfg.deterministic)
     int64_t conv_param_end = 0;
     int Bp, Ip, Dp, Kp, Hp, Tp;   // padded batch / input / latent / classes / head / trunk
     int es;                        // bytes per activation element
@@ -287,6 +289,15 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
             p->o_wt = take(wmax * es);
             p->o_dflat = take(Bp * p->flat * es);
             p->o_c0part = take((int64_t)conv_first_dw_blocks(p->conv.front().hw, Bp) * 320 * 4);
+            if (c->deterministic) {      // split-K slabs instead of float atomics: the largest layer's split x (kdim + 1) x cout_np floats
+                int64_t mx = 0;
+                for (size_t i = 1; i < p->conv.size(); ++i) {
+                    const PConv& L = p->conv[i];
+                    const int sp = conv_dw_split((int64_t)Bp * L.P * L.P, (L.kdim / 64) * (L.cout_np / 64));
+                    mx = std::max<int64_t>(mx, (int64_t)sp * (L.kdim + 1) * L.cout_np);
+                }
+                p->o_cslab = take(mx * 4);
+            }
         }
     }
     for (auto& L : p->enc) p->o_enc.push_back(take(Bp * L.out_pad * es));
@@ -477,8 +488,25 @@ static int conv_trunk_backward(dmvae_plan* p, hipStream_t s) {
         const PConv& Lp = p->conv[i - 1];
         const char* in = Lp.pool ? rows0(p, Lp.o_pool, L.P, L.cin_ld) : rows0(p, Lp.o_act, L.P, L.cin_ld);
         e.out = p->buf.grad + L.w_off; e.out2 = p->buf.grad + L.b_off;
-        TRY(gemm_checked(s, dt, DMVAE_GEMM_DW, L.kdim, L.cout_np, M, in, L.cin_ld, dact, L.cout_ld, &e,
-                         conv_dw_split(M, (L.kdim / 64) * (L.cout_np / 64)), nullptr, L.P, L.cin));
+        const int sp = conv_dw_split(M, (L.kdim / 64) * (L.cout_np / 64));
+        if (p->cfg.deterministic && sp > 1) {
+            // K slice y stores its partial product (and bias-gradient partial) into slab y; the slabs are then added in
+            // ascending order: bit-reproducible, no float atomics (the atomic form drifts after a few Adam steps)
+            float* slab = reinterpret_cast<float*>(WS(p, p->o_cslab));
+            const int64_t wn = (int64_t)L.kdim * L.cout_np;
+            e.kind = DMVAE_EPI_STORE_F32; e.out = slab; e.out2 = slab + (int64_t)sp * wn;
+            GemmArgs g;
+            TRY(gemm_checked(s, dt, DMVAE_GEMM_DW, L.kdim, L.cout_np, M, in, L.cin_ld, dact, L.cout_ld, &e, 1, &g, L.P, L.cin));
+            g.k_split = M / sp; g.slab_stride = wn; g.slab_stride2 = L.cout_np;
+            if (dt == DMVAE_BF16) TRY(gemm_bf16_dispatch(s, DMVAE_GEMM_DW, g, sp));
+            else {
+                ProfScope ps(s, "gemm_f32_dw", 2.0 * g.M * g.N * (double)g.K, 4.0 * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N));
+                TRY(gemm_f32_dispatch(s, DMVAE_GEMM_DW, g, sp));
+            }
+            TRY(slab_reduce_launch(s, slab, wn, sp, wn, p->buf.grad + L.w_off));
+            TRY(slab_reduce_launch(s, slab + (int64_t)sp * wn, L.cout_np, sp, L.cout_np, p->buf.grad + L.b_off));
+        } else
+        TRY(gemm_checked(s, dt, DMVAE_GEMM_DW, L.kdim, L.cout_np, M, in, L.cin_ld, dact, L.cout_ld, &e, sp, nullptr, L.P, L.cin));
         if (L.kdim > 9 * L.cin) {   // rows past the ninth tap are padding: the GEMM filled them with a copy of tap 8
             me = hipMemsetAsync(p->buf.grad + L.w_off + (int64_t)9 * L.cin * L.cout_np, 0, (size_t)(L.kdim - 9 * L.cin) * L.cout_np * 4, s);
             if (me != hipSuccess) { set_error("conv gradient pad memset: %s", hipGetErrorString(me)); return (int)me; }

@@ -2,6 +2,8 @@
 // gradients / reduction of per-block partials), stand-alone reconstruction
 // loss, batch assembly, Philox noise, casts, loss finalize.
 // All loads/stores are 16 B per lane where the layout allows.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace dmvae {
@@ -122,6 +124,26 @@ int colsum_launch(hipStream_t s, int in_dtype, const void* in, int64_t ld, int M
     else hipLaunchKernelGGL(colsum_kernel<float>, dim3(strips, slabs), dim3(256), 0, s, (const float*)in, ld, M, N, rps, ws, (int64_t)N);
     hipLaunchKernelGGL(colsum_kernel<float>, dim3(strips, 1), dim3(256), 0, s, (const float*)ws, (int64_t)N, slabs, N, slabs, out, (int64_t)0);
     return check_launch("colsum");
+}
+
+// ---------------------------------------------------------------- slab reduction (deterministic split-K)
+// out[i] = slab[0][i] + slab[1][i] + ... in ascending order; n a multiple of 4, 16-byte accesses
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int64_t n4, int nslab, int64_t stride4, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 a = reinterpret_cast<const float4*>(slabs)[i];
+        for (int s = 1; s < nslab; ++s) {
+            const float4 b = reinterpret_cast<const float4*>(slabs)[(int64_t)s * stride4 + i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = a;
+    }
+}
+int slab_reduce_launch(hipStream_t s, const float* slabs, int64_t n, int nslab, int64_t stride, float* out) {
+    if (n % 4 || stride % 4) { set_error("slab_reduce: sizes must be multiples of 4"); return DMVAE_EINVAL; }
+    ProfScope ps(s, "slab_reduce", (double)n * nslab, 4.0 * n * (nslab + 1));
+    const int blocks = (int)std::min<int64_t>(2048, (n / 4 + 255) / 256);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(std::max(1, blocks)), dim3(256), 0, s, slabs, n / 4, nslab, stride / 4, out);
+    return check_launch("slab_reduce");
 }
 
 // ---------------------------------------------------------------- stand-alone recon loss

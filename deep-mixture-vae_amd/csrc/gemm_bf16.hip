@@ -308,6 +308,14 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     const int li = lane & 15, g = lane >> 4;
     constexpr int CH = BN / 4, NT = 64 * NW;
     static_assert(BM * BN * 4 <= NSTAGE * STAGE * 2, "fp32 tile must fit in the ring");
+    // deterministic split-K (conv weight gradient, cfg.deterministic): K slice y stores into its own slab, summed in a fixed
+    // order by slab_reduce afterwards -- no float atomics
+    dmvae_epilogue epi_s = a.epi;
+    if constexpr (CONV && EPI == DMVAE_EPI_STORE_F32) {
+        const int ys = kslice >= 0 ? kslice : (int)blockIdx.y;
+        epi_s.out = reinterpret_cast<float*>(epi_s.out) + (int64_t)ys * a.slab_stride;
+        if (epi_s.out2) epi_s.out2 = reinterpret_cast<float*>(epi_s.out2) + (int64_t)ys * a.slab_stride2;
+    }
     float* ct = reinterpret_cast<float*>(smem);
 #if DMVAE_ABLATE != 5
 #pragma unroll
@@ -343,7 +351,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
             const float xq[4] = {target[q].x, target[q].y, target[q].z, target[q].w};
             epilogue_quad<EPI, bf16_t>(a.epi, m0 + ml, n0 + c * 4, v, loss, xq);
         } else {
-            epilogue_quad<EPI, bf16_t>(a.epi, m0 + ml, n0 + c * 4, v, loss);
+            epilogue_quad<EPI, bf16_t>(epi_s, m0 + ml, n0 + c * 4, v, loss);
         }
     }
 #else
@@ -354,7 +362,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
 #endif
     if constexpr (DW) {
         if (do_bias && wm == 0 && li == 0) {      // D[row = n][col = any m]: column 0 of the wm == 0 waves writes
-            float* db = reinterpret_cast<float*>(a.epi.out2);
+            float* db = reinterpret_cast<float*>(epi_s.out2);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn * (BN / 2) + j * 16 + g * 4;
@@ -773,7 +781,7 @@ static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split) {
     int t = gemm_bf16_tile_m(a.M, a.N, split);
     if (a.conv_c) {          // conv mode (csrc/conv.hip): the three (layout, epilogue) pairs a convolution layer uses
         constexpr bool ok = (LAYOUT == DMVAE_GEMM_FWD && EPI == DMVAE_EPI_BIAS_RELU) || (LAYOUT == DMVAE_GEMM_DX && EPI == DMVAE_EPI_RELU_MASK) ||
-                            (LAYOUT == DMVAE_GEMM_DW && EPI == DMVAE_EPI_ATOMIC_F32);
+                            (LAYOUT == DMVAE_GEMM_DW && (EPI == DMVAE_EPI_ATOMIC_F32 || EPI == DMVAE_EPI_STORE_F32));
         if constexpr (ok) {
             if (LAYOUT == DMVAE_GEMM_DW) t = 64 * 1000 + (a.N % 128 == 0 ? 128 : 64);   // a tile row stays inside one tap
             a.group_m = gemm_auto_group_m(a.M / (t / 1000), a.N / (t % 1000), t / 1000, t % 1000);

@@ -32,6 +32,7 @@ struct GemmArgs {
     // f32 kernel, DMVAE_EPI_STORE_F32 with split-K: K slice y stores its partial product at out + y * slab_stride (deterministic
     // split: the caller adds the slabs in a fixed order); 0 = plain store
     int64_t slab_stride = 0;
+    int64_t slab_stride2 = 0;      // likewise for the DW layout's fused bias gradient (epi.out2)
 };
 
 // element offset of K position k (multiple of the tile depth) of a conv-mode A operand

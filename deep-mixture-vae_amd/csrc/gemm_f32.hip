@@ -132,7 +132,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
 
     float loss = 0.f;
     dmvae_epilogue epi = a.epi;
-    if constexpr (EPI == DMVAE_EPI_STORE_F32) epi.out = reinterpret_cast<float*>(epi.out) + (int64_t)blockIdx.y * a.slab_stride;   // K-slice slabs
+    if constexpr (EPI == DMVAE_EPI_STORE_F32) {      // K-slice slabs
+        epi.out = reinterpret_cast<float*>(epi.out) + (int64_t)blockIdx.y * a.slab_stride;
+        if (epi.out2) epi.out2 = reinterpret_cast<float*>(epi.out2) + (int64_t)blockIdx.y * a.slab_stride2;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
         }
     if constexpr (DW) {
         if (do_bias && wm == 0 && li == 0) {
-            float* db = reinterpret_cast<float*>(a.epi.out2);
+            float* db = reinterpret_cast<float*>(epi.out2);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = n0 + wn * 32 + j * 16 + g * 4;

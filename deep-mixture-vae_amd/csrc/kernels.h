@@ -40,6 +40,7 @@ int64_t latent_mfma_ws_bytes(int B_pad, int D, int K);
 int latent_mfma_launch(hipStream_t s, const dmvae_latent_args* a, float* ws, int64_t ws_bytes);
 int adam_launch(hipStream_t s, const AdamArgs& a);
 int adam_finish_launch(hipStream_t s, void* st);
+int slab_reduce_launch(hipStream_t s, const float* slabs, int64_t n, int nslab, int64_t stride, float* out);
 int colsum_prepare(int64_t max_n);
 float* colsum_global_scratch(int64_t* elems);
 int colsum_launch(hipStream_t s, int in_dtype, const void* in, int64_t ld, int M, int N, float* out, float* ws, int64_t ws_elems);

@@ -156,6 +156,38 @@ def test_cli_keeps_every_reference_flag():
     assert a.batch_size == 100 and not a.gumbel and not a.host_noise
 
 
+def test_layer_descriptors_carry_the_reference_shapes():
+    """includes/layers.py + includes/network.py as descriptors: the spec lists of base_models.py:181-202 (CNN encoder) and
+    :280-288 (decoder) build, expose the variable shapes the reference creates (layers.py:24-28, :45-51) and reduce to the
+    conv stack / dense widths the step plan implements; anything the plan has no kernel for is refused."""
+    from includes.network import DeepNetwork
+    from includes import layers as Ly
+    spec = [("cn", {"n_kernels": 32, "prev_n_kernels": 1, "kernel": (3, 3)}), ("cn", {"n_kernels": 32, "prev_n_kernels": 32, "kernel": (3, 3)}),
+            ("mp", {"k": 2}), ("cn", {"n_kernels": 64, "prev_n_kernels": 32, "kernel": (3, 3)}),
+            ("cn", {"n_kernels": 64, "prev_n_kernels": 64, "kernel": (3, 3)}), ("mp", {"k": 2}),
+            ("cn", {"n_kernels": 128, "prev_n_kernels": 64, "kernel": (3, 3)}), ("cn", {"n_kernels": 128, "prev_n_kernels": 128, "kernel": (3, 3)}),
+            ("mp", {"k": 2}), ("fc", {"input_dim": 2048, "output_dim": 500})]
+    net = DeepNetwork("layers", spec, activation="relu", initializer="xavier")
+    assert [type(l).__name__ for l in net.layers] == ["Convolution", "Convolution", "MaxPooling"] * 3 + ["FullyConnected"]
+    assert net.layers[0].weight_shape == (3, 3, 1, 32) and net.layers[0].bias_shape == (32,) and net.layers[0].strides == [1, 1, 1, 1]
+    assert net.layers[2].ksize == [1, 2, 2, 1] and net.layers[2].strides == [1, 2, 2, 1]
+    assert net.layers[-1].weight_shape == (2048, 500) and net.layers[-1].bias_shape == (1, 500)
+    stack, side = net.conv_stack(28)
+    assert stack == ((1, 32, 28, False), (32, 32, 28, True), (32, 64, 14, False), (64, 64, 14, True), (64, 128, 7, False), (128, 128, 7, True))
+    assert side == 4 and side * side * 128 == 2048 and net.widths() == (500,)
+    dec = DeepNetwork("layers", [("fc", {"input_dim": 10, "output_dim": 2000}), ("fc", {"input_dim": 2000, "output_dim": 500}),
+                                 ("fc", {"input_dim": 500, "output_dim": 500})])
+    assert dec.widths() == (2000, 500, 500)
+    with pytest.raises(ValueError):
+        DeepNetwork("l", [("fc", {"input_dim": 10, "output_dim": 20}), ("fc", {"input_dim": 21, "output_dim": 5})]).widths()
+    with pytest.raises(NotImplementedError):
+        DeepNetwork("l", [("cn", {"n_kernels": 8, "prev_n_kernels": 1, "kernel": (5, 5)})]).conv_stack()
+    with pytest.raises(NotImplementedError):
+        DeepNetwork("l", [("bn", {"is_training": True})])
+    with pytest.raises(NotImplementedError):
+        DeepNetwork("l", [("xx", {})])
+
+
 def test_load_data_synthetic_standin_shapes():
     from includes.utils import load_data
     ds = load_data("mnist", n_train=300, n_test=100)
