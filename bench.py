@@ -129,7 +129,7 @@ def cpu_baseline(args):
     out = {}
     for B, want, budget in ((args.batch, args.cpu_steps, args.cpu_seconds), (100, 50, 4.0)):
         cfg = O.Config(args.input_dim, args.latent_dim, args.n_clusters, tuple(int(v) for v in args.enc_layers.split(",")),
-                       args.head_dim, tuple(int(v) for v in args.dec_layers.split(",")))
+                       args.head_dim, tuple(int(v) for v in args.dec_layers.split(",")), cnn=args.cnn)
         p = O.init_params(cfg, 0, np.float32)
         m, v = O.adam_tf_init(p)
         X = O.synthetic_images(B, args.input_dim, seed=1)
@@ -249,6 +249,9 @@ def main():
     torch.cuda.set_device(dev)
     I, D, K, B = args.input_dim, args.latent_dim, args.n_clusters, args.batch
     enc = tuple(int(v) for v in args.enc_layers.split(","))
+    if args.cnn:
+        enc = enc[-1:]            # the CNN trunk ends in ONE dense layer, fc 2048 -> 500 (base_models.py:202)
+        args.enc_layers = str(enc[0])
     dec = tuple(int(v) for v in args.dec_layers.split(","))
     eng = StepEngine(I, D, K, enc_layers=enc, head_dim=args.head_dim, dec_layers=dec, dtype=args.dtype, max_batch=B,
                      seed=1234 + rank, deterministic=args.deterministic, cnn=args.cnn)
@@ -345,7 +348,7 @@ def main():
         "config": {"workload": "%sDMVAE MLP %s, one ELBO training step (gather+fwd+loss+bwd+Adam), synthetic rows resident in HBM"
                                % ("configs[1]: " if is_cfg2 else "", arch),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                   "hip_graph": (not args.no_graph) and sync is None, "float_atomics": bool(args.cnn),
+                   "hip_graph": (not args.no_graph) and sync is None, "float_atomics": bool(args.cnn) and not args.deterministic,
                    "update": "stand-alone adam" if args.cnn and sync is None else "adam fused into the dW launch" if sync is None else "bucketed all-reduce overlapped with backward, then adam"},
         "step_flops_algorithmic": fpi * B,
         "step_mfma_frac_of_peak": round(fpi * B / (ms_step * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4),

@@ -127,21 +127,35 @@ int colsum_launch(hipStream_t s, int in_dtype, const void* in, int64_t ld, int M
 }
 
 // ---------------------------------------------------------------- slab reduction (deterministic split-K)
-// out[i] = slab[0][i] + slab[1][i] + ... in ascending order; n a multiple of 4, 16-byte accesses
+// out[i] = sum over the slabs in a FIXED order; n a multiple of 4, 16-byte accesses.  A block = 16 slab groups x 16 quads:
+// thread (g, q) adds slabs g, g + 16, g + 32, ... in ascending order, then the 16 group sums are added in ascending order
+// (the slab count is often in the hundreds while n is a few thousand quads: one thread per quad would run 20 blocks).
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int64_t n4, int nslab, int64_t stride4, float* __restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 a = reinterpret_cast<const float4*>(slabs)[i];
-        for (int s = 1; s < nslab; ++s) {
-            const float4 b = reinterpret_cast<const float4*>(slabs)[(int64_t)s * stride4 + i];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    __shared__ float4 red[16][17];
+    const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
+    for (int64_t base = (int64_t)blockIdx.x * 16; base < n4; base += (int64_t)gridDim.x * 16) {
+        const int64_t i = base + q;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n4)
+            for (int s = g; s < nslab; s += 16) {
+                const float4 b = reinterpret_cast<const float4*>(slabs)[(int64_t)s * stride4 + i];
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+        red[g][q] = a;
+        __syncthreads();
+        if (g == 0 && i < n4) {
+            float4 t = red[0][q];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) { const float4 b = red[k][q]; t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w; }
+            reinterpret_cast<float4*>(out)[i] = t;
         }
-        reinterpret_cast<float4*>(out)[i] = a;
+        __syncthreads();
     }
 }
 int slab_reduce_launch(hipStream_t s, const float* slabs, int64_t n, int nslab, int64_t stride, float* out) {
     if (n % 4 || stride % 4) { set_error("slab_reduce: sizes must be multiples of 4"); return DMVAE_EINVAL; }
     ProfScope ps(s, "slab_reduce", (double)n * nslab, 4.0 * n * (nslab + 1));
-    const int blocks = (int)std::min<int64_t>(2048, (n / 4 + 255) / 256);
+    const int blocks = (int)std::min<int64_t>(4096, (n / 4 + 15) / 16);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(std::max(1, blocks)), dim3(256), 0, s, slabs, n / 4, nslab, stride / 4, out);
     return check_launch("slab_reduce");
 }

@@ -437,11 +437,14 @@ struct GroupedArgs {
     dmvae_adam_ctx adam;      // DMVAE_EPI_ADAM launches only
     dmvae_finalize_args fin;  // DMVAE_EPI_RELU_MASK launches: fin.nblocks extra workgroups run step_finalize (0 = none)
 };
-template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4>
+// SHORTK: every problem has K <= 128 (one or two K tiles: the dX of the narrow heads).  Such a workgroup is all prologue
+// and epilogue -- what helps is MORE of them per CU: 64x64 tiles on a 2-slot ring = 32 KiB of LDS, four to five workgroups
+// per CU instead of two.
+template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4, bool SHORTK = false>
 __global__ __launch_bounds__(64 * NW) void gemm_bf16_grouped_kernel(GroupedArgs g) {
     // every problem takes the largest tile its shape divides (traffic per flop ~ (BM+BN)/(BM*BN)):
     // kind 0 = 128x128 / 2 stages, 1 = 128x64 / 3, 2 = 64x64 / 4  -- one LDS array of the largest ring
-    __shared__ __attribute__((aligned(16))) bf16_t smem[3 * (128 + 64) * BK];   // 72 KiB >= 2*(128+128)*64, 4*(64+64)*64
+    __shared__ __attribute__((aligned(16))) bf16_t smem[SHORTK ? 2 * (64 + 64) * BK : 3 * (128 + 64) * BK];   // 72 KiB >= 2*(128+128)*64, 4*(64+64)*64
     const dmvae_adam_ctx* ac = EPI == DMVAE_EPI_ADAM ? &g.adam : nullptr;
     if constexpr (EPI == DMVAE_EPI_ADAM) {
         if ((int)blockIdx.x >= g.start[g.nprob]) {   // the extra workgroup(s): arena segment whose gradient is already in memory
@@ -478,9 +481,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_grouped_kernel(GroupedArgs 
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // (a 4-slot ring of K depth 32 in the same 64 KiB was measured for the 128x128 dW tiles: no gain)
-    if (kind == 0) gemm_bf16_body<128, 128, LAYOUT, EPI, 2, NW>(g.p[i], bid, gs, cnt, smem, ac);
-    else if (kind == 1) gemm_bf16_body<128, 64, LAYOUT, EPI, 3, NW>(g.p[i], bid, gs, cnt, smem, ac);
-    else gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW>(g.p[i], bid, gs, cnt, smem, ac);
+    if constexpr (SHORTK) {
+        gemm_bf16_body<64, 64, LAYOUT, EPI, 2, NW>(g.p[i], bid, gs, cnt, smem, ac);
+    } else {
+        if (kind == 0) gemm_bf16_body<128, 128, LAYOUT, EPI, 2, NW>(g.p[i], bid, gs, cnt, smem, ac);
+        else if (kind == 1) gemm_bf16_body<128, 64, LAYOUT, EPI, 3, NW>(g.p[i], bid, gs, cnt, smem, ac);
+        else gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW>(g.p[i], bid, gs, cnt, smem, ac);
+    }
 #if DMVAE_ABLATE == 6
     if (threadIdx.x == 0 && blockIdx.x < 2048) {
         unsigned long long* st = g_stamps + 4 * blockIdx.x;
@@ -506,6 +513,7 @@ int gemm_auto_group_m(int tiles_m, int tiles_n, int bm, int bn, double run) {
     gm = std::max(gm, need);
     return std::max(1, std::min(gm, tiles_m));
 }
+static int g_shortk = 1;                    // tuning knob (dmvae_debug_set_knob 7): K <= 128 problems as 64x64 / 2-slot workgroups (four to five per CU)
 static int g_conv_short = 2;                // tuning knob (dmvae_debug_set_knob 5): >= 1 short-K conv tiles as 4-wave / 2-slot workgroups, 2 also 3-slot rings for the 64x64 weight-gradient tiles (tools/cnn_knob.py: 3.539 / 3.290 / 3.270 ms)
 static int g_grouped_cls = 1;               // tuning knob (dmvae_debug_set_knob 4): XCD runs cut per tile-shape class (1) or per problem (0)
 static int g_grouped_mixed = 1;             // tuning knob (dmvae_debug_set_knob 2): 0 all 64x64, 1 planned per-problem tiles, 2 largest tile each shape divides
@@ -575,8 +583,10 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
     // CUs' second slots evenly): take the assignment with the least-loaded busiest CU, ties to
     // the fewest bytes in total.  <= 3^nprob candidates, searched once per set of shapes.
     int kinds[DMVAE_MAX_GROUP];
-    for (int i = 0; i < nprob; ++i) kinds[i] = g_grouped_mixed ? best_kind(probs[i]) : 2;
-    if (g_grouped_mixed == 1) {
+    bool shortk = g_shortk && LAYOUT != DMVAE_GEMM_DW && EPI != DMVAE_EPI_ADAM;
+    for (int i = 0; i < nprob; ++i) shortk = shortk && probs[i].K <= 128;
+    for (int i = 0; i < nprob; ++i) kinds[i] = (g_grouped_mixed && !shortk) ? best_kind(probs[i]) : 2;
+    if (g_grouped_mixed == 1 && !shortk) {
         static std::mutex mu;
         static std::map<std::vector<int>, std::vector<int>> memo;
         std::vector<int> key;
@@ -668,6 +678,12 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
     }();
     ProfScope ps(s, pname.c_str(), flops, bytes);
     // (8-wave workgroups in the grouped grids were measured too: 0.3071 vs 0.3014 ms/step, not kept)
+    if constexpr (LAYOUT != DMVAE_GEMM_DW) {
+        if (shortk) {
+            hipLaunchKernelGGL((gemm_bf16_grouped_kernel<64, 64, LAYOUT, EPI, 2, 4, true>), dim3(total + extra), dim3(256), 0, s, g);
+            return check_launch("gemm_bf16_grouped");
+        }
+    }
     hipLaunchKernelGGL((gemm_bf16_grouped_kernel<64, 64, LAYOUT, EPI, 4, 4>), dim3(total + extra), dim3(256), 0, s, g);
     return check_launch("gemm_bf16_grouped");
 }
@@ -748,6 +764,7 @@ void gemm_bf16_set_knob(int which, int v) {
     if (which == 4) g_grouped_cls = v;
     if (which == 5) g_conv_short = v;
     if (which == 6) gemm_bf16_256_set_policy(v);
+    if (which == 7) g_shortk = v;
 }
 
 // Tile choice, BM*1000+BN.  These GEMMs run at the per-CU L2->LDS streaming rate, so the figure
@@ -812,6 +829,11 @@ static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split) {
     //  smaller intake of one.)
     if (split == 1 && gemm_bf16_256_ok(LAYOUT, EPI, a.M, a.N, a.K, false)) return gemm_bf16_256_launch(s, LAYOUT, a);
     a.group_m = gemm_auto_group_m(a.M / (t / 1000), a.N / (t % 1000), t / 1000, t % 1000);
+    if (g_shortk && a.K <= 128 && split == 1 && LAYOUT != DMVAE_GEMM_DW && EPI != DMVAE_EPI_BIAS_RECON) {
+        // one or two K tiles: the workgroup is prologue + epilogue; small LDS footprint -> more workgroups per CU
+        a.group_m = gemm_auto_group_m(a.M / 64, a.N / 64, 64, 64);
+        return launch<64, 64, LAYOUT, EPI, 2>(s, a, split);
+    }
     const long wgs = (long)(a.M / (t / 1000)) * (a.N / (t % 1000)) * split;
     // one workgroup per CU at most -> a single deep ring (more bytes in flight); else two shallow ones
     const bool deep = g_deep < 0 ? wgs <= 320 : g_deep == 1;

@@ -1,5 +1,5 @@
 """the CNN encoder trunk (base_models.py:176-216, `cnn=True`) on the GPU against the oracle.
-The conv layers run as the step's GEMMs over explicit patch matrices (csrc/conv.hip)."""
+The conv layers run as the step's GEMMs in conv mode -- implicit patch matrices (csrc/conv.hip)."""
 import os
 import sys
 
@@ -17,9 +17,9 @@ import dmvae_oracle as O  # noqa: E402
 KW = dict(input_dim=784, latent_dim=8, n_classes=5, enc_layers=(96,), head_dim=64, dec_layers=(64, 48))
 
 
-def make(dtype, B, seed=2):
+def make(dtype, B, seed=2, deterministic=False):
     from dmvae_hip import StepEngine
-    eng = StepEngine(dtype=dtype, max_batch=B, mode="exact", cnn=True, **KW)
+    eng = StepEngine(dtype=dtype, max_batch=B, mode="exact", cnn=True, deterministic=deterministic, **KW)
     eng.init_parameters(seed)
     return eng
 
@@ -137,3 +137,59 @@ def test_cnn_staged_backward_and_bucket_update_match_the_whole_step():
     pw, ps = whole.get_parameters(), staged.get_parameters()
     for k in pw:
         assert np.percentile(np.abs(pw[k] - ps[k]), 99.9) <= 1e-5, k
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_cnn_deterministic_mode_is_bit_reproducible(dtype):
+    """deterministic=True: the conv weight gradients are split-K SLABS added in a fixed order instead of float atomics
+    (DESIGN section 9): two runs of several Adam steps leave identical bits, and the gradients agree with the atomic form
+    to summation-order round-off.  B = 256 reaches the XCD-placed split (a multiple of 8 K slices) of the bf16 kernel."""
+    B = 256
+    X, eps = batch(B)
+    Xd, ed = torch.as_tensor(X).cuda(), torch.as_tensor(eps).cuda()
+    runs = []
+    for _ in range(2):
+        eng = make(dtype, B, deterministic=True)
+        eng.load_batch(Xd, None, 0, B)
+        eng.forward_backward(B, ed, None)
+        torch.cuda.synchronize()
+        g0 = eng.grad.clone()
+        eng.update(1.0)
+        for _ in range(4):
+            eng.train_step(Xd, None, B, ed, None)
+        torch.cuda.synchronize()
+        runs.append((g0, eng.param.clone(), eng.read_state().last_loss))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]) and runs[0][2] == runs[1][2]
+    at = make(dtype, B, deterministic=False)
+    at.load_batch(Xd, None, 0, B)
+    at.forward_backward(B, ed, None)
+    torch.cuda.synchronize()
+    ga, gd = at.get_gradients(), None
+    det = make(dtype, B, deterministic=True)
+    det.load_batch(Xd, None, 0, B)
+    det.forward_backward(B, ed, None)
+    torch.cuda.synchronize()
+    gd = det.get_gradients()
+    for k in ga:
+        np.testing.assert_allclose(gd[k], ga[k], rtol=0, atol=2e-5 * (np.abs(ga[k]).max() + 1e-12), err_msg=k)
+
+
+def test_bf16_cnn_step_close_to_oracle():
+    """bf16 against the float64 ORACLE (not only against the repo's fp32 engine), at a batch whose conv weight gradients
+    take the XCD-placed split-K path"""
+    B = 64
+    eng = make("bf16", B, deterministic=True)
+    cfg = O.Config(cnn=True, **KW)
+    X, eps = batch(B)
+    p = {k: v.astype(np.float64) for k, v in eng.get_parameters().items()}
+    eng.load_batch(torch.as_tensor(X).cuda(), None, 0, B)
+    eng.forward_backward(B, torch.as_tensor(eps).cuda(), None)
+    torch.cuda.synchronize()
+    a = O.forward(p, cfg, X.astype(np.float64), eps.astype(np.float64), 1.0, "exact")
+    g = O.backward(p, cfg, a)
+    st = eng.read_state()
+    assert abs(st.last_loss - a["loss"]) <= 5e-3 * abs(a["loss"]), (st.last_loss, a["loss"])
+    gg = eng.get_gradients()
+    for k in g:
+        err = np.linalg.norm(gg[k] - g[k]) / (np.linalg.norm(g[k]) + 1e-12)
+        assert err <= 0.15, (k, err)

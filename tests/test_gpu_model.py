@@ -243,8 +243,8 @@ def test_unsupported_surfaces_fail_loudly():
     import base_models
     with pytest.raises(ValueError):                    # the CNN trunk reshapes to 28x28x1 (base_models.py:176)
         base_models.DeepMixtureVAE("m", "binary", 100, 10, 10, cnn=True)
-    with pytest.raises(NotImplementedError):
-        base_models.VaDE("v", "binary", 784, 10, 10)
+    with pytest.raises(NotImplementedError):           # VaDE's convolutional encoder variant (base_models.py:456-488) is not built
+        base_models.VaDE("v", "binary", 784, 10, 10, cnn=True)
 
 
 def test_cnn_model_trains_through_the_reference_surface():
