@@ -348,7 +348,7 @@ def main():
         "config": {"workload": "%sDMVAE MLP %s, one ELBO training step (gather+fwd+loss+bwd+Adam), synthetic rows resident in HBM"
                                % ("configs[1]: " if is_cfg2 else "", arch),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                   "hip_graph": (not args.no_graph) and sync is None, "float_atomics": bool(args.cnn) and not args.deterministic,
+                   "hip_graph": (not args.no_graph) and sync is None, "float_atomics": False,
                    "update": "stand-alone adam" if args.cnn and sync is None else "adam fused into the dW launch" if sync is None else "bucketed all-reduce overlapped with backward, then adam"},
         "step_flops_algorithmic": fpi * B,
         "step_mfma_frac_of_peak": round(fpi * B / (ms_step * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4),

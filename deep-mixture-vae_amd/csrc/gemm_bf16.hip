@@ -513,7 +513,8 @@ int gemm_auto_group_m(int tiles_m, int tiles_n, int bm, int bn, double run) {
     gm = std::max(gm, need);
     return std::max(1, std::min(gm, tiles_m));
 }
-static int g_shortk = 1;                    // tuning knob (dmvae_debug_set_knob 7): K <= 128 problems as 64x64 / 2-slot workgroups (four to five per CU)
+static int g_shortk = 0;                    // tuning knob (dmvae_debug_set_knob 7): K <= 128 problems as 64x64 / 2-slot workgroups (four to five per CU).
+                                            // MEASURED (tools/knob_ab.py 7 0 1): cfg2 0.2948 (off) vs 0.2985 ms (on), cfg4 0.6834 vs 0.6845: off
 static int g_conv_short = 2;                // tuning knob (dmvae_debug_set_knob 5): >= 1 short-K conv tiles as 4-wave / 2-slot workgroups, 2 also 3-slot rings for the 64x64 weight-gradient tiles (tools/cnn_knob.py: 3.539 / 3.290 / 3.270 ms)
 static int g_grouped_cls = 1;               // tuning knob (dmvae_debug_set_knob 4): XCD runs cut per tile-shape class (1) or per problem (0)
 static int g_grouped_mixed = 1;             // tuning knob (dmvae_debug_set_knob 2): 0 all 64x64, 1 planned per-problem tiles, 2 largest tile each shape divides

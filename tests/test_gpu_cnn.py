@@ -112,8 +112,7 @@ def test_bf16_cnn_step_close_to_fp32_engine_and_trains():
 
 def test_cnn_staged_backward_and_bucket_update_match_the_whole_step():
     """the data-parallel launch sequence (three backward segments, one Adam per gradient bucket) on the CNN
-    trunk: same gradients as the whole pass up to the summation order of the split-K conv weight gradients
-    (fp32 atomics), conv tensors inside the trunk bucket."""
+    trunk: same gradients as the whole pass, conv tensors inside the trunk bucket."""
     B = 32
     X, eps = batch(B)
     Xd, ed = torch.as_tensor(X).cuda(), torch.as_tensor(eps).cuda()
@@ -141,9 +140,9 @@ def test_cnn_staged_backward_and_bucket_update_match_the_whole_step():
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
 def test_cnn_deterministic_mode_is_bit_reproducible(dtype):
-    """deterministic=True: the conv weight gradients are split-K SLABS added in a fixed order instead of float atomics
-    (DESIGN section 9): two runs of several Adam steps leave identical bits, and the gradients agree with the atomic form
-    to summation-order round-off.  B = 256 reaches the XCD-placed split (a multiple of 8 K slices) of the bf16 kernel."""
+    """the conv weight gradients are split-K SLABS added in a fixed order (round 1 used float atomics and
+    drifted after three steps): two runs of several Adam steps leave identical bits.  B = 256 reaches the XCD-placed split
+    (a multiple of 8 K slices) of the bf16 kernel."""
     B = 256
     X, eps = batch(B)
     Xd, ed = torch.as_tensor(X).cuda(), torch.as_tensor(eps).cuda()
@@ -160,18 +159,12 @@ def test_cnn_deterministic_mode_is_bit_reproducible(dtype):
         torch.cuda.synchronize()
         runs.append((g0, eng.param.clone(), eng.read_state().last_loss))
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]) and runs[0][2] == runs[1][2]
-    at = make(dtype, B, deterministic=False)
-    at.load_batch(Xd, None, 0, B)
-    at.forward_backward(B, ed, None)
+    # (the atomic split-K form of round 1 is gone: the slab form measured faster; deterministic needs no switch)
+    nd = make(dtype, B, deterministic=False)
+    nd.load_batch(Xd, None, 0, B)
+    nd.forward_backward(B, ed, None)
     torch.cuda.synchronize()
-    ga, gd = at.get_gradients(), None
-    det = make(dtype, B, deterministic=True)
-    det.load_batch(Xd, None, 0, B)
-    det.forward_backward(B, ed, None)
-    torch.cuda.synchronize()
-    gd = det.get_gradients()
-    for k in ga:
-        np.testing.assert_allclose(gd[k], ga[k], rtol=0, atol=2e-5 * (np.abs(ga[k]).max() + 1e-12), err_msg=k)
+    assert torch.equal(nd.grad, runs[0][0])
 
 
 def test_bf16_cnn_step_close_to_oracle():
