@@ -161,6 +161,11 @@ struct dmvae_plan {
     bool overlap_dw = true;
     bool finalize_rides = true;       // DMVAE_FINALIZE_INLINE=1: step_finalize as its own launch (A/B)
     bool vade = false;                // cfg.model == DMVAE_MODEL_VADE: no head hidden layers, no logits; latent mode 2
+    // bias gradients of the macro-tile path: the GEMM that PRODUCES a dY (256x256 kernel, ReLU-gate / recon epilogue) leaves
+    // its column sums per 256-row tile, [Bp/256][width] floats per dY tensor; the dW problem of that layer picks them up
+    int64_t o_cs_dl = -1, o_cs_dhzc = -1;
+    std::vector<int64_t> o_cs_ddec, o_cs_denc;
+    std::map<const void*, std::pair<const float*, int64_t>> csum_of;     // dY base pointer -> (partials, ld), filled during a pass
 };
 
 static void add_tensor(dmvae_plan* p, const std::string& name, int64_t off, int rows, int cols, int64_t ld) {
@@ -318,6 +323,13 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
     p->o_dmv = take(Bp * 2 * p->Dp * es);
     p->o_dhzc = take(Bp * 2 * p->Hp * es);
     for (auto& L : p->enc) p->o_denc.push_back(take(Bp * L.out_pad * es));
+    if (c->dtype == DMVAE_BF16 && p->Bp % 256 == 0) {
+        const int64_t tr = p->Bp / 256;
+        p->o_cs_dl = take(tr * p->Ip * 4);
+        p->o_cs_dhzc = take(tr * 2 * p->Hp * 4);
+        for (auto& L : p->dec) p->o_cs_ddec.push_back(take(tr * L.out_pad * 4));
+        for (auto& L : p->enc) p->o_cs_denc.push_back(take(tr * L.out_pad * 4));
+    }
     p->n_rpart = gemm_partials(c->dtype, p->Bp, p->Ip);
     p->o_rpart = take((int64_t)p->n_rpart * 4);
     p->n_lblk = p->vade ? latent_vade_nblocks(p->Bp) : latent_nblocks(p->Bp, c->latent_dim, c->n_classes);
@@ -618,6 +630,10 @@ static int grad_dense(dmvae_plan* p, hipStream_t s, const void* X, int64_t ldx, 
                 GemmArgs a;
                 TRY(gemm_checked(s, DMVAE_BF16, DMVAE_GEMM_DW, mm, nn, p->Bp, Xb + mo, ldx, dYb + no, ldy, &es, 1, &a));
                 a.ws = reinterpret_cast<float*>(WS(p, p->o_cs)); a.ws_elems = p->cs_elems;     // bias-gradient slab sums of a 256x256-tile problem
+                auto cs = p->csum_of.find(dY);
+                if (cs != p->csum_of.end() && no == 0 && nn == N && cs->second.second == N) {      // ... unless dY's producer left its column sums
+                    a.csum_in = cs->second.first; a.csum_ld = N; a.csum_rows = p->Bp / 256;
+                }
                 p->dw_queue.push_back(a);
             }
         }
@@ -669,11 +685,23 @@ static int launch_dw_queue(dmvae_plan* p, hipStream_t target, bool with_prior) {
     return rc;
 }
 
+// cs_off >= 0: where this dY tensor's column-sum partials live ([Bp/256][cs_ld] floats at workspace offset cs_off; this
+// GEMM writes columns cs_col .. cs_col + N); taken only when the 256x256 kernel runs the GEMM, and then registered under
+// cs_key (the dY tensor's base pointer) for the weight-gradient problem of that layer
 static int dx_dense(dmvae_plan* p, hipStream_t s, const void* dY, int64_t ldy, int Kdim, int64_t w_off, int64_t ldw, int N,
-                    const void* Yfwd, int64_t ldyf, void* out, int64_t ldo, GemmArgs* deferred = nullptr) {
+                    const void* Yfwd, int64_t ldyf, void* out, int64_t ldo, GemmArgs* deferred = nullptr,
+                    const void* cs_key = nullptr, int64_t cs_off = -1, int64_t cs_ld = 0, int64_t cs_col = 0) {
     dmvae_epilogue e;
     memset(&e, 0, sizeof(e));
     e.kind = DMVAE_EPI_RELU_MASK; e.out = out; e.ldo = ldo; e.aux0 = Yfwd; e.ld0 = ldyf;
+    if (!deferred && cs_off >= 0 && p->cfg.dtype == DMVAE_BF16 && gemm_bf16_256_ok(DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK, p->Bp, N, Kdim, false)) {
+        GemmArgs a;
+        TRY(gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_DX, p->Bp, N, Kdim, dY, ldy, Wp(p, w_off), ldw, &e, 1, &a));
+        float* part = reinterpret_cast<float*>(WS(p, cs_off));
+        a.csum_out = part + cs_col; a.csum_ld = cs_ld;
+        p->csum_of[cs_key] = std::make_pair((const float*)part, cs_ld);
+        return gemm_bf16_dispatch(s, DMVAE_GEMM_DX, a, 1);
+    }
     return gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_DX, p->Bp, N, Kdim, dY, ldy, Wp(p, w_off), ldw, &e, 1, deferred);
 }
 
@@ -693,6 +721,7 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     const bool all = stage < 0;
     p->staged = !all;
     const int nd = (int)p->dec.size(), ne = (int)p->enc.size();
+    auto cso = [](const std::vector<int64_t>& v, int i) -> int64_t { return v.empty() ? -1 : v[i]; };      // column-sum partials of a dY (bf16, Bp % 256 == 0)
     // Loss scalars, Adam t / lr_t and the prior-table gradients need only the forward partials.  Whole pass, bf16:
     // the 1 + 80 blocks of step_finalize ride as extra workgroups of the grouped heads-dX launch further down (one
     // kernel boundary less); staged (data parallel: the prior tables belong to this segment's bucket) and f32: a
@@ -708,6 +737,7 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     const bool fin_rides = all && dt == DMVAE_BF16 && p->finalize_rides && !heads_big && !p->vade;
   if (all || stage == 0) {
     p->dw_queue.clear();
+    p->csum_of.clear();
     TRY(encode_impl(p, s));
 
     dmvae_latent_args la;
@@ -740,8 +770,16 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
         e.kind = DMVAE_EPI_BIAS_RECON; e.m_valid = n_valid; e.n_valid = c.input_dim; e.recon_kind = c.input_type; e.scale = inv_B;
         e.out = WS(p, p->o_dl); e.ldo = p->Ip; e.bias = p->buf.param + L.b_off;
         e.aux0 = WS(p, p->o_xf); e.ld0 = p->Ip; e.partials = reinterpret_cast<float*>(WS(p, p->o_rpart));
-        TRY(gemm_checked(s, dt, DMVAE_GEMM_FWD, p->Bp, p->Ip, p->dec[nd - 1].out_pad, WS(p, p->o_dec[nd - 1]), p->dec[nd - 1].out_pad,
-                         Wp(p, L.w_off), L.ldw, &e, 1));
+        const int Kd = p->dec[nd - 1].out_pad;
+        if (dt == DMVAE_BF16 && p->o_cs_dl >= 0 && gemm_bf16_256_ok(DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_RECON, p->Bp, p->Ip, Kd, false)) {
+            GemmArgs a;      // the macro-tile kernel also leaves dLoss/dlogits' column sums = the output bias gradient
+            TRY(gemm_checked(s, dt, DMVAE_GEMM_FWD, p->Bp, p->Ip, Kd, WS(p, p->o_dec[nd - 1]), Kd, Wp(p, L.w_off), L.ldw, &e, 1, &a));
+            float* part = reinterpret_cast<float*>(WS(p, p->o_cs_dl));
+            a.csum_out = part; a.csum_ld = p->Ip;
+            p->csum_of[(const void*)WS(p, p->o_dl)] = std::make_pair((const float*)part, (int64_t)p->Ip);
+            TRY(gemm_bf16_dispatch(s, DMVAE_GEMM_FWD, a, 1));
+        } else
+        TRY(gemm_checked(s, dt, DMVAE_GEMM_FWD, p->Bp, p->Ip, Kd, WS(p, p->o_dec[nd - 1]), Kd, Wp(p, L.w_off), L.ldw, &e, 1));
     }
     if (!fin_rides)
         TRY(step_finalize_launch(s, fin.rp, fin.nr, fin.lp, fin.nl, inv_B, p->buf.state, 1, c.beta1, c.beta2, fin.part, fin.nblk, fin.ncol, fin.gout));
@@ -749,7 +787,8 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     TRY(grad_dense(p, s, WS(p, p->o_dec[nd - 1]), p->dec[nd - 1].out_pad, p->dec[nd - 1].out_pad, WS(p, p->o_dl), p->Ip, p->Ip,
                    p->out.w_off, p->out.ldw, p->out.b_off));
     TRY(dx_dense(p, s, WS(p, p->o_dl), p->Ip, p->Ip, p->out.w_off, p->out.ldw, p->dec[nd - 1].out_pad,
-                 WS(p, p->o_dec[nd - 1]), p->dec[nd - 1].out_pad, WS(p, p->o_ddec[nd - 1]), p->dec[nd - 1].out_pad));
+                 WS(p, p->o_dec[nd - 1]), p->dec[nd - 1].out_pad, WS(p, p->o_ddec[nd - 1]), p->dec[nd - 1].out_pad, nullptr,
+                 WS(p, p->o_ddec[nd - 1]), cso(p->o_cs_ddec, nd - 1), p->dec[nd - 1].out_pad));
     for (int i = nd - 1; i >= 0; --i) {
         const PLayer& L = p->dec[i];
         const void* xin = i > 0 ? WS(p, p->o_dec[i - 1]) : WS(p, p->o_Z);
@@ -757,7 +796,8 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
         TRY(grad_dense(p, s, xin, ldx, L.in_pad, WS(p, p->o_ddec[i]), L.out_pad, L.out_pad, L.w_off, L.ldw, L.b_off));
         if (i > 0) {
             TRY(dx_dense(p, s, WS(p, p->o_ddec[i]), L.out_pad, L.out_pad, L.w_off, L.ldw, L.in_pad,
-                         WS(p, p->o_dec[i - 1]), p->dec[i - 1].out_pad, WS(p, p->o_ddec[i - 1]), p->dec[i - 1].out_pad));
+                         WS(p, p->o_dec[i - 1]), p->dec[i - 1].out_pad, WS(p, p->o_ddec[i - 1]), p->dec[i - 1].out_pad, nullptr,
+                         WS(p, p->o_ddec[i - 1]), cso(p->o_cs_ddec, i - 1), p->dec[i - 1].out_pad));
         } else {   // dZ -> [dmean | dlog_var] through the reparameterisation + KL gradients
             dmvae_epilogue e;
             memset(&e, 0, sizeof(e));
@@ -771,7 +811,8 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
   if ((all || stage == 1) && p->vade) {
     // ---- backward: VaDE's heads are the one linear layer [mean | log_var] off the trunk
     TRY(grad_dense(p, s, WS(p, p->o_enc[ne - 1]), p->Tp, p->Tp, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->mv.b_off));
-    TRY(dx_dense(p, s, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->Tp, WS(p, p->o_enc[ne - 1]), p->Tp, WS(p, p->o_denc[ne - 1]), p->Tp));
+    TRY(dx_dense(p, s, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->Tp, WS(p, p->o_enc[ne - 1]), p->Tp, WS(p, p->o_denc[ne - 1]), p->Tp,
+                 nullptr, WS(p, p->o_denc[ne - 1]), cso(p->o_cs_denc, ne - 1), p->Tp));
     TRY(flush_dw(p, s, 1));
   } else if (all || stage == 1) {
     // ---- backward: heads
@@ -781,9 +822,9 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
         GemmArgs q[2];
         const bool grp = dt == DMVAE_BF16 && !heads_big;
         TRY(dx_dense(p, s, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->Hp, WS(p, p->o_hzc), 2 * p->Hp, WS(p, p->o_dhzc), 2 * p->Hp,
-                     grp ? &q[0] : nullptr));
+                     grp ? &q[0] : nullptr, WS(p, p->o_dhzc), p->o_cs_dhzc, 2 * p->Hp, 0));
         TRY(dx_dense(p, s, WS(p, p->o_dlg), p->Kp, p->Kp, p->lg.w_off, p->lg.ldw, p->Hp, act_off(p, p->o_hzc, p->Hp), 2 * p->Hp,
-                     const_cast<void*>(act_off(p, p->o_dhzc, p->Hp)), 2 * p->Hp, grp ? &q[1] : nullptr));
+                     const_cast<void*>(act_off(p, p->o_dhzc, p->Hp)), 2 * p->Hp, grp ? &q[1] : nullptr, WS(p, p->o_dhzc), p->o_cs_dhzc, 2 * p->Hp, p->Hp));
         if (grp) TRY(gemm_bf16_grouped(s, DMVAE_GEMM_DX, q, 2, fin_rides ? &fin : nullptr));
     }
     // ---- backward: trunk
@@ -793,7 +834,7 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
   if (all || stage == 2) {
     if (!p->vade)
         TRY(dx_dense(p, s, WS(p, p->o_dhzc), 2 * p->Hp, 2 * p->Hp, p->zc.w_off, p->zc.ldw, p->Tp, WS(p, p->o_enc[ne - 1]), p->Tp,
-                     WS(p, p->o_denc[ne - 1]), p->Tp));
+                     WS(p, p->o_denc[ne - 1]), p->Tp, nullptr, WS(p, p->o_denc[ne - 1]), cso(p->o_cs_denc, ne - 1), p->Tp));
     for (int i = ne - 1; i >= 0; --i) {
         const PLayer& L = p->enc[i];
         const bool cnn = !p->conv.empty();
@@ -803,7 +844,8 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
         TRY(grad_dense(p, s, xin, ldx, L.in_pad, WS(p, p->o_denc[i]), L.out_pad, L.out_pad, L.w_off, L.ldw, L.b_off));
         if (i > 0)
             TRY(dx_dense(p, s, WS(p, p->o_denc[i]), L.out_pad, L.out_pad, L.w_off, L.ldw, L.in_pad,
-                         WS(p, p->o_enc[i - 1]), p->enc[i - 1].out_pad, WS(p, p->o_denc[i - 1]), p->enc[i - 1].out_pad));
+                         WS(p, p->o_enc[i - 1]), p->enc[i - 1].out_pad, WS(p, p->o_denc[i - 1]), p->enc[i - 1].out_pad, nullptr,
+                         WS(p, p->o_denc[i - 1]), cso(p->o_cs_denc, i - 1), p->enc[i - 1].out_pad));
         else if (cnn)   // gradient of the flattened pool output (gate: pool output > 0, see conv_trunk_backward)
             TRY(dx_dense(p, s, WS(p, p->o_denc[0]), L.out_pad, L.out_pad, L.w_off, L.ldw, L.in_pad, flat, p->flat, WS(p, p->o_dflat), p->flat));
     }

@@ -237,6 +237,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(GemmArgs a, dmvae
     float loss = 0.f;
     float* st = reinterpret_cast<float*>(smem) + wave * 4096;
     const int li = lane & 15, g = lane >> 4;
+    constexpr bool CSUM = (EPI == DMVAE_EPI_RELU_MASK || EPI == DMVAE_EPI_BIAS_RECON);     // the output is a dY: its column sums = a bias gradient
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -256,11 +258,34 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(GemmArgs a, dmvae
             if constexpr (EPI == DMVAE_EPI_ADAM) {
                 const int64_t off = (reinterpret_cast<const float*>(a.epi.out) - ac.grad) + (int64_t)m * a.epi.ldo + n;
                 adam_quad(ac, off, v);
+            } else if constexpr (CSUM) {
+                float sv[4];
+                epilogue_quad<EPI, bf16_t>(a.epi, m, n, v, loss, nullptr, sv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cs[j] += bf2f(f2bf(sv[j]));       // the value the weight-gradient GEMM will read
             } else {
                 epilogue_quad<EPI, bf16_t>(a.epi, m, n, v, loss);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next block overwrites
+    }
+    if constexpr (CSUM) {
+        if (a.csum_out) {     // fixed order: a lane's rows ascending, the 4 row classes (shuffles), then wave row 0 + wave row 1
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cs[j] += __shfl_xor(cs[j], 16, 64);
+                cs[j] += __shfl_xor(cs[j], 32, 64);
+            }
+            __syncthreads();                                   // every wave is done with its staging block
+            float* cx = reinterpret_cast<float*>(smem);        // [4 wave columns][64]
+            if (wr == 1 && g == 0) *reinterpret_cast<float4*>(cx + wc * 64 + li * 4) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+            __syncthreads();
+            if (wr == 0 && g == 0) {
+                const float4 o4 = *reinterpret_cast<const float4*>(cx + wc * 64 + li * 4);
+                *reinterpret_cast<float4*>(a.csum_out + (int64_t)tm * a.csum_ld + n0 + wc * 64 + li * 4) =
+                    make_float4(cs[0] + o4.x, cs[1] + o4.y, cs[2] + o4.z, cs[3] + o4.w);
+            }
+        }
     }
     if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
         float* red = reinterpret_cast<float*>(smem);
@@ -300,7 +325,12 @@ static int launch256(hipStream_t s, const GemmArgs& a0, const dmvae_adam_ctx* ct
     if (ctx) c = *ctx;
     BiasSeg bs{};
     int extra = 0;
-    if (LAYOUT == DMVAE_GEMM_DW && a.epi.out2) {      // bias gradient: slab partials now, the sum (and its Adam) in the launch's extra workgroups
+    if (LAYOUT == DMVAE_GEMM_DW && a.epi.out2 && a.csum_in) {
+        // the GEMM that produced dY left its column sums per 256-row tile (GemmArgs::csum_out): nothing to re-read
+        bs.part = a.csum_in; bs.nslab = a.csum_rows; bs.n = a.N; bs.out = reinterpret_cast<float*>(a.epi.out2);
+        if (a.csum_ld != a.N) { set_error("gemm_bf16_256: column-sum partials must be [rows][N]"); return DMVAE_EINVAL; }
+        extra = std::min(8, (a.N / 4 + 511) / 512);
+    } else if (LAYOUT == DMVAE_GEMM_DW && a.epi.out2) {      // bias gradient: slab partials now, the sum (and its Adam) in the launch's extra workgroups
         float* ws = a.ws;
         int64_t ws_elems = a.ws_elems;
         if (!ws) {

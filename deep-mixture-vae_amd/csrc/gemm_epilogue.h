@@ -33,6 +33,11 @@ struct GemmArgs {
     // split: the caller adds the slabs in a fixed order); 0 = plain store
     int64_t slab_stride = 0;
     int64_t slab_stride2 = 0;      // likewise for the DW layout's fused bias gradient (epi.out2)
+    // 256x256 kernel: column sums of the tile's OUTPUT as it is stored (RELU_MASK / BIAS_RECON epilogues: the dY of the next
+    // weight-gradient GEMM) -> csum_out[tile_row][csum_ld]: the bias gradient of that layer without re-reading dY.
+    float* csum_out = nullptr; int64_t csum_ld = 0;
+    // DW layout, 256x256 kernel: such partials of this problem's dY, [csum_rows][csum_ld] (replaces the slab column sums)
+    const float* csum_in = nullptr; int csum_rows = 0;
 };
 
 // element offset of K position k (multiple of the tile depth) of a conv-mode A operand
@@ -88,8 +93,9 @@ __device__ __forceinline__ void xent_sigmoid(float l, float x, float& xent, floa
 
 // One quad of the epilogue.  `loss` accumulates the RECON contribution.
 // xpre: RECON only, the target quad x[m][n..n+3] when the caller fetched it ahead of time.
+// stored: optional, receives the four values as they were stored in the ACT output (RELU_MASK, BIAS_RECON: the gradient quad)
 template <int EPI, typename ACT>
-__device__ __forceinline__ void epilogue_quad(const dmvae_epilogue& e, int m, int n, float v[4], float& loss, const float* xpre = nullptr) {
+__device__ __forceinline__ void epilogue_quad(const dmvae_epilogue& e, int m, int n, float v[4], float& loss, const float* xpre = nullptr, float* stored = nullptr) {
     if constexpr (EPI == DMVAE_EPI_BIAS_RELU) {
         float b[4];
         loadf4(e.bias, n, b);
@@ -131,6 +137,7 @@ __device__ __forceinline__ void epilogue_quad(const dmvae_epilogue& e, int m, in
             }
         }
         ActIO<ACT>::store4(e.out, (int64_t)m * e.ldo + n, d);
+        if (stored) { stored[0] = d[0]; stored[1] = d[1]; stored[2] = d[2]; stored[3] = d[3]; }
         if (e.out2) ActIO<float>::store4(e.out2, (int64_t)m * e.ldo2 + n, v);
     } else if constexpr (EPI == DMVAE_EPI_RELU_MASK) {
         float y[4];
@@ -138,6 +145,7 @@ __device__ __forceinline__ void epilogue_quad(const dmvae_epilogue& e, int m, in
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = y[j] > 0.f ? v[j] : 0.f;
         ActIO<ACT>::store4(e.out, (int64_t)m * e.ldo + n, v);
+        if (stored) { stored[0] = v[0]; stored[1] = v[1]; stored[2] = v[2]; stored[3] = v[3]; }
     } else if constexpr (EPI == DMVAE_EPI_LATENT) {
         float gm[4], gl[4], cl[4], o0[4], o1[4];
         loadf4(e.aux0, (int64_t)m * e.ld0 + n, gm);
