@@ -1093,7 +1093,7 @@ extern "C" int dmvae_debug_set_tile(int bm, int bn) {
 }
 
 extern "C" int dmvae_debug_set_knob(int which, int value) {
-    DMVAE_REQUIRE(which >= 0 && which <= 7, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, 3 = ring depth policy, 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy, 7 = short-K workgroups");
+    DMVAE_REQUIRE(which >= 0 && which <= 8, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, 3 = ring depth policy, 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy, 7 = short-K workgroups, 8 = first-tile stagger of the merged dW grid");
     gemm_bf16_set_knob(which, value);
     return 0;
 }

@@ -707,16 +707,13 @@ int gemm_bf16_grouped(hipStream_t s, int layout, const GemmArgs* probs, int npro
 // (its grid covers the chip by itself), with the bias gradient from slab column sums and -- under ctx -- its Adam
 // update.  Returns the problems that stay grouped.
 static int peel_large_dw(hipStream_t s, const GemmArgs* probs, int nprob, const dmvae_adam_ctx* ctx, std::vector<GemmArgs>& rest) {
+    std::vector<GemmArgs> large;
     for (int i = 0; i < nprob; ++i) {
         const GemmArgs& p = probs[i];
-        if (p.k_split == p.K && gemm_bf16_256_ok(DMVAE_GEMM_DW, p.epi.kind, p.M, p.N, p.K, p.conv_c != 0)) {
-            const int rc = gemm_bf16_256_launch(s, DMVAE_GEMM_DW, p, ctx);
-            if (rc) return rc;
-        } else {
-            rest.push_back(p);
-        }
+        if (p.k_split == p.K && gemm_bf16_256_ok(DMVAE_GEMM_DW, p.epi.kind, p.M, p.N, p.K, p.conv_c != 0)) large.push_back(p);
+        else rest.push_back(p);
     }
-    return 0;
+    return large.empty() ? 0 : gemm_bf16_256_dw_all(s, large.data(), (int)large.size(), ctx);      // merged into one grid where possible
 }
 int gemm_bf16_grouped_dw(hipStream_t s, const GemmArgs* probs, int nprob) {
     if (nprob < 1 || nprob > DMVAE_MAX_GROUP) { set_error("dmvae_gemm_grouped_dw: 1..%d problems", DMVAE_MAX_GROUP); return DMVAE_EINVAL; }
@@ -766,6 +763,7 @@ void gemm_bf16_set_knob(int which, int v) {
     if (which == 5) g_conv_short = v;
     if (which == 6) gemm_bf16_256_set_policy(v);
     if (which == 7) g_shortk = v;
+    if (which == 8) gemm_bf16_256_set_stagger(v);
 }
 
 // Tile choice, BM*1000+BN.  These GEMMs run at the per-CU L2->LDS streaming rate, so the figure

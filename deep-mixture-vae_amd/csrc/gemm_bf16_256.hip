@@ -35,9 +35,12 @@
 // Epilogue: every wave parks a 64x64 fp32 block in its PRIVATE 16 KiB of the idle LDS (XOR-swizzled, conflict-free)
 // and re-reads it row-contiguous: 128..256-byte row segments per 16 lanes -> the fused epilogues of
 // gemm_epilogue.h, or the TF-Adam update on the gradient quad (DMVAE_EPI_ADAM).
+#include <string.h>
+
 #include <algorithm>
 #include <string>
 #include <type_traits>
+#include <vector>
 
 #include "gemm_tile.h"
 
@@ -81,37 +84,36 @@ __global__ __launch_bounds__(256) void colsum_slabs_kernel(const bf16_t* in, int
             part[(int64_t)blockIdx.y * N + blockIdx.x * 512 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
+// bias gradient from its partials (slab column sums, or the per-tile column sums dY's producer left) + its Adam update:
+// workgroup e of ne (512 threads each)
+template <int EPI>
+__device__ __forceinline__ void bias_seg_block(const BiasSeg& bs, const dmvae_adam_ctx& ac, const int e, const int ne) {
+    for (int q = e * 512 + (int)threadIdx.x; q < bs.n / 4; q += ne * 512) {
+        float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sl = 0; sl < bs.nslab; ++sl) {                      // ascending order
+            const float4 p4 = *reinterpret_cast<const float4*>(bs.part + (int64_t)sl * bs.n + 4 * q);
+            g4.x += p4.x; g4.y += p4.y; g4.z += p4.z; g4.w += p4.w;
+        }
+        if constexpr (EPI == DMVAE_EPI_ADAM) {
+            const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+            adam_quad(ac, (bs.out - ac.grad) + 4 * q, gv);
+        } else {
+            *reinterpret_cast<float4*>(bs.out + 4 * q) = g4;
+        }
+    }
+}
+
+// one 256x256 output tile; bid = tile id within the problem (the caller did the XCD-aware remap)
 template <int LAYOUT, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(GemmArgs a, dmvae_adam_ctx ac, int ntiles, BiasSeg bs) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[8 * HALF_ELEMS];       // 128 KiB: 2 K tiles x {A-lo, A-hi, B-lo, B-hi}
+__device__ __forceinline__ void gemm256_tile(const GemmArgs& a, const dmvae_adam_ctx& ac, const int bid, bf16_t* smem) {
     constexpr bool A_KC = (LAYOUT != DMVAE_GEMM_DW);
     constexpr bool B_KC = (LAYOUT == DMVAE_GEMM_DX);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
-    if constexpr (LAYOUT == DMVAE_GEMM_DW) {
-        if ((int)blockIdx.x >= ntiles) {         // extra workgroups: the bias gradient from its slab partials (+ its Adam update)
-            for (int q = ((int)blockIdx.x - ntiles) * 512 + tid; q < bs.n / 4; q += ((int)gridDim.x - ntiles) * 512) {
-                float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int sl = 0; sl < bs.nslab; ++sl) {
-                    const float4 p4 = *reinterpret_cast<const float4*>(bs.part + (int64_t)sl * bs.n + 4 * q);
-                    g4.x += p4.x; g4.y += p4.y; g4.z += p4.z; g4.w += p4.w;
-                }
-                if constexpr (EPI == DMVAE_EPI_ADAM) {
-                    const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
-                    adam_quad(ac, (bs.out - ac.grad) + 4 * q, gv);
-                } else {
-                    *reinterpret_cast<float4*>(bs.out + 4 * q) = g4;
-                }
-            }
-            return;
-        }
-    }
-
-    // XCD-aware tile order, as in gemm_bf16.hip: a contiguous run of tile ids per XCD, walked in supertiles
+    // tiles of an XCD's run are walked in supertiles, as in gemm_bf16.hip
     const int tiles_n = a.N / 256, tiles_m = a.M / 256;
-    const int bid = xcd_run_index((int)blockIdx.x, 0, ntiles);
     int tm, tn;
     {
         const int gm_max = a.group_m;
@@ -295,6 +297,53 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(GemmArgs a, dmvae
     }
 }
 
+template <int LAYOUT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(GemmArgs a, dmvae_adam_ctx ac, int ntiles, BiasSeg bs) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[8 * HALF_ELEMS];       // 128 KiB: 2 K tiles x {A-lo, A-hi, B-lo, B-hi}
+    if constexpr (LAYOUT == DMVAE_GEMM_DW) {
+        if ((int)blockIdx.x >= ntiles) {         // extra workgroups: the bias gradient
+            bias_seg_block<EPI>(bs, ac, (int)blockIdx.x - ntiles, (int)gridDim.x - ntiles);
+            return;
+        }
+    }
+    // XCD-aware tile order: a contiguous run of tile ids per XCD
+    gemm256_tile<LAYOUT, EPI>(a, ac, xcd_run_index((int)blockIdx.x, 0, ntiles), smem);
+}
+
+// Several weight-gradient problems in ONE grid (the 4096-wide configuration has nine of 256..512 tiles each).  A launch per
+// problem ends with every CU in its Adam epilogue at the same time (1.66 MB per tile: the chip's HBM rate, 80 us, with the
+// matrix cores idle) and re-synchronises all CUs at every boundary.  In one grid a CU takes the next tile when it is done,
+// and the first tile of every CU starts behind a delay that grows with the workgroup id: the tiles drift apart, an epilogue
+// then shares HBM with few others and overlaps the other CUs' K loops.
+constexpr int MULTI_MAX = 12;
+struct Multi256 {
+    int nprob, stagger;
+    int start[MULTI_MAX + 1];            // tile workgroups of problem i: [start[i], start[i+1])
+    int extra[MULTI_MAX + 1];            // bias-gradient workgroups of problem i, behind all tiles: start[nprob] + [extra[i], extra[i+1])
+    GemmArgs p[MULTI_MAX];
+    BiasSeg bs[MULTI_MAX];
+    dmvae_adam_ctx ac;
+};
+static_assert(sizeof(Multi256) <= 4096, "kernel argument block");
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_256_dw_multi_kernel(Multi256 m) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[8 * HALF_ELEMS];
+    const int b = (int)blockIdx.x, ntile = m.start[m.nprob];
+    if (b >= ntile) {
+        int j = 0;
+        while (j + 1 < m.nprob && b - ntile >= m.extra[j + 1]) ++j;
+        bias_seg_block<EPI>(m.bs[j], m.ac, b - ntile - m.extra[j], m.extra[j + 1] - m.extra[j]);
+        return;
+    }
+    int i = 0;
+    while (i + 1 < m.nprob && b >= m.start[i + 1]) ++i;
+    if (b < 256) {                       // first tile of a CU: delayed by up to `stagger` x 3.4 us, growing with the workgroup id
+        const int n = (b * m.stagger) >> 8;
+        for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(127);
+    }
+    gemm256_tile<DMVAE_GEMM_DW, EPI>(m.p[i], m.ac, xcd_run_index(b, m.start[i], m.start[i + 1]), smem);
+}
+
 // ---------------------------------------------------------------- host side
 static int g_policy256 = 1;     // tuning knob (dmvae_debug_set_knob 6): 0 never, 1 when the grid fills the chip, 2 whenever the shape divides
 void gemm_bf16_256_set_policy(int v) { g_policy256 = v; }
@@ -360,6 +409,61 @@ static int launch256(hipStream_t s, const GemmArgs& a0, const dmvae_adam_ctx* ct
     ProfScope ps(s, nm.c_str(), 2.0 * a.M * a.N * (double)a.K, bytes);
     hipLaunchKernelGGL((gemm_bf16_256_kernel<LAYOUT, EPI>), dim3(tiles + extra), dim3(512), 0, s, a, c, tiles, bs);
     return check_launch("gemm_bf16_256");
+}
+
+static int g_stagger = 24;      // tuning knob (dmvae_debug_set_knob 8): first-tile delay of the merged dW grid, units of 3.4 us spread over the 256 CUs (0 = none)
+void gemm_bf16_256_set_stagger(int v) { g_stagger = v; }      // -1: no merged grid at all (one launch per problem)
+
+// n (2 .. MULTI_MAX) weight-gradient problems as one grid; every problem with a bias gradient must bring its column-sum partials
+template <int EPI>
+static int launch256_dw_multi(hipStream_t s, const GemmArgs* probs, int n, const dmvae_adam_ctx* ctx) {
+    Multi256 m;
+    memset(&m, 0, sizeof(m));
+    m.nprob = n; m.stagger = std::max(0, g_stagger);
+    if (ctx) m.ac = *ctx;
+    int total = 0, extra = 0;
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        GemmArgs a = probs[i];
+        const int tiles = (a.M / 256) * (a.N / 256);
+        a.group_m = gemm_auto_group_m(a.M / 256, a.N / 256, 256, 256, std::max(1.0, std::min(tiles, 256) / 8.0));
+        m.p[i] = a;
+        m.start[i] = total; total += tiles;
+        m.extra[i] = extra;
+        if (a.epi.out2) {
+            if (!a.csum_in || a.csum_ld != a.N) { set_error("gemm_bf16_256 (merged dW): a problem with a bias gradient needs its column-sum partials"); return DMVAE_EINVAL; }
+            m.bs[i].part = a.csum_in; m.bs[i].nslab = a.csum_rows; m.bs[i].n = a.N; m.bs[i].out = reinterpret_cast<float*>(a.epi.out2);
+            extra += std::min(8, (a.N / 4 + 511) / 512);
+        }
+        flops += 2.0 * a.M * a.N * (double)a.K;
+        bytes += 2.0 * ((double)a.M * a.K + (double)a.K * a.N);
+        if (EPI == DMVAE_EPI_ADAM) bytes += ((double)a.M * a.N + (a.epi.out2 ? a.N : 0)) * (24.0 + (m.ac.param_bf16 ? 2.0 : 0.0) + (m.ac.store_grad ? 4.0 : 0.0));
+        else bytes += 4.0 * a.M * a.N;
+    }
+    for (int i = n; i <= MULTI_MAX; ++i) { m.start[i] = total; m.extra[i] = extra; }
+    static const std::string nm = std::string("gemm_bf16_256_dw_multi_kernel<") + std::to_string(EPI) + ">";
+    ProfScope ps(s, nm.c_str(), flops, bytes);
+    hipLaunchKernelGGL((gemm_bf16_256_dw_multi_kernel<EPI>), dim3(total + extra), dim3(512), 0, s, m);
+    return check_launch("gemm_bf16_256_dw_multi");
+}
+// the large weight-gradient problems of a step: merged into grids of up to MULTI_MAX, singles launched alone
+int gemm_bf16_256_dw_all(hipStream_t s, const GemmArgs* probs, int n, const dmvae_adam_ctx* ctx) {
+    std::vector<GemmArgs> merge;
+    for (int i = 0; i < n; ++i) {
+        const GemmArgs& a = probs[i];
+        if (a.k_split != a.K) { set_error("gemm_bf16_256: no split-K"); return DMVAE_EINVAL; }
+        if (g_stagger >= 0 && (!a.epi.out2 || (a.csum_in && a.csum_ld == a.N))) merge.push_back(a);
+        else { const int rc = gemm_bf16_256_launch(s, DMVAE_GEMM_DW, a, ctx); if (rc) return rc; }
+    }
+    for (size_t lo = 0; lo < merge.size(); lo += MULTI_MAX) {
+        const int cnt = (int)std::min<size_t>(MULTI_MAX, merge.size() - lo);
+        int rc;
+        if (cnt == 1) rc = gemm_bf16_256_launch(s, DMVAE_GEMM_DW, merge[lo], ctx);
+        else if (merge[lo].epi.kind == DMVAE_EPI_ADAM) rc = launch256_dw_multi<DMVAE_EPI_ADAM>(s, merge.data() + lo, cnt, ctx);
+        else rc = launch256_dw_multi<DMVAE_EPI_STORE_F32>(s, merge.data() + lo, cnt, ctx);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int gemm_bf16_256_launch(hipStream_t s, int layout, const GemmArgs& a, const dmvae_adam_ctx* ctx) {

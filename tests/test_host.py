@@ -415,5 +415,14 @@ def test_png_writer_roundtrip(tmp_path):
     raw = zlib.decompress(chunks[b"IDAT"])
     rows = np.frombuffer(raw, dtype=np.uint8).reshape(6, 6)
     assert (rows[:, 0] == 0).all() and (rows[:, 1:] == img.astype(np.uint8)).all()
+    # RGB form + the cluster scatter of mnist_sample_plot(tsne=True) (visualization.py:93-110)
+    rng = np.random.RandomState(0)
+    sc = V.cluster_scatter([rng.randn(80, 2) + 6 * k for k in range(3)], side=60)
+    assert sc.shape == (60, 60, 3) and len({tuple(c) for c in sc.reshape(-1, 3).astype(int).tolist()}) == 4      # white + three cluster colours
+    sc5 = V.cluster_scatter([rng.randn(40, 5) + 4 * k for k in range(2)], side=32)                             # > 2 latent dims: through t-SNE
+    assert sc5.shape == (32, 32, 3) and (sc5 != 255).any()
+    V._write_png(str(tmp_path / "rgb.png"), sc)
+    blob = open(str(tmp_path / "rgb.png"), "rb").read()
+    assert struct.unpack(">IIBB", blob[16:26]) == (60, 60, 8, 2)
     g = V._grid(np.arange(100 * 4).reshape(100, 4), side=2)
     assert g.shape == (20, 20) and g[0, 0] == 0 and g[0, 2] == 4 and g[2, 0] == 40      # image 1 to the right, image 10 below
