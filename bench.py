@@ -349,7 +349,9 @@ def main():
                                % ("configs[1]: " if is_cfg2 else "", arch),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                    "hip_graph": (not args.no_graph) and sync is None, "float_atomics": False,
-                   "update": "stand-alone adam" if args.cnn and sync is None else "adam fused into the dW launch" if sync is None else "bucketed all-reduce overlapped with backward, then adam"},
+                   "update": "stand-alone adam" if args.cnn and sync is None else "adam fused into the dW launch" if sync is None else
+                             ("%s, %s" % ("reduce-scatter -> adam on the owned 1/world slice -> all-gather" if getattr(sync, "sharded", False) else "all-reduce -> replicated adam",
+                                          "three buckets overlapped with the backward pass" if getattr(sync, "overlap", False) else "one collective after the backward pass"))},
         "step_flops_algorithmic": fpi * B,
         "step_mfma_frac_of_peak": round(fpi * B / (ms_step * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4),
         "last_loss": round(float(st.last_loss), 4),

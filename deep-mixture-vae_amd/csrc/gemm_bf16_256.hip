@@ -411,7 +411,9 @@ static int launch256(hipStream_t s, const GemmArgs& a0, const dmvae_adam_ctx* ct
     return check_launch("gemm_bf16_256");
 }
 
-static int g_stagger = 24;      // tuning knob (dmvae_debug_set_knob 8): first-tile delay of the merged dW grid, units of 3.4 us spread over the 256 CUs (0 = none)
+static int g_stagger = 0;       // tuning knob (dmvae_debug_set_knob 8): first-tile delay of the merged dW grid, units of 3.4 us spread over the 256 CUs.
+                                // MEASURED at cfg5 (tools/knob_cfg5.py 8 -1 0 12 24 48): one launch per problem 7.07 ms; merged, no delay 6.89;
+                                // delays 12 / 24 / 48 units 7.01 / 7.01 / 7.11 -- the tiles drift apart by themselves, a forced stagger only costs
 void gemm_bf16_256_set_stagger(int v) { g_stagger = v; }      // -1: no merged grid at all (one launch per problem)
 
 // n (2 .. MULTI_MAX) weight-gradient problems as one grid; every problem with a bias gradient must bring its column-sum partials
