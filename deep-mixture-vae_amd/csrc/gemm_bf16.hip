@@ -331,11 +331,14 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     for (int q = 0; q < BM * CH / NT; ++q) {
         const int idx = q * NT + tid;
         const int ml = idx / CH, c = idx % CH;
+        bool padcol = false;
         if constexpr (CONV) {     // a 32-channel activation is stored 32 wide: the tile's other columns are not part of the output
-            if (n0 + c * 4 >= a.epi.n_valid) continue;
+            padcol = n0 + c * 4 >= a.epi.n_valid;
+            if (padcol && !(EPI == DMVAE_EPI_STORE_F32 && a.slab_stride)) continue;      // (slabs are summed whole: their pad columns must hold zeros)
         }
         const f32x4 t = *reinterpret_cast<const f32x4*>(ct + ml * BN + ((c ^ (ml & 7)) << 2));
         float v[4] = {t[0], t[1], t[2], t[3]};
+        if (padcol) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
         if constexpr (EPI == DMVAE_EPI_ADAM) {
             // the gradient quad updates the matching parameter / m / v elements (same offset in every arena)
             const int64_t off = (reinterpret_cast<const float*>(a.epi.out) - ac->grad) + (int64_t)(m0 + ml) * a.epi.ldo + n0 + c * 4;
@@ -367,7 +370,10 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn * (BN / 2) + j * 16 + g * 4;
                 if constexpr (CONV) {
-                    if (n >= a.epi.n_valid) continue;
+                    if (n >= a.epi.n_valid) {
+                        if (EPI == DMVAE_EPI_STORE_F32 && a.slab_stride2) *reinterpret_cast<float4*>(db + n) = make_float4(0.f, 0.f, 0.f, 0.f);
+                        continue;
+                    }
                 }
                 if constexpr (EPI == DMVAE_EPI_ATOMIC_F32) {
 #pragma unroll

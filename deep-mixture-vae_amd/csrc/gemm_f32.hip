@@ -143,7 +143,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
             const int m = m0 + wm * 32 + i * 16 + li;
             const int n = n0 + wn * 32 + j * 16 + g * 4;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (a.conv_c && n >= a.epi.n_valid) continue;      // conv mode: a 32-channel activation is stored 32 wide
+            if (a.conv_c && n >= a.epi.n_valid) {              // conv mode: a 32-channel activation is stored 32 wide
+                if (!(EPI == DMVAE_EPI_STORE_F32 && a.slab_stride)) continue;
+                v[0] = v[1] = v[2] = v[3] = 0.f;               // (slabs are summed whole: their pad columns must hold zeros)
+            }
             epilogue_quad<EPI, float>(epi, m, n, v, loss);
         }
     if constexpr (DW) {
@@ -152,7 +155,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = n0 + wn * 32 + j * 16 + g * 4;
-                if (a.conv_c && n >= a.epi.n_valid) continue;
+                if (a.conv_c && n >= a.epi.n_valid) {
+                    if (EPI == DMVAE_EPI_STORE_F32 && a.slab_stride2) *reinterpret_cast<float4*>(db + n) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    continue;
+                }
                 if constexpr (EPI == DMVAE_EPI_ATOMIC_F32) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) atomicAdd(db + n + e, bacc[j][e]);
