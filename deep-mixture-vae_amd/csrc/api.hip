@@ -102,6 +102,10 @@ static int gemm_partials(int, int M, int N) { return (M / 64) * (N / 64); }
 
 using namespace dmvae;
 
+// tuning knob (dmvae_debug_set_knob 9): the narrow middle of the backward pass (dZ GEMM + latent epilogue + both head dX GEMMs)
+// as one 16-row-block kernel (mid_bwd.hip) instead of three tile-GEMM launches
+static int g_mid_bwd = 0;
+
 // ====================================================================== plan
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -735,6 +739,8 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     const bool heads_big = dt == DMVAE_BF16 && gemm_bf16_256_ok(DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK, p->Bp, p->Hp, 2 * p->Dp, false) &&
                            gemm_bf16_256_ok(DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK, p->Bp, p->Hp, p->Kp, false);
     const bool fin_rides = all && dt == DMVAE_BF16 && p->finalize_rides && !heads_big && !p->vade;
+    const bool use_mid = g_mid_bwd && dt == DMVAE_BF16 && !p->vade && !heads_big && p->conv.empty() &&
+                         mid_bwd_applies(p->Bp, p->Dp, p->Kp, p->Hp, p->dec[0].out_pad);
   if (all || stage == 0) {
     p->dw_queue.clear();
     p->csum_of.clear();
@@ -798,7 +804,7 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
             TRY(dx_dense(p, s, WS(p, p->o_ddec[i]), L.out_pad, L.out_pad, L.w_off, L.ldw, L.in_pad,
                          WS(p, p->o_dec[i - 1]), p->dec[i - 1].out_pad, WS(p, p->o_ddec[i - 1]), p->dec[i - 1].out_pad, nullptr,
                          WS(p, p->o_ddec[i - 1]), cso(p->o_cs_ddec, i - 1), p->dec[i - 1].out_pad));
-        } else {   // dZ -> [dmean | dlog_var] through the reparameterisation + KL gradients
+        } else if (!use_mid) {   // dZ -> [dmean | dlog_var] through the reparameterisation + KL gradients (use_mid: part of mid_bwd, below)
             dmvae_epilogue e;
             memset(&e, 0, sizeof(e));
             e.kind = DMVAE_EPI_LATENT; e.out = WS(p, p->o_dmv); e.ldo = 2 * p->Dp; e.d_off = p->Dp;
@@ -816,9 +822,26 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     TRY(flush_dw(p, s, 1));
   } else if (all || stage == 1) {
     // ---- backward: heads
+    if (use_mid) {    // dZ, the latent backward and both head dX GEMMs as one kernel over 16-row blocks
+        MidBwdArgs m;
+        memset(&m, 0, sizeof(m));
+        m.Bp = p->Bp; m.Dp = p->Dp; m.Kp = p->Kp; m.Hp = p->Hp; m.N0 = p->dec[0].out_pad;
+        m.ddec0 = reinterpret_cast<const bf16_t*>(WS(p, p->o_ddec[0])); m.ld_dd = p->dec[0].out_pad;
+        m.Wd0 = reinterpret_cast<const bf16_t*>(Wp(p, p->dec[0].w_off)); m.ld_wd0 = p->dec[0].ldw;
+        m.gmu = reinterpret_cast<const float*>(WS(p, p->o_gmu)); m.glv = reinterpret_cast<const float*>(WS(p, p->o_glv));
+        m.clv = reinterpret_cast<const float*>(WS(p, p->o_clv)); m.ld_g = p->Dp;
+        m.dmv = reinterpret_cast<bf16_t*>(WS(p, p->o_dmv)); m.ld_dmv = 2 * p->Dp;
+        m.dlg = reinterpret_cast<const bf16_t*>(WS(p, p->o_dlg)); m.ld_dlg = p->Kp;
+        m.Wmv = reinterpret_cast<const bf16_t*>(Wp(p, p->mv.w_off)); m.ld_wmv = p->mv.ldw;
+        m.Wlg = reinterpret_cast<const bf16_t*>(Wp(p, p->lg.w_off)); m.ld_wlg = p->lg.ldw;
+        m.hzc = reinterpret_cast<const bf16_t*>(WS(p, p->o_hzc)); m.ld_h = 2 * p->Hp;
+        m.dhzc = reinterpret_cast<bf16_t*>(WS(p, p->o_dhzc)); m.ld_dh = 2 * p->Hp;
+        if (fin_rides) m.fin = fin;
+        TRY(mid_bwd_launch(s, m));
+    }
     TRY(grad_dense(p, s, WS(p, p->o_hzc), 2 * p->Hp, p->Hp, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->mv.b_off));
     TRY(grad_dense(p, s, act_off(p, p->o_hzc, p->Hp), 2 * p->Hp, p->Hp, WS(p, p->o_dlg), p->Kp, p->Kp, p->lg.w_off, p->lg.ldw, p->lg.b_off));
-    {   // d(z-hidden) and d(c-hidden): independent siblings writing the two halves of dhzc -> one grouped grid (bf16)
+    if (!use_mid) {   // d(z-hidden) and d(c-hidden): independent siblings writing the two halves of dhzc -> one grouped grid (bf16)
         GemmArgs q[2];
         const bool grp = dt == DMVAE_BF16 && !heads_big;
         TRY(dx_dense(p, s, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->Hp, WS(p, p->o_hzc), 2 * p->Hp, WS(p, p->o_dhzc), 2 * p->Hp,
@@ -1093,6 +1116,7 @@ extern "C" int dmvae_debug_set_tile(int bm, int bn) {
 }
 
 extern "C" int dmvae_debug_set_knob(int which, int value) {
+    if (which == 9) { g_mid_bwd = value; return 0; }
     DMVAE_REQUIRE(which >= 0 && which <= 8, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, 3 = ring depth policy, 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy, 7 = short-K workgroups, 8 = first-tile stagger of the merged dW grid");
     gemm_bf16_set_knob(which, value);
     return 0;

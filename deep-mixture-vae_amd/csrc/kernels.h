@@ -70,4 +70,22 @@ int maxpool2_fwd_launch(hipStream_t s, int dtype, const void* in, int H, int ld,
 int maxpool2_bwd_relu_launch(hipStream_t s, int dtype, const void* in, const void* dout, int H, int ld, int64_t n_img, void* din, int dout_border);
 int conv_wflip_launch(hipStream_t s, int dtype, const void* W, int cin, int cin_ld, int cout, int ldw, void* Wt, int Kt);
 
+// fused middle of the backward pass (mid_bwd.hip): dZ GEMM + latent backward epilogue + both head dX GEMMs over 16-row blocks
+struct MidBwdArgs {
+    int Bp, Dp, Kp, Hp, N0;                       // padded batch, latent, classes, head width, width of the first decoder layer
+    const bf16_t* ddec0; int64_t ld_dd;           // [Bp][N0]  gradient of the first decoder layer's output (ReLU-gated)
+    const bf16_t* Wd0; int64_t ld_wd0;            // [Dp][N0]  W_dec0 (row d: its N0 outputs contiguous)
+    const float* gmu; const float* glv; const float* clv; int64_t ld_g;    // [Bp][Dp] from the latent kernel
+    bf16_t* dmv; int64_t ld_dmv;                  // [Bp][2 Dp]  out: [dmean | dlog_var]
+    const bf16_t* dlg; int64_t ld_dlg;            // [Bp][Kp]   dlogits from the latent kernel
+    const bf16_t* Wmv; int64_t ld_wmv;            // [Hp][2 Dp]
+    const bf16_t* Wlg; int64_t ld_wlg;            // [Hp][Kp]
+    const bf16_t* hzc; int64_t ld_h;              // [Bp][2 Hp] forward activations [z-hidden | c-hidden] (the ReLU gates)
+    bf16_t* dhzc; int64_t ld_dh;                  // [Bp][2 Hp] out
+    dmvae_finalize_args fin;                      // fin.nblocks extra workgroups run step_finalize (0 = none)
+    int nrow_blocks;
+};
+bool mid_bwd_applies(int Bp, int Dp, int Kp, int Hp, int N0);
+int mid_bwd_launch(hipStream_t s, const MidBwdArgs& a);
+
 }  // namespace dmvae

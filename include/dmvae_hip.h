@@ -389,7 +389,9 @@ int dmvae_debug_set_tile(int bm, int bn);
  *             knob 7 = problems with K <= 128 as 64x64 tiles on a 2-slot ring (32 KiB: four to five workgroups per CU) (0|1;
  *                      default 0: measured slower on the whole step),
  *             knob 8 = merged weight-gradient grid of the 256x256 kernel: first-tile delay, units of 3.4 us spread over the
- *                      256 CUs (default 0 = none, measured best; -1 = one launch per problem) */
+ *                      256 CUs (default 0 = none, measured best; -1 = one launch per problem),
+ *             knob 9 = the narrow middle of the backward pass (dZ GEMM + latent epilogue + both head dX GEMMs) as one kernel over
+ *                      16-row blocks, csrc/mid_bwd.hip (0|1) */
 int dmvae_debug_set_knob(int which, int value);
 
 int dmvae_abi_version(void);
