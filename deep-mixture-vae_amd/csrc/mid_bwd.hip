@@ -11,6 +11,12 @@
 // w, w + 4, ... in phase 1 and every fourth 64-column group of the 2 x head_dim outputs in phase 3; the [16][2D]
 // intermediate goes through LDS (it is phase 3's second operand), the outputs leave through a wave-private LDS tile in
 // 128-byte row segments.  The step_finalize workgroups ride on this launch as they did on the grouped heads-dX launch.
+//
+// MEASURED (tools/knob_ab.py 9 0 1; correct: tests/test_gpu_configs.py ..._with_the_fused_middle_backward) and NOT FASTER:
+// cfg2 0.2973 -> 0.3246 ms/step, cfg4 0.691 -> 0.864, cfg3 1.049 -> 1.334.  The kernel takes ~60 us where the three launches
+// take 35: fragment-shaped global loads (a wave instruction = 16 rows x 64 B) are bound by the texture-addresser, a CU
+// streams its 1.3 MB at ~22 GB/s instead of the ~70 GB/s that full 128-byte lines through LDS-DMA reach (the CDNA guide's
+// "x through LDS in full lines" rule, re-learnt).  Off by default (knob 9); kept as the measured negative result.
 #include <algorithm>
 
 #include "kernels.h"
