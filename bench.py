@@ -84,10 +84,11 @@ def parse():
 
 def rocprof_name(name):
     """the library reports a grouped launch as gemm_bf16_grouped_mixed_tiles<Ll, Ee> (it dispatches 128x128 / 128x64 /
-    64x64 tiles per problem); rocprofv3 prints the instantiation, whose template arguments are the smallest tile"""
+    64x64 tiles per problem); rocprofv3 prints the instantiation, whose template arguments are the smallest tile and
+    the short-K variant flag (knob 7, off)"""
     import re
     m = re.match(r"gemm_bf16_grouped_mixed_tiles<L(\d+), E(\d+)>", name)
-    return "gemm_bf16_grouped_kernel<64, 64, %s, %s, 4, 4>" % (m.group(1), m.group(2)) if m else name
+    return "gemm_bf16_grouped_kernel<64, 64, %s, %s, 4, 4, false>" % (m.group(1), m.group(2)) if m else name
 
 
 def flops_per_image(I, D, K, enc=(500, 500), head=2000, dec=(2000, 500, 500), cnn=False):
@@ -392,7 +393,11 @@ def main():
         if os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
-                traffic = (tj.get(dom["name"]) or tj.get(rocname) or {}).get("hbm_bytes_per_launch")
+                hit = tj.get(dom["name"]) or tj.get(rocname)
+                if hit is None:      # tolerate a template argument list that grew since the PMC pass was keyed
+                    stem = rocname.rstrip(">")
+                    hit = next((v for k, v in tj.items() if k.startswith(stem)), {})
+                traffic = hit.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out["roofline"] = {"kernel": dom["name"], "rocprof_kernel": rocname,

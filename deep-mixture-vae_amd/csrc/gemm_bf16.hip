@@ -714,9 +714,17 @@ int gemm_bf16_grouped(hipStream_t s, int layout, const GemmArgs* probs, int npro
 // update.  Returns the problems that stay grouped.
 static int peel_large_dw(hipStream_t s, const GemmArgs* probs, int nprob, const dmvae_adam_ctx* ctx, std::vector<GemmArgs>& rest) {
     std::vector<GemmArgs> large;
+    // a problem joins when its own grid covers the chip -- or, once such problems exist, when it merely divides by 256 (K >= 1024):
+    // inside the merged grid (gemm_bf16_256_dw_all) a 16..64-tile problem rides at the macro tile's rate instead of the small tiles'
+    bool any = false;
+    for (int i = 0; i < nprob; ++i)
+        any = any || (probs[i].k_split == probs[i].K && gemm_bf16_256_ok(DMVAE_GEMM_DW, probs[i].epi.kind, probs[i].M, probs[i].N, probs[i].K, probs[i].conv_c != 0));
     for (int i = 0; i < nprob; ++i) {
         const GemmArgs& p = probs[i];
-        if (p.k_split == p.K && gemm_bf16_256_ok(DMVAE_GEMM_DW, p.epi.kind, p.M, p.N, p.K, p.conv_c != 0)) large.push_back(p);
+        const bool own = p.k_split == p.K && gemm_bf16_256_ok(DMVAE_GEMM_DW, p.epi.kind, p.M, p.N, p.K, p.conv_c != 0);
+        const bool rides = any && gemm_bf16_256_rides() && p.k_split == p.K && !p.conv_c && p.M % 256 == 0 && p.N % 256 == 0 && p.K >= 1024 &&
+                           (p.epi.kind == DMVAE_EPI_STORE_F32 || p.epi.kind == DMVAE_EPI_ADAM);
+        if (own || rides) large.push_back(p);
         else rest.push_back(p);
     }
     return large.empty() ? 0 : gemm_bf16_256_dw_all(s, large.data(), (int)large.size(), ctx);      // merged into one grid where possible

@@ -448,24 +448,58 @@ static int launch256_dw_multi(hipStream_t s, const GemmArgs* probs, int n, const
     hipLaunchKernelGGL((gemm_bf16_256_dw_multi_kernel<EPI>), dim3(total + extra), dim3(512), 0, s, m);
     return check_launch("gemm_bf16_256_dw_multi");
 }
+bool gemm_bf16_256_rides() { return g_policy256 >= 1 && g_stagger >= 0; }
+
+// slab column sums of dY for a problem whose producer left none: into [nslab][N] floats at ws
+static int colsum_slabs_into(hipStream_t s, const GemmArgs& a, float* ws, int* nslab_out) {
+    constexpr int SLABS = 64;
+    const int rps = std::max(8, (a.K + SLABS - 1) / SLABS);
+    const int nslab = (a.K + rps - 1) / rps;
+    ProfScope ps(s, "colsum_slabs", (double)a.K * a.N, 2.0 * a.K * a.N + 4.0 * nslab * a.N);
+    hipLaunchKernelGGL(colsum_slabs_kernel, dim3((a.N + 511) / 512, nslab), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(a.B), a.ldb, a.K, rps, a.N, ws);
+    *nslab_out = nslab;
+    return check_launch("colsum_slabs");
+}
+
 // the large weight-gradient problems of a step: merged into grids of up to MULTI_MAX, singles launched alone
 int gemm_bf16_256_dw_all(hipStream_t s, const GemmArgs* probs, int n, const dmvae_adam_ctx* ctx) {
     std::vector<GemmArgs> merge;
+    int64_t ws_used = 0;         // the problems of one call share the caller's scratch (GemmArgs::ws): sub-allocated here
+    auto flush = [&]() -> int {  // launch what has been collected (its slab sums live in [0, ws_used) of the scratch)
+        for (size_t lo = 0; lo < merge.size(); lo += MULTI_MAX) {
+            const int cnt = (int)std::min<size_t>(MULTI_MAX, merge.size() - lo);
+            int rc;
+            if (cnt == 1) rc = gemm_bf16_256_launch(s, DMVAE_GEMM_DW, merge[lo], ctx);
+            else if (merge[lo].epi.kind == DMVAE_EPI_ADAM) rc = launch256_dw_multi<DMVAE_EPI_ADAM>(s, merge.data() + lo, cnt, ctx);
+            else rc = launch256_dw_multi<DMVAE_EPI_STORE_F32>(s, merge.data() + lo, cnt, ctx);
+            if (rc) return rc;
+        }
+        merge.clear();
+        ws_used = 0;
+        return 0;
+    };
     for (int i = 0; i < n; ++i) {
-        const GemmArgs& a = probs[i];
+        GemmArgs a = probs[i];
         if (a.k_split != a.K) { set_error("gemm_bf16_256: no split-K"); return DMVAE_EINVAL; }
-        if (g_stagger >= 0 && (!a.epi.out2 || (a.csum_in && a.csum_ld == a.N))) merge.push_back(a);
-        else { const int rc = gemm_bf16_256_launch(s, DMVAE_GEMM_DW, a, ctx); if (rc) return rc; }
+        const bool has_part = a.csum_in && a.csum_ld == a.N;
+        if (g_stagger < 0 || (a.epi.out2 && !has_part && (!a.ws || (int64_t)64 * a.N > a.ws_elems))) {
+            // not mergeable (merging off, or a bias gradient with neither partials nor a scratch of the caller's): alone, in stream order
+            int rc = flush();
+            if (!rc) rc = gemm_bf16_256_launch(s, DMVAE_GEMM_DW, a, ctx);
+            if (rc) return rc;
+            continue;
+        }
+        if (a.epi.out2 && !has_part) {      // no partials from dY's producer: slab column sums now, into this problem's part of the scratch
+            if (ws_used + (int64_t)64 * a.N > a.ws_elems) { const int rc = flush(); if (rc) return rc; }
+            int nslab = 0;
+            const int rc = colsum_slabs_into(s, a, a.ws + ws_used, &nslab);
+            if (rc) return rc;
+            a.csum_in = a.ws + ws_used; a.csum_ld = a.N; a.csum_rows = nslab;
+            ws_used += (int64_t)64 * a.N;
+        }
+        merge.push_back(a);
     }
-    for (size_t lo = 0; lo < merge.size(); lo += MULTI_MAX) {
-        const int cnt = (int)std::min<size_t>(MULTI_MAX, merge.size() - lo);
-        int rc;
-        if (cnt == 1) rc = gemm_bf16_256_launch(s, DMVAE_GEMM_DW, merge[lo], ctx);
-        else if (merge[lo].epi.kind == DMVAE_EPI_ADAM) rc = launch256_dw_multi<DMVAE_EPI_ADAM>(s, merge.data() + lo, cnt, ctx);
-        else rc = launch256_dw_multi<DMVAE_EPI_STORE_F32>(s, merge.data() + lo, cnt, ctx);
-        if (rc) return rc;
-    }
-    return 0;
+    return flush();
 }
 
 int gemm_bf16_256_launch(hipStream_t s, int layout, const GemmArgs& a, const dmvae_adam_ctx* ctx) {
