@@ -327,7 +327,7 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
     p->o_dmv = take(Bp * 2 * p->Dp * es);
     p->o_dhzc = take(Bp * 2 * p->Hp * es);
     for (auto& L : p->enc) p->o_denc.push_back(take(Bp * L.out_pad * es));
-    if (c->dtype == DMVAE_BF16 && p->Bp % 256 == 0) {
+    if (c->dtype == DMVAE_BF16 && p->Bp % 256 == 0 && !getenv("DMVAE_NO_CSUM")) {
         const int64_t tr = p->Bp / 256;
         p->o_cs_dl = take(tr * p->Ip * 4);
         p->o_cs_dhzc = take(tr * 2 * p->Hp * 4);
@@ -738,8 +738,9 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     // (wide heads -- the 4096-wide configuration -- take the 256x256 macro-tile kernel one by one instead of the grouped grid)
     const bool heads_big = dt == DMVAE_BF16 && gemm_bf16_256_ok(DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK, p->Bp, p->Hp, 2 * p->Dp, false) &&
                            gemm_bf16_256_ok(DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK, p->Bp, p->Hp, p->Kp, false);
-    const bool fin_rides = all && dt == DMVAE_BF16 && p->finalize_rides && !heads_big && !p->vade;
-    const bool use_mid = g_mid_bwd && dt == DMVAE_BF16 && !p->vade && !heads_big && p->conv.empty() &&
+    // (not with the dW groups on the side stream: the first of them starts ahead of the heads launch and its Adam reads lr_t)
+    const bool fin_rides = all && dt == DMVAE_BF16 && p->finalize_rides && !heads_big && !p->vade && !p->overlap_dw;
+    const bool use_mid = g_mid_bwd && !p->overlap_dw && dt == DMVAE_BF16 && !p->vade && !heads_big && p->conv.empty() &&
                          mid_bwd_applies(p->Bp, p->Dp, p->Kp, p->Hp, p->dec[0].out_pad);
   if (all || stage == 0) {
     p->dw_queue.clear();
@@ -852,12 +853,16 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     }
     // ---- backward: trunk
     TRY(grad_dense(p, s, WS(p, p->o_enc[ne - 1]), p->Tp, p->Tp, WS(p, p->o_dhzc), 2 * p->Hp, 2 * p->Hp, p->zc.w_off, p->zc.ldw, p->zc.b_off));
-    TRY(flush_dw(p, s, 1));   // heads dW group ([mean|log_var], logits, [zh|ch])
+    // heads dW group ([mean|log_var], logits, [zh|ch]).  On the side stream with the Adam update in its epilogue it would rewrite
+    // the [zh|ch] weights while the dX GEMM below still reads them: there it is flushed BEHIND that GEMM.
+    if (!(all && p->overlap_dw)) TRY(flush_dw(p, s, 1));
   }
   if (all || stage == 2) {
-    if (!p->vade)
+    if (!p->vade) {
         TRY(dx_dense(p, s, WS(p, p->o_dhzc), 2 * p->Hp, 2 * p->Hp, p->zc.w_off, p->zc.ldw, p->Tp, WS(p, p->o_enc[ne - 1]), p->Tp,
                      WS(p, p->o_denc[ne - 1]), p->Tp, nullptr, WS(p, p->o_denc[ne - 1]), cso(p->o_cs_denc, ne - 1), p->Tp));
+        if (all && p->overlap_dw) TRY(flush_dw(p, s, 1));
+    }
     for (int i = ne - 1; i >= 0; --i) {
         const PLayer& L = p->enc[i];
         const bool cnn = !p->conv.empty();

@@ -327,6 +327,27 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
             *reinterpret_cast<f32x4*>(ct + ml * BN + ((c ^ (ml & 7)) << 2)) = acc[i][j];
         }
     __syncthreads();
+    if constexpr (EPI == DMVAE_EPI_ADAM && !CONV) {
+        // the update in batches of NB quads whose parameter / m / v loads are in flight together (adam_quads, gemm_tile.h)
+        constexpr int NQE = BM * CH / NT;
+        constexpr int NB = NQE % 4 == 0 ? 4 : (NQE % 2 == 0 ? 2 : 1);
+        const unsigned base = (unsigned)((reinterpret_cast<const float*>(a.epi.out) - ac->grad) + (int64_t)m0 * a.epi.ldo + n0);
+#pragma unroll
+        for (int q0 = 0; q0 < NQE; q0 += NB) {
+            unsigned off[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int idx = (q0 + b) * NT + tid;
+                off[b] = base + (unsigned)(idx / CH) * (unsigned)a.epi.ldo + (unsigned)(idx % CH) * 4u;
+            }
+            adam_quads<NB>(*ac, off, [&](int b, float (&gv)[4]) {
+                const int idx = (q0 + b) * NT + tid;
+                const int ml = idx / CH, c = idx % CH;
+                const f32x4 t = *reinterpret_cast<const f32x4*>(ct + ml * BN + ((c ^ (ml & 7)) << 2));
+                gv[0] = t[0]; gv[1] = t[1]; gv[2] = t[2]; gv[3] = t[3];
+            });
+        }
+    } else
 #pragma unroll
     for (int q = 0; q < BM * CH / NT; ++q) {
         const int idx = q * NT + tid;
@@ -746,6 +767,10 @@ int gemm_bf16_grouped_dw_adam(hipStream_t s, const GemmArgs* probs, int nprob, c
     if (!ctx.param || !ctx.grad || !ctx.m || !ctx.v || !ctx.state || (ctx.seg_off & 3) || (ctx.seg_n & 3) || ctx.seg_n < 0) {
         set_error("dmvae_gemm_grouped_dw_adam: null arena / state, or a segment that is not a multiple of 4 elements");
         return DMVAE_EINVAL;
+    }
+    for (int i = 0; i < nprob; ++i) {               // the fused update addresses the arenas with 32-bit element offsets (adam_quads)
+        const int64_t end = (reinterpret_cast<const float*>(probs[i].epi.out) - ctx.grad) + (int64_t)probs[i].M * probs[i].epi.ldo;
+        if (end < 0 || end > ADAM_QUADS_MAX_ELEMS) { set_error("dmvae_gemm_grouped_dw_adam: gradient %d ends %lld elements into the arena (limit 2^30)", i, (long long)end); return DMVAE_EUNSUPPORTED; }
     }
     std::vector<GemmArgs> rest;
     dmvae_adam_ctx c1 = ctx;

@@ -48,6 +48,7 @@ namespace dmvae {
 
 constexpr int HALF_ELEMS = 128 * BK;     // one half-tile: 128 rows (or columns) x 64 k of bf16 = 16 KiB
 constexpr int LOOKAHEAD = 6;             // half-tiles issued ahead of the phase that consumes them
+constexpr int ADAM_NB = 8;               // quads per thread whose parameter / m / v loads are in flight together in the dW + Adam epilogue
 template <int V> using IC = std::integral_constant<int, V>;
 
 // Bias gradient of a dW problem: db[n] = sum_k dY[k][n].  The smaller tiles get it from a ones-operand MFMA in the
@@ -136,17 +137,15 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& a, const dmvae_adam
     unsigned goA[2], goB[2];
     stage_offsets<128, A_KC, 8, BK>(a.lda, wave, lane, goA);
     stage_offsets<128, B_KC, 8, BK>(a.ldb, wave, lane, goB);
-    unsigned short foA[2][4][2], foB[2][4][2];
+    unsigned foA[4], foB[4];             // fragment offsets of K sub-step 0; sub-step 1 and the second transposing read: read_frag_ks
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            frag_offsets<128, A_KC>(wr * 64 + i * 16, ks, lane, foA[ks][i][0], foA[ks][i][1]);
-            frag_offsets<128, B_KC>((wc & 1) * 64 + i * 16, ks, lane, foB[ks][i][0], foB[ks][i][1]);
-            // this wave's B half (columns wc*64.. lie in B-lo for wc < 2, in B-hi else) is folded into the offsets
-            foB[ks][i][0] = (unsigned short)(foB[ks][i][0] + (wc >> 1) * HALF_ELEMS);
-            foB[ks][i][1] = (unsigned short)(foB[ks][i][1] + (wc >> 1) * HALF_ELEMS);
-        }
+    for (int i = 0; i < 4; ++i) {
+        unsigned short lo, hi;
+        frag_offsets<128, A_KC>(wr * 64 + i * 16, 0, lane, lo, hi);
+        foA[i] = lo;
+        frag_offsets<128, B_KC>((wc & 1) * 64 + i * 16, 0, lane, lo, hi);
+        // this wave's B half (columns wc*64.. lie in B-lo for wc < 2, in B-hi else) is folded into the offsets
+        foB[i] = (unsigned)lo + (unsigned)((wc >> 1) * HALF_ELEMS);
     }
     const unsigned lds_w = __builtin_amdgcn_readfirstlane(
         (unsigned)(size_t)((__attribute__((address_space(3))) bf16_t*)smem) + 1024u * (unsigned)wave);
@@ -179,20 +178,17 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& a, const dmvae_adam
         if constexpr (P == 0) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) fb0[j][ks] = read_frag<B_KC>(Bt, foB[ks][j][0], foB[ks][j][1]);
+                { fb0[j][0] = read_frag_ks<128, B_KC, 0>(Bt, foB[j]); fb0[j][1] = read_frag_ks<128, B_KC, 1>(Bt, foB[j]); }
         }
         if constexpr (P == 1) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) fb1[j][ks] = read_frag<B_KC>(Bt, foB[ks][2 + j][0], foB[ks][2 + j][1]);
+                { fb1[j][0] = read_frag_ks<128, B_KC, 0>(Bt, foB[2 + j]); fb1[j][1] = read_frag_ks<128, B_KC, 1>(Bt, foB[2 + j]); }
         }
         if constexpr (P == 0 || P == 2) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) fa[i][ks] = read_frag<A_KC>(At, foA[ks][i][0], foA[ks][i][1]);
+                { fa[i][0] = read_frag_ks<128, A_KC, 0>(At, foA[i]); fa[i][1] = read_frag_ks<128, A_KC, 1>(At, foA[i]); }
         }
         // half-tile (4t + P) + LOOKAHEAD: J = (P + 2) & 3 of K tile t + 1 (P < 2) / t + 2 (P >= 2)
         issue(IC<(P + 2) & 3>{}, IC<(P < 2 ? 1 - PAR : PAR)>{}, t + (P < 2 ? 1 : 2));
@@ -251,6 +247,20 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& a, const dmvae_adam
                 *reinterpret_cast<f32x4*>(st + r * 64 + ((c ^ (r & 7)) << 2)) = acc[h][i][j];
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave, in-order LDS: the block is written
+        if constexpr (EPI == DMVAE_EPI_ADAM) {                  // batches of ADAM_NB quads: loads of a batch in flight together (adam_quads)
+            const unsigned base = (unsigned)((reinterpret_cast<const float*>(a.epi.out) - ac.grad) + (int64_t)(m0 + h * 128 + wr * 64) * a.epi.ldo + n0 + wc * 64 + li * 4);
+#pragma unroll 1
+            for (int it0 = 0; it0 < 16; it0 += ADAM_NB) {
+                unsigned off[ADAM_NB];
+#pragma unroll
+                for (int b = 0; b < ADAM_NB; ++b) off[b] = base + (unsigned)((it0 + b) * 4 + g) * (unsigned)a.epi.ldo;
+                adam_quads<ADAM_NB>(ac, off, [&](int b, float (&gv)[4]) {
+                    const int r = (it0 + b) * 4 + g;
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(st + r * 64 + ((li ^ (r & 7)) << 2));
+                    gv[0] = t4[0]; gv[1] = t4[1]; gv[2] = t4[2]; gv[3] = t4[3];
+                });
+            }
+        } else
 #pragma unroll 4
         for (int it = 0; it < 16; ++it) {
             const int r = it * 4 + g, c = li;

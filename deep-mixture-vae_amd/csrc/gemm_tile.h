@@ -102,6 +102,22 @@ __device__ __forceinline__ void frag_offsets(int i0, int ks, int lane, unsigned 
         hi = (unsigned short)(k1 * R + swz_nc<R>(k1, c) * 8 + (p & 1) * 4);
     }
 }
+// The same fragment from ONE offset per 16-row / 16-column block (that of ks = 0): for an n-contiguous operand the second
+// transposing read sits 4 k-rows further and the ks = 1 fragment 32 k-rows further, and neither move changes the swizzle
+// (k & 3 and (k >> 3) & 1 are the same: k0 & 7 < 4) -- constant offsets, folded into the ds_read's immediate; for a
+// k-contiguous operand ks = 1 flips chunk bit 2 (chunk = ks*4 + g, XOR-swizzled): element offset ^ 32.
+template <int R, bool KC, int KS>
+__device__ __forceinline__ bf16x8 read_frag_ks(const bf16_t* s, unsigned lo) {
+    if constexpr (KC) {
+        const s16x8 v = *reinterpret_cast<const s16x8*>(s + (KS ? (lo ^ 32u) : lo));
+        return __builtin_bit_cast(bf16x8, v);
+    } else {
+        const s16x4 l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(s + lo + KS * 32 * R));
+        const s16x4 h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(s + lo + KS * 32 * R + 4 * R));
+        const s16x8 v = __builtin_shufflevector(l, h, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
 template <bool KC>
 __device__ __forceinline__ bf16x8 read_frag(const bf16_t* s, unsigned lo, unsigned hi) {
     if constexpr (KC) {
@@ -136,6 +152,43 @@ __device__ __forceinline__ void adam_quad(const dmvae_adam_ctx& c, int64_t off, 
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(c.param_bf16) + off) = q;
     }
     if (c.store_grad) *reinterpret_cast<float4*>(c.grad + off) = make_float4(g[0], g[1], g[2], g[3]);
+}
+
+// NB quads at once: every load of the batch is issued before the first store.  One quad at a time the compiler must keep
+// quad j + 1's loads behind quad j's stores (same arrays, offsets it cannot tell apart), and vmcnt(0) then also drains those
+// stores: a full memory round trip per quad, the matrix cores idle meanwhile.  Same arithmetic per element: bit-identical.
+// Offsets are 32-bit ELEMENT offsets into the arenas (the host checks the arena against ADAM_QUADS_MAX_ELEMS): one VGPR per
+// quad beside the three uniform base pointers, instead of three 64-bit addresses kept from the loads to the stores.
+constexpr int64_t ADAM_QUADS_MAX_ELEMS = (int64_t)1 << 30;
+template <int NB, class G>
+__device__ __forceinline__ void adam_quads(const dmvae_adam_ctx& c, const unsigned (&off)[NB], G&& grad_of) {     // grad_of(b, g[4]): the gradient quad of batch item b
+    const dmvae_state* st = reinterpret_cast<const dmvae_state*>(c.state);
+    const float lr_t = st->lr_t;
+    float4 p[NB], m[NB], v[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        p[b] = *reinterpret_cast<const float4*>(c.param + off[b]);
+        m[b] = *reinterpret_cast<const float4*>(c.m + off[b]);
+        v[b] = *reinterpret_cast<const float4*>(c.v + off[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float g[4];
+        grad_of(b, g);
+        float* pp = &p[b].x; float* mp = &m[b].x; float* vp = &v[b].x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) adam_elem(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);
+        *reinterpret_cast<float4*>(c.param + off[b]) = p[b];
+        *reinterpret_cast<float4*>(c.m + off[b]) = m[b];
+        *reinterpret_cast<float4*>(c.v + off[b]) = v[b];
+        if (c.param_bf16) {
+            uint2 q;
+            q.x = pack2bf(p[b].x, p[b].y);
+            q.y = pack2bf(p[b].z, p[b].w);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(c.param_bf16) + off[b]) = q;
+        }
+        if (c.store_grad) *reinterpret_cast<float4*>(c.grad + off[b]) = make_float4(g[0], g[1], g[2], g[3]);
+    }
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
