@@ -1071,9 +1071,29 @@ extern "C" int dmvae_cast_bf16_to_f32(void* stream, const void* in, float* out, 
 }
 
 extern "C" int dmvae_debug_spin(void* stream, int microseconds) { return spin_launch((hipStream_t)stream, microseconds); }
+// probe (tools/chain_probe.py): nlayer square bias + ReLU layers [M x N] as ONE XCD-sliced launch; layer l reads act[l % 2], writes act[(l + 1) % 2]
+extern "C" int dmvae_debug_chain(void* stream, int variant, int nlayer, int M, int N, void* act0, void* act1, const void* const* W,
+                                 const float* const* bias, void* sync, int* err) {
+    DMVAE_REQUIRE(nlayer >= 1 && nlayer <= 8 && act0 && act1 && W && bias && sync && err, "dmvae_debug_chain: bad arguments");
+    GemmArgs layers[8];
+    for (int l = 0; l < nlayer; ++l) {
+        dmvae_epilogue e;
+        memset(&e, 0, sizeof(e));
+        e.kind = DMVAE_EPI_BIAS_RELU; e.out = (l % 2) ? act0 : act1; e.ldo = N; e.bias = bias[l];
+        TRY(gemm_checked((hipStream_t)stream, DMVAE_BF16, DMVAE_GEMM_FWD, M, N, N, (l % 2) ? act1 : act0, N, W[l], N, &e, 1, &layers[l]));
+    }
+    return chain_probe_launch((hipStream_t)stream, variant, nlayer, layers, reinterpret_cast<unsigned*>(sync), err);
+}
+
 extern "C" int dmvae_debug_stamps(void** device_ptr) {
     if (!device_ptr) return DMVAE_EINVAL;
     *device_ptr = gemm_bf16_stamps();
+    return *device_ptr ? 0 : DMVAE_ESTATE;
+}
+
+extern "C" int dmvae_debug_anatomy(void** device_ptr) {
+    if (!device_ptr) return DMVAE_EINVAL;
+    *device_ptr = gemm_bf16_anatomy();
     return *device_ptr ? 0 : DMVAE_ESTATE;
 }
 

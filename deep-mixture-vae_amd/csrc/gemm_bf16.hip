@@ -52,6 +52,12 @@
 #include "gemm_tile.h"
 
 __device__ unsigned long long g_mid[2048];           // DMVAE_ABLATE == 6 builds only: end of each workgroup's K loop
+__device__ unsigned long long g_anat[2048 * 8];      // DMVAE_ABLATE == 6: per workgroup {entry, first tile landed, K loop done, epilogue issued, stores acknowledged, HW_ID|XCC} (tools/anatomy.py)
+#if DMVAE_ABLATE == 6
+#define ANAT(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_anat[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ANAT(i) do { } while (0)
+#endif
 // Measurement-only builds (tools/ablate.sh -> a separately named .so, never the product library):
 // 1 = no MFMA, 2 = no LDS fragment reads, 3 = no global->LDS loads in the K loop, 4 = 1 + 2.
 #ifndef DMVAE_ABLATE
@@ -78,6 +84,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     static_assert(NSTAGE >= 2 && NSTAGE <= 8 && LOADS * (NSTAGE - 1) <= 63, "ring depth / vmcnt range");
     // smem: NSTAGE * STAGE elements, the kernel's ONLY LDS object (owned by the __global__ wrapper)
 
+    ANAT(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -168,14 +175,13 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     const unsigned lds_w = __builtin_amdgcn_readfirstlane(
         (unsigned)(size_t)((__attribute__((address_space(3))) bf16_t*)smem) + 1024u * (unsigned)wave);
 
-    // issue the loads of K tile t (clamped to the last tile: keeps the vmcnt arithmetic uniform;
-    // a clamped tile lands in a ring slot nobody reads) into ring slot `slot`
+    // issue the loads of K tile t (< nk) into ring slot `slot`
     // conv mode: tiles are issued in K order, so (tap, channel) of a tile's first column is a running counter
     int cv_tap = 0, cv_c0 = 0;
     int64_t cv_off = 0;
     unsigned cv_delta = 0;                              // bytes from the tile's first tap to its second (conv_c = 32)
-    auto issue = [&](int t, int slot) {
-        const int tc = t < nk ? t : nk - 1;
+    auto issue = [&](int t, int slot) {                 // t < nk
+        const int tc = t;
         const unsigned s = lds_w + 2u * (unsigned)(slot * STAGE);
         if constexpr (A_KC && CONV) {
             if (t < nk) {
@@ -269,10 +275,16 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
             gate[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.epi.aux0) + (int64_t)(m0 + ml) * a.epi.ld0 + n0 + c * 4);
         }
     }
+    // Only real tiles are issued.  (Round 1 clamped tile ids past the K range to the last tile to keep every vmcnt count a
+    // constant: NSTAGE extra tile loads per workgroup that the epilogue then had to wait for -- 3 of 11 at K = 512.)  The waits
+    // of the last NSTAGE - 1 iterations, where fewer tiles are in flight than the constant assumes, drain everything instead.
 #pragma unroll
-    for (int t = 0; t < NSTAGE; ++t) issue(t, t);
-    wait_vmcnt<LOADS*(NSTAGE - 1)>();                           // tile 0 has landed (this wave's share)
+    for (int t = 0; t < NSTAGE; ++t)
+        if (t < nk) issue(t, t);
+    if (nk >= NSTAGE) wait_vmcnt<LOADS*(NSTAGE - 1)>();        // tile 0 has landed (this wave's share)
+    else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    ANAT(1);
     rd(0, 0, f0a, f0b);
     for (int kt = 0; kt < nk; kt += NSTAGE) {
 #pragma unroll
@@ -281,22 +293,23 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
                 rd(s, 1, f1a, f1b);
                 mma(f0a, f0b);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                wait_vmcnt<LOADS*(NSTAGE - 2)>();               // tile kt+s+1 has landed (this wave's share)
+                if (kt + s + NSTAGE <= nk) wait_vmcnt<LOADS*(NSTAGE - 2)>();   // tile kt+s+1 has landed (this wave's share)
+                else wait_vmcnt<0>();                                          // K tail: fewer tiles in flight than the constant assumes
                 __builtin_amdgcn_s_barrier();
-#if DMVAE_ABLATE == 3                            // tools/ablate.sh: no global loads in the K loop
-                if (kt + s + NSTAGE >= nk)
+#if DMVAE_ABLATE != 3                            // (tools/ablate.sh 3: no global loads in the K loop)
+                if (kt + s + NSTAGE < nk) issue(kt + s + NSTAGE, s);
 #endif
-                issue(kt + s + NSTAGE, s);
                 if (kt + s + 1 < nk) rd((s + 1) % NSTAGE, 0, f0a, f0b);
                 mma(f1a, f1b);
             }
         }
     }
-    wait_vmcnt<0>();                                            // drain the clamped tail loads before LDS is reused / the wave ends
+    wait_vmcnt<0>();                                            // (nothing is in flight any more)
     __builtin_amdgcn_s_barrier();
 #if DMVAE_ABLATE == 6     // tools/stamps.py: when the K loop of this workgroup ended
     if (threadIdx.x == 0 && blockIdx.x < 2048) g_mid[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
+    ANAT(2);
 
     // Epilogue through LDS.  The MFMA result map gives a lane 4 consecutive n of ONE row and its 15
     // neighbours 15 OTHER rows: stored straight from the accumulators a wave instruction touches
@@ -417,6 +430,13 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
         constexpr int CM = BM / 64, CN = BN / 64;
         if (tid < CM * CN) a.epi.partials[(tm * CM + tid / CN) * (a.N / 64) + tn * CN + tid % CN] = tid == 0 ? t : 0.f;
     }
+#if DMVAE_ABLATE == 6
+    ANAT(3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ANAT(4);
+    if (threadIdx.x == 0 && blockIdx.x < 2048)
+        g_anat[blockIdx.x * 8 + 5] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);
+#endif
 }
 
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW>
@@ -451,6 +471,10 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_bf16_conv_kernel(GemmArg
 // CUs, together they keep every CU at two resident workgroups).  Problem i owns the workgroups
 // [start[i], start[i+1]).
 __device__ unsigned long long g_stamps[2048 * 4];   // written by DMVAE_ABLATE == 6 builds only
+void* gemm_bf16_anatomy() {
+    void* p = nullptr;
+    return hipGetSymbolAddress(&p, HIP_SYMBOL(g_anat)) == hipSuccess ? p : nullptr;
+}
 void* gemm_bf16_stamps() {
     void* p = nullptr;
     return hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps)) == hipSuccess ? p : nullptr;
@@ -905,6 +929,89 @@ int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split) 
 #undef CASE
     set_error("dmvae_gemm(bf16): layout %d with epilogue %d is not instantiated", layout, epi);
     return DMVAE_EUNSUPPORTED;
+}
+
+// ---------------------------------------------------------------- XCD-sliced layer chain (probe)
+// A dependent chain of dense layers is row-parallel: row block r of layer l + 1 needs row block r of layer l only.  Kernel
+// boundaries between the layers cost the fill / drain of a grid and, on this chip, an L2 write-back + invalidate (the eight
+// XCDs' L2s are not coherent with one another): every layer starts from cold activations.  Here ONE launch runs the whole
+// chain; the workgroups that share a physical XCD (HW_REG_XCC_ID, read at run time -- never assumed from blockIdx) own one
+// eighth of the rows through every layer, so a layer's output stays in THAT XCD's L2 for the next layer and the only
+// synchronisation is a barrier among the XCD's own workgroups.  Correctness does not depend on placement: membership is
+// measured, data only ever flows between workgroups of one measured XCD, and every wait is bounded (err != 0 instead of a hang).
+constexpr int CHAIN_MAX = 8;
+struct ChainArgs {
+    int nlayer, variant;          // variant 0: L1 invalidate only between layers; 1: agent-scope release / acquire fences (the kernel-boundary semantics)
+    unsigned* sync;               // zeroed by the host before the launch: [0] registrations, [16 + 64 x + 0] members of XCD x, [16 + 64 x + 1 + l] arrivals behind layer l
+    int* err;
+    GemmArgs layer[CHAIN_MAX];
+};
+static_assert(sizeof(ChainArgs) <= 4096, "kernel argument block");
+
+__device__ __forceinline__ bool chain_wait(const unsigned* p, unsigned target, int* err) {
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    *err = 1;
+    return false;
+}
+
+template <int BM, int BN, int NSTAGE, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void chain_probe_kernel(ChainArgs c) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * (BM + BN) * BK];
+    __shared__ int sh[2];
+    const int xcc = (int)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;        // HW_REG_XCC_ID
+    unsigned* xs = c.sync + 16 + 64 * xcc;
+    if (threadIdx.x == 0) {
+        sh[0] = (int)__hip_atomic_fetch_add(xs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(c.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ok = chain_wait(c.sync, gridDim.x, c.err);                    // every workgroup has registered: the XCD head counts are final
+        int nx = ok ? (int)__hip_atomic_load(xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        for (int x = 0; ok && x < 8; ++x)
+            if (__hip_atomic_load(c.sync + 16 + 64 * x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) { *c.err = 2; nx = 0; }     // an XCD without workgroups: its rows would have no owner
+        sh[1] = nx;
+    }
+    __syncthreads();
+    const int rank = sh[0], nx = sh[1];
+    if (nx == 0) return;
+    for (int l = 0; l < c.nlayer; ++l) {
+        const GemmArgs& a = c.layer[l];
+        const int tiles_m = a.M / BM, tiles_ms = tiles_m / 8, tiles_n = a.N / BN;      // (host: a.group_m = tiles_m, M % (8 BM) == 0)
+        for (int t = rank; t < tiles_ms * tiles_n; t += nx) {
+            const int tm = xcc * tiles_ms + t % tiles_ms, tn = t / tiles_ms;
+            gemm_bf16_body<BM, BN, DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_RELU, NSTAGE, NW>(a, tn * tiles_m + tm, 0, -1, smem);
+            __syncthreads();                                                    // the ring is free again
+        }
+        if (l + 1 == c.nlayer) break;
+        // XCD barrier: this workgroup's stores are in the XCD's L2 (vmcnt(0): acknowledged), then arrive / wait, then drop stale L1 lines
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (c.variant == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(xs + 1 + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh[1] = chain_wait(xs + 1 + l, (unsigned)nx, c.err) ? nx : 0;
+        }
+        __syncthreads();
+        if (sh[1] == 0) return;
+        if (c.variant == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        else asm volatile("buffer_inv sc0" ::: "memory");
+    }
+}
+
+int chain_probe_launch(hipStream_t s, int variant, int nlayer, const GemmArgs* layers, unsigned* sync, int* err) {
+    if (nlayer < 1 || nlayer > CHAIN_MAX) { set_error("chain probe: 1..%d layers", CHAIN_MAX); return DMVAE_EINVAL; }
+    ChainArgs c{};
+    c.nlayer = nlayer; c.variant = variant; c.sync = sync; c.err = err;
+    for (int l = 0; l < nlayer; ++l) {
+        c.layer[l] = layers[l];
+        if (layers[l].M % (8 * 128) || layers[l].N % 64 || layers[l].epi.kind != DMVAE_EPI_BIAS_RELU) { set_error("chain probe: M %% 1024, N %% 64, bias + ReLU layers"); return DMVAE_EINVAL; }
+        c.layer[l].group_m = layers[l].M / 128;
+    }
+    hipError_t e = hipMemsetAsync(sync, 0, sizeof(unsigned) * (16 + 64 * 8), s);
+    if (e != hipSuccess) { set_error("chain probe: memset: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL((chain_probe_kernel<128, 64, 3, 8>), dim3(256), dim3(512), 0, s, c);
+    return check_launch("chain_probe");
 }
 
 }  // namespace dmvae

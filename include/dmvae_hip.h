@@ -374,6 +374,15 @@ int dmvae_prof_collect(dmvae_prof_row* rows, int max_rows);   /* returns number 
  * grouped GEMM kernel, 2048 x {start, end (100 MHz ticks), HW_ID<<32 | XCC_ID, layout<<32 | tile kind};
  * the product library never writes it */
 int dmvae_debug_stamps(void** device_ptr);
+/* DMVAE_ABLATE=6 builds: per-workgroup phase stamps of the last small-tile bf16 GEMM launch, 2048 x 8 uint64 (100 MHz ticks):
+ * {entry, first K tile landed, K loop done, epilogue issued, stores acknowledged, HW_ID << 32 | XCC_ID} (tools/anatomy.py) */
+int dmvae_debug_anatomy(void** device_ptr);
+/* probe (tools/chain_probe.py): nlayer (1..8) square bias + ReLU layers [M x N] x [N x N] (bf16, M % 1024 == 0, N % 64 == 0)
+ * as ONE launch in which the workgroups of a physical XCD own one eighth of the rows through every layer; layer l reads
+ * act[l % 2] and writes act[(l + 1) % 2].  variant 0: L1 invalidate between layers, 1: agent-scope fences.  sync: 2112 B of
+ * device scratch (zeroed by the call); *err (device int, zeroed by the caller) != 0 when a bounded wait gave up. */
+int dmvae_debug_chain(void* stream, int variant, int nlayer, int M, int N, void* act0, void* act1,
+                      const void* const* W, const float* const* bias, void* sync, int* err);
 
 /* tuning aid: force the bf16 GEMM tile (64|128 x 64|128); (0,0) restores the heuristic */
 int dmvae_debug_set_tile(int bm, int bn);

@@ -1,0 +1,84 @@
+// Per-CU intake on MI355X by load path (tools/README.md):  hipcc --offload-arch=gfx950 -O3 tools/intake_probe.hip -o deep-mixture-vae_amd/build/intake_probe
+//   mode 0  global_load_lds_dwordx4 (LDS-DMA, what the GEMM rings use)
+//   mode 1  global_load_dwordx4 into VGPRs, discarded
+//   mode 2  global_load_dwordx4 into VGPRs + ds_write_b128 (register-staged ring)
+// Every workgroup streams its own region `reps` times (region small: L2-resident after the first pass; large: from Infinity Cache / HBM).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+template <int MODE, int DEPTH>
+__global__ __launch_bounds__(512) void intake_kernel(const char* base, size_t region, int reps, unsigned long long* ticks, float* sink) {
+    __shared__ __attribute__((aligned(16))) char lds[DEPTH * 8192];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const char* mine = base + (size_t)blockIdx.x * region;
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)lds) + 1024u * wave);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const int chunks = (int)(region / 8192);          // one chunk = 512 threads x 16 B
+    for (int r = 0; r < reps; ++r) {
+        for (int c0 = 0; c0 < chunks; c0 += DEPTH) {
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {
+                    const char* src = mine + (size_t)(c0 + d) * 8192 + wave * 1024;      // wave-uniform
+                    const unsigned off = lane * 16, dst = lds_w + d * 8192;
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "s"(src), "v"(off), "s"(dst) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                float4 v[DEPTH];
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) v[d] = *reinterpret_cast<const float4*>(mine + (size_t)(c0 + d) * 8192 + tid * 16);
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {
+                    if constexpr (MODE == 2) *reinterpret_cast<float4*>(lds + d * 8192 + tid * 16) = v[d];
+                    else { acc.x += v[d].x; acc.y += v[d].y; acc.z += v[d].z; acc.w += v[d].w; }
+                }
+            }
+        }
+    }
+    if constexpr (MODE != 1) { __syncthreads(); acc = *reinterpret_cast<float4*>(lds + tid * 16); }
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) ticks[blockIdx.x] = t1 - t0;
+    if (acc.x == 123.456f) sink[0] = acc.x + acc.y + acc.z + acc.w;
+}
+
+template <int MODE, int DEPTH>
+static void run(const char* name, const char* buf, size_t region, int wgs, int reps, unsigned long long* dticks, float* sink) {
+    std::vector<unsigned long long> h(wgs);
+    for (int it = 0; it < 3; ++it) {
+        hipLaunchKernelGGL((intake_kernel<MODE, DEPTH>), dim3(wgs), dim3(512), 0, 0, buf, region, reps, dticks, sink);
+        CK(hipDeviceSynchronize());
+    }
+    CK(hipMemcpy(h.data(), dticks, sizeof(unsigned long long) * wgs, hipMemcpyDeviceToHost));
+    double worst = 0, sum = 0;
+    for (auto t : h) { worst = t > worst ? (double)t : worst; sum += (double)t; }
+    const double bytes = (double)region * reps;
+    printf("%-34s depth %2d  region %7zu KB x %3d reps, %4d WGs : per-WG %6.1f GB/s (mean)  %6.1f GB/s (slowest)  chip %6.2f TB/s\n", name, DEPTH, region >> 10, reps, wgs,
+           bytes / (sum / wgs * 10e-9) / 1e9, bytes / (worst * 10e-9) / 1e9, bytes * wgs / (worst * 10e-9) / 1e12);
+}
+
+int main() {
+    const size_t total = (size_t)1 << 30;
+    char* buf; unsigned long long* dt; float* sink;
+    CK(hipMalloc(&buf, total)); CK(hipMemset(buf, 1, total)); CK(hipMalloc(&dt, 8 * 4096)); CK(hipMalloc(&sink, 64));
+    for (int wgs : {256, 512}) {
+        for (size_t region : {(size_t)64 << 10, (size_t)2 << 20}) {       // 64 KB per WG: L2-resident; 2 MB per WG: 0.5-1 GB in all, Infinity Cache / HBM
+            const int reps = region == ((size_t)64 << 10) ? 64 : 2;
+            run<0, 2>("LDS-DMA global_load_lds_dwordx4", buf, region, wgs, reps, dt, sink);
+            run<0, 4>("LDS-DMA global_load_lds_dwordx4", buf, region, wgs, reps, dt, sink);
+            run<0, 8>("LDS-DMA global_load_lds_dwordx4", buf, region, wgs, reps, dt, sink);
+            run<1, 4>("global_load_dwordx4 -> VGPR", buf, region, wgs, reps, dt, sink);
+            run<1, 8>("global_load_dwordx4 -> VGPR", buf, region, wgs, reps, dt, sink);
+            run<2, 4>("global_load_dwordx4 -> ds_write", buf, region, wgs, reps, dt, sink);
+            run<2, 8>("global_load_dwordx4 -> ds_write", buf, region, wgs, reps, dt, sink);
+        }
+    }
+    return 0;
+}
