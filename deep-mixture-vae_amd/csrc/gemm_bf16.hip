@@ -266,6 +266,11 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
             target[q] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.epi.aux0) + (int64_t)(m0 + ml) * a.epi.ld0 + n0 + c * 4);
         }
     }
+    // the bias quad of this thread's column block: the same for every row it handles (64 NW is a multiple of BN / 4)
+    constexpr bool HAS_BIAS = (EPI == DMVAE_EPI_BIAS_RELU || EPI == DMVAE_EPI_BIAS_F32 || EPI == DMVAE_EPI_BIAS_SIGMOID || EPI == DMVAE_EPI_BIAS_RECON);
+    static_assert((64 * NW) % (BN / 4) == 0, "a thread keeps its column block across the epilogue's passes");
+    float bq[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (HAS_BIAS) loadf4(a.epi.bias, n0 + (tid % (BN / 4)) * 4, bq);
     uint2 gate[EPI == DMVAE_EPI_RELU_MASK ? NQ : 1];
     if constexpr (EPI == DMVAE_EPI_RELU_MASK) {
 #pragma unroll
@@ -386,9 +391,9 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
             ActIO<bf16_t>::store4(a.epi.out, (int64_t)(m0 + ml) * a.epi.ldo + n0 + c * 4, v);
         } else if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
             const float xq[4] = {target[q].x, target[q].y, target[q].z, target[q].w};
-            epilogue_quad<EPI, bf16_t>(a.epi, m0 + ml, n0 + c * 4, v, loss, xq);
+            epilogue_quad<EPI, bf16_t>(a.epi, m0 + ml, n0 + c * 4, v, loss, xq, nullptr, bq);
         } else {
-            epilogue_quad<EPI, bf16_t>(epi_s, m0 + ml, n0 + c * 4, v, loss);
+            epilogue_quad<EPI, bf16_t>(epi_s, m0 + ml, n0 + c * 4, v, loss, nullptr, nullptr, HAS_BIAS ? bq : nullptr);
         }
     }
 #else

@@ -237,6 +237,9 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& a, const dmvae_adam
     const int li = lane & 15, g = lane >> 4;
     constexpr bool CSUM = (EPI == DMVAE_EPI_RELU_MASK || EPI == DMVAE_EPI_BIAS_RECON);     // the output is a dY: its column sums = a bias gradient
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr bool HAS_BIAS = (EPI == DMVAE_EPI_BIAS_RELU || EPI == DMVAE_EPI_BIAS_F32 || EPI == DMVAE_EPI_BIAS_SIGMOID || EPI == DMVAE_EPI_BIAS_RECON);
+    float bq[4] = {0.f, 0.f, 0.f, 0.f};         // a lane's column quad is the same for every row it handles: the bias once
+    if constexpr (HAS_BIAS) loadf4(a.epi.bias, n0 + wc * 64 + li * 4, bq);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -260,23 +263,36 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& a, const dmvae_adam
                     gv[0] = t4[0]; gv[1] = t4[1]; gv[2] = t4[2]; gv[3] = t4[3];
                 });
             }
-        } else
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int r = it * 4 + g, c = li;
-            const f32x4 t4 = *reinterpret_cast<const f32x4*>(st + r * 64 + ((c ^ (r & 7)) << 2));
-            float v[4] = {t4[0], t4[1], t4[2], t4[3]};
-            const int m = m0 + h * 128 + wr * 64 + r, n = n0 + wc * 64 + c * 4;
-            if constexpr (EPI == DMVAE_EPI_ADAM) {
-                const int64_t off = (reinterpret_cast<const float*>(a.epi.out) - ac.grad) + (int64_t)m * a.epi.ldo + n;
-                adam_quad(ac, off, v);
-            } else if constexpr (CSUM) {
-                float sv[4];
-                epilogue_quad<EPI, bf16_t>(a.epi, m, n, v, loss, nullptr, sv);
+        } else {
+            // batches of EPI_NB rows: the gate / target loads of a batch are issued before its first store (see epilogue_quad)
+            constexpr int EPI_NB = 8;
+#pragma unroll 1
+            for (int it0 = 0; it0 < 16; it0 += EPI_NB) {
+                float pre[EPI_NB][4];
+                if constexpr (EPI == DMVAE_EPI_RELU_MASK || EPI == DMVAE_EPI_BIAS_RECON) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cs[j] += bf2f(f2bf(sv[j]));       // the value the weight-gradient GEMM will read
-            } else {
-                epilogue_quad<EPI, bf16_t>(a.epi, m, n, v, loss);
+                    for (int b = 0; b < EPI_NB; ++b) {
+                        const int64_t o = (int64_t)(m0 + h * 128 + wr * 64 + (it0 + b) * 4 + g) * a.epi.ld0 + n0 + wc * 64 + li * 4;
+                        if constexpr (EPI == DMVAE_EPI_RELU_MASK) ActIO<bf16_t>::load4(a.epi.aux0, o, pre[b]);
+                        else loadf4(a.epi.aux0, o, pre[b]);
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < EPI_NB; ++b) {
+                    const int r = (it0 + b) * 4 + g, c = li;
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(st + r * 64 + ((c ^ (r & 7)) << 2));
+                    float v[4] = {t4[0], t4[1], t4[2], t4[3]};
+                    const int m = m0 + h * 128 + wr * 64 + r, n = n0 + wc * 64 + c * 4;
+                    if constexpr (CSUM) {
+                        float sv[4];
+                        epilogue_quad<EPI, bf16_t>(a.epi, m, n, v, loss, EPI == DMVAE_EPI_BIAS_RECON ? pre[b] : nullptr, sv, HAS_BIAS ? bq : nullptr,
+                                                   EPI == DMVAE_EPI_RELU_MASK ? pre[b] : nullptr);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) cs[j] += bf2f(f2bf(sv[j]));       // the value the weight-gradient GEMM will read
+                    } else {
+                        epilogue_quad<EPI, bf16_t>(a.epi, m, n, v, loss, nullptr, nullptr, HAS_BIAS ? bq : nullptr);
+                    }
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next block overwrites

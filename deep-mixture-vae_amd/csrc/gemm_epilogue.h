@@ -95,28 +95,35 @@ __device__ __forceinline__ void xent_sigmoid(float l, float x, float& xent, floa
 // xpre: RECON only, the target quad x[m][n..n+3] when the caller fetched it ahead of time.
 // stored: optional, receives the four values as they were stored in the ACT output (RELU_MASK, BIAS_RECON: the gradient quad)
 template <int EPI, typename ACT>
-__device__ __forceinline__ void epilogue_quad(const dmvae_epilogue& e, int m, int n, float v[4], float& loss, const float* xpre = nullptr, float* stored = nullptr) {
+// bpre / ypre: the bias quad / the forward-activation (ReLU gate) quad already in registers.  Loaded inside, every call sits
+// behind the previous call's stores (the compiler cannot tell the arrays apart): one memory round trip per quad.
+__device__ __forceinline__ void epilogue_quad(const dmvae_epilogue& e, int m, int n, float v[4], float& loss, const float* xpre = nullptr, float* stored = nullptr,
+                                              const float* bpre = nullptr, const float* ypre = nullptr) {
     if constexpr (EPI == DMVAE_EPI_BIAS_RELU) {
         float b[4];
-        loadf4(e.bias, n, b);
+        if (bpre) { b[0] = bpre[0]; b[1] = bpre[1]; b[2] = bpre[2]; b[3] = bpre[3]; }
+        else loadf4(e.bias, n, b);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j] + b[j], 0.f);
         ActIO<ACT>::store4(e.out, (int64_t)m * e.ldo + n, v);
     } else if constexpr (EPI == DMVAE_EPI_BIAS_F32) {
         float b[4];
-        loadf4(e.bias, n, b);
+        if (bpre) { b[0] = bpre[0]; b[1] = bpre[1]; b[2] = bpre[2]; b[3] = bpre[3]; }
+        else loadf4(e.bias, n, b);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += b[j];
         ActIO<float>::store4(e.out, (int64_t)m * e.ldo + n, v);
     } else if constexpr (EPI == DMVAE_EPI_BIAS_SIGMOID) {
         float b[4];
-        loadf4(e.bias, n, b);
+        if (bpre) { b[0] = bpre[0]; b[1] = bpre[1]; b[2] = bpre[2]; b[3] = bpre[3]; }
+        else loadf4(e.bias, n, b);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = sigmoidf_(v[j] + b[j]);
         ActIO<float>::store4(e.out, (int64_t)m * e.ldo + n, v);
     } else if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
         float b[4], x[4], d[4];
-        loadf4(e.bias, n, b);
+        if (bpre) { b[0] = bpre[0]; b[1] = bpre[1]; b[2] = bpre[2]; b[3] = bpre[3]; }
+        else loadf4(e.bias, n, b);
         if (xpre) { x[0] = xpre[0]; x[1] = xpre[1]; x[2] = xpre[2]; x[3] = xpre[3]; }
         else loadf4(e.aux0, (int64_t)m * e.ld0 + n, x);
         const bool rowok = m < e.m_valid;
@@ -141,7 +148,8 @@ __device__ __forceinline__ void epilogue_quad(const dmvae_epilogue& e, int m, in
         if (e.out2) ActIO<float>::store4(e.out2, (int64_t)m * e.ldo2 + n, v);
     } else if constexpr (EPI == DMVAE_EPI_RELU_MASK) {
         float y[4];
-        ActIO<ACT>::load4(e.aux0, (int64_t)m * e.ld0 + n, y);
+        if (ypre) { y[0] = ypre[0]; y[1] = ypre[1]; y[2] = ypre[2]; y[3] = ypre[3]; }
+        else ActIO<ACT>::load4(e.aux0, (int64_t)m * e.ld0 + n, y);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = y[j] > 0.f ? v[j] : 0.f;
         ActIO<ACT>::store4(e.out, (int64_t)m * e.ldo + n, v);

@@ -11,6 +11,8 @@ torch.cuda.set_device(0)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 shapes = [(4096, 512, 512, 0), (4096, 512, 832, 0), (4096, 4096, 512, 0), (4096, 512, 512, 1), (4096, 512, 2048, 1), (4096, 64, 2048, 1)]
 if len(sys.argv) == 5: shapes = [tuple(int(v) for v in sys.argv[1:5])]
+for kv in os.environ.get("DMVAE_KNOBS", "").split(","):          # e.g. DMVAE_KNOBS=3=1,1=0
+    if kv: L.check(L.lib.dmvae_debug_set_knob(int(kv.split("=")[0]), int(kv.split("=")[1])))
 p = C.c_void_p(); L.check(L.lib.dmvae_debug_anatomy(C.byref(p)))
 hip = C.cdll.LoadLibrary("libamdhip64.so")
 for M, N, K, lay in shapes:
@@ -20,7 +22,7 @@ for M, N, K, lay in shapes:
     bias = torch.zeros(N, device="cuda"); junk = torch.empty(64 << 20, device="cuda")
     e = L.Epilogue(); e.kind = L.EPI_BIAS_RELU if lay == 0 else L.EPI_RELU_MASK
     e.out, e.ldo, e.bias, e.aux0, e.ld0 = out.data_ptr(), N, bias.data_ptr(), Y.data_ptr(), N
-    for mode in ("hot", "cold"):
+    for mode in ("hot",):
         for _ in range(3):
             if mode == "cold": junk.fill_(1.0)          # evict L2 / Infinity Cache between launches
             t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)

@@ -2,6 +2,8 @@
 //   mode 0  global_load_lds_dwordx4 (LDS-DMA, what the GEMM rings use)
 //   mode 1  global_load_dwordx4 into VGPRs, discarded
 //   mode 2  global_load_dwordx4 into VGPRs + ds_write_b128 (register-staged ring)
+//   mode 3  LDS-DMA with the GEMM's k-contiguous tile pattern: a wave instruction = 8 rows x 128 B, row stride `stride` bytes; a
+//           workgroup's chunk = 64 rows x 128 B, successive chunks advance 128 B along the rows (the K loop), `region` = 64 rows x stride
 // Every workgroup streams its own region `reps` times (region small: L2-resident after the first pass; large: from Infinity Cache / HBM).
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -10,18 +12,30 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-template <int MODE, int DEPTH>
-__global__ __launch_bounds__(512) void intake_kernel(const char* base, size_t region, int reps, unsigned long long* ticks, float* sink) {
+template <int MODE, int DEPTH, int SEG = 128>
+__global__ __launch_bounds__(512) void intake_kernel(const char* base, size_t region, int reps, unsigned long long* ticks, float* sink, unsigned stride = 0, unsigned seg = 128) {      // MODE 0: stride = G > 0 -> workgroups b and b + G read the SAME region (panel sharing)
     __shared__ __attribute__((aligned(16))) char lds[DEPTH * 8192];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const char* mine = base + (size_t)blockIdx.x * region;
+    const char* mine = base + (size_t)((MODE == 0 && stride) ? blockIdx.x % stride : blockIdx.x) * region;
     const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)lds) + 1024u * wave);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     const int chunks = (int)(region / 8192);          // one chunk = 512 threads x 16 B
     for (int r = 0; r < reps; ++r) {
         for (int c0 = 0; c0 < chunks; c0 += DEPTH) {
-            if constexpr (MODE == 0) {
+            if constexpr (MODE == 3) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {
+                    constexpr unsigned STRIDE = 1024, lps = SEG / 16, rpi = 1024 / SEG;      // lanes per segment, rows per instruction
+                    const int c = c0 + d, kt = c % (int)(STRIDE / SEG), rb = c / (int)(STRIDE / SEG);      // chunk c = row block rb (8 waves x rpi rows), k tile kt
+                    const char* src = mine + (size_t)kt * SEG + ((size_t)rb * 8 + wave) * rpi * STRIDE;      // wave-uniform
+                    const unsigned off = (unsigned)(lane / lps) * STRIDE + (unsigned)(lane % lps) * 16, dst = lds_w + d * 8192;
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "s"(src), "v"(off), "s"(dst) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if constexpr (MODE == 0) {
 #pragma unroll
                 for (int d = 0; d < DEPTH; ++d) {
                     const char* src = mine + (size_t)(c0 + d) * 8192 + wave * 1024;      // wave-uniform
@@ -49,11 +63,11 @@ __global__ __launch_bounds__(512) void intake_kernel(const char* base, size_t re
     if (acc.x == 123.456f) sink[0] = acc.x + acc.y + acc.z + acc.w;
 }
 
-template <int MODE, int DEPTH>
-static void run(const char* name, const char* buf, size_t region, int wgs, int reps, unsigned long long* dticks, float* sink) {
+template <int MODE, int DEPTH, int SEG = 128>
+static void run(const char* name, const char* buf, size_t region, int wgs, int reps, unsigned long long* dticks, float* sink, unsigned stride = 0, unsigned seg = 128) {
     std::vector<unsigned long long> h(wgs);
     for (int it = 0; it < 3; ++it) {
-        hipLaunchKernelGGL((intake_kernel<MODE, DEPTH>), dim3(wgs), dim3(512), 0, 0, buf, region, reps, dticks, sink);
+        hipLaunchKernelGGL((intake_kernel<MODE, DEPTH, SEG>), dim3(wgs), dim3(512), 0, 0, buf, region, reps, dticks, sink, stride, seg);
         CK(hipDeviceSynchronize());
     }
     CK(hipMemcpy(h.data(), dticks, sizeof(unsigned long long) * wgs, hipMemcpyDeviceToHost));
@@ -79,6 +93,28 @@ int main() {
             run<2, 4>("global_load_dwordx4 -> ds_write", buf, region, wgs, reps, dt, sink);
             run<2, 8>("global_load_dwordx4 -> ds_write", buf, region, wgs, reps, dt, sink);
         }
+    }
+    // the GEMM's tile pattern: 64 rows x (stride / 128) K tiles per workgroup = stride * 64 bytes, re-read `reps` times (L2-resident)
+    // one pass over data that sits in the Infinity Cache but not in L2 (a launch boundary invalidates the L2s): what a GEMM's first touch sees
+    for (size_t kb : {64, 128, 256, 512}) {
+        run<0, 4>("LDS-DMA, ONE pass, Infinity-Cache", buf, kb << 10, 256, 1, dt, sink);
+        run<0, 8>("LDS-DMA, ONE pass, Infinity-Cache", buf, kb << 10, 256, 1, dt, sink);
+    }
+    for (unsigned G : {256u, 64u, 32u, 8u}) {        // 256 / G workgroups (round-robin: b and b + G, G % 8 == 0 -> the same XCD) stream the same 64 KB in lockstep
+        char nm[64]; snprintf(nm, sizeof nm, "LDS-DMA, %u WGs share a region", 256 / G);
+        run<0, 4>(nm, buf, (size_t)64 << 10, 256, 64, dt, sink, G);
+    }
+    {
+        const size_t region = (size_t)64 << 10;      // 64 rows x 1 KB: the same 64 KB (L2-resident, larger than L1) for every instruction shape
+        const int reps = 64;
+        run<3, 4, 128>("LDS-DMA 8 rows x 128 B per instr", buf, region, 256, reps, dt, sink);
+        run<3, 8, 128>("LDS-DMA 8 rows x 128 B per instr", buf, region, 256, reps, dt, sink);
+        run<3, 4, 256>("LDS-DMA 4 rows x 256 B per instr", buf, region, 256, reps, dt, sink);
+        run<3, 8, 256>("LDS-DMA 4 rows x 256 B per instr", buf, region, 256, reps, dt, sink);
+        run<3, 4, 512>("LDS-DMA 2 rows x 512 B per instr", buf, region, 256, reps, dt, sink);
+        run<3, 8, 512>("LDS-DMA 2 rows x 512 B per instr", buf, region, 256, reps, dt, sink);
+        run<3, 4, 1024>("LDS-DMA 1 row x 1 KB per instr", buf, region, 256, reps, dt, sink);
+        run<3, 8, 1024>("LDS-DMA 1 row x 1 KB per instr", buf, region, 256, reps, dt, sink);
     }
     return 0;
 }
