@@ -266,6 +266,18 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
             target[q] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.epi.aux0) + (int64_t)(m0 + ml) * a.epi.ld0 + n0 + c * 4);
         }
     }
+    constexpr bool LAT_PRE = EPI == DMVAE_EPI_LATENT && NQ <= 4;       // (12 registers per quad: the small tiles only)
+    float lat[LAT_PRE ? NQ : 1][12];            // LATENT (the dZ GEMM): the reparameterisation / KL gradient quads, likewise
+    if constexpr (LAT_PRE) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = q * (64 * NW) + tid;
+            const int ml = idx / (BN / 4), c = idx % (BN / 4);
+            loadf4(a.epi.aux0, (int64_t)(m0 + ml) * a.epi.ld0 + n0 + c * 4, lat[q]);
+            loadf4(a.epi.aux1, (int64_t)(m0 + ml) * a.epi.ld1 + n0 + c * 4, lat[q] + 4);
+            loadf4(a.epi.aux2, (int64_t)(m0 + ml) * a.epi.ld2 + n0 + c * 4, lat[q] + 8);
+        }
+    }
     // the bias quad of this thread's column block: the same for every row it handles (64 NW is a multiple of BN / 4)
     constexpr bool HAS_BIAS = (EPI == DMVAE_EPI_BIAS_RELU || EPI == DMVAE_EPI_BIAS_F32 || EPI == DMVAE_EPI_BIAS_SIGMOID || EPI == DMVAE_EPI_BIAS_RECON);
     static_assert((64 * NW) % (BN / 4) == 0, "a thread keeps its column block across the epilogue's passes");
@@ -392,6 +404,8 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
         } else if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
             const float xq[4] = {target[q].x, target[q].y, target[q].z, target[q].w};
             epilogue_quad<EPI, bf16_t>(a.epi, m0 + ml, n0 + c * 4, v, loss, xq, nullptr, bq);
+        } else if constexpr (LAT_PRE) {
+            epilogue_quad<EPI, bf16_t>(a.epi, m0 + ml, n0 + c * 4, v, loss, lat[q]);
         } else {
             epilogue_quad<EPI, bf16_t>(epi_s, m0 + ml, n0 + c * 4, v, loss, nullptr, nullptr, HAS_BIAS ? bq : nullptr);
         }

@@ -48,7 +48,7 @@ namespace dmvae {
 
 constexpr int HALF_ELEMS = 128 * BK;     // one half-tile: 128 rows (or columns) x 64 k of bf16 = 16 KiB
 constexpr int LOOKAHEAD = 6;             // half-tiles issued ahead of the phase that consumes them
-constexpr int ADAM_NB = 8;               // quads per thread whose parameter / m / v loads are in flight together in the dW + Adam epilogue
+constexpr int ADAM_NB = 4;               // quads per batch of the dW + Adam epilogue; two batches of parameter / m / v loads in flight (adam_pipelined)
 template <int V> using IC = std::integral_constant<int, V>;
 
 // Bias gradient of a dW problem: db[n] = sum_k dY[k][n].  The smaller tiles get it from a ones-operand MFMA in the
@@ -252,17 +252,13 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& a, const dmvae_adam
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave, in-order LDS: the block is written
         if constexpr (EPI == DMVAE_EPI_ADAM) {                  // batches of ADAM_NB quads: loads of a batch in flight together (adam_quads)
             const unsigned base = (unsigned)((reinterpret_cast<const float*>(a.epi.out) - ac.grad) + (int64_t)(m0 + h * 128 + wr * 64) * a.epi.ldo + n0 + wc * 64 + li * 4);
-#pragma unroll 1
-            for (int it0 = 0; it0 < 16; it0 += ADAM_NB) {
-                unsigned off[ADAM_NB];
-#pragma unroll
-                for (int b = 0; b < ADAM_NB; ++b) off[b] = base + (unsigned)((it0 + b) * 4 + g) * (unsigned)a.epi.ldo;
-                adam_quads<ADAM_NB>(ac, off, [&](int b, float (&gv)[4]) {
-                    const int r = (it0 + b) * 4 + g;
+            adam_pipelined<ADAM_NB, 16 / ADAM_NB>(ac,
+                [&](int i, int b) { return base + (unsigned)((i * ADAM_NB + b) * 4 + g) * (unsigned)a.epi.ldo; },
+                [&](int i, int b, float (&gv)[4]) {
+                    const int r = (i * ADAM_NB + b) * 4 + g;
                     const f32x4 t4 = *reinterpret_cast<const f32x4*>(st + r * 64 + ((li ^ (r & 7)) << 2));
                     gv[0] = t4[0]; gv[1] = t4[1]; gv[2] = t4[2]; gv[3] = t4[3];
                 });
-            }
         } else {
             // batches of EPI_NB rows: the gate / target loads of a batch are issued before its first store (see epilogue_quad)
             constexpr int EPI_NB = 8;

@@ -156,9 +156,14 @@ __device__ __forceinline__ void epilogue_quad(const dmvae_epilogue& e, int m, in
         if (stored) { stored[0] = v[0]; stored[1] = v[1]; stored[2] = v[2]; stored[3] = v[3]; }
     } else if constexpr (EPI == DMVAE_EPI_LATENT) {
         float gm[4], gl[4], cl[4], o0[4], o1[4];
-        loadf4(e.aux0, (int64_t)m * e.ld0 + n, gm);
-        loadf4(e.aux1, (int64_t)m * e.ld1 + n, gl);
-        loadf4(e.aux2, (int64_t)m * e.ld2 + n, cl);
+        if (xpre) {       // xpre[12]: the three quads already in registers
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { gm[j] = xpre[j]; gl[j] = xpre[4 + j]; cl[j] = xpre[8 + j]; }
+        } else {
+            loadf4(e.aux0, (int64_t)m * e.ld0 + n, gm);
+            loadf4(e.aux1, (int64_t)m * e.ld1 + n, gl);
+            loadf4(e.aux2, (int64_t)m * e.ld2 + n, cl);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             o0[j] = v[j] + gm[j];

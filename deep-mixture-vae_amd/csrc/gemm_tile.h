@@ -191,6 +191,50 @@ __device__ __forceinline__ void adam_quads(const dmvae_adam_ctx& c, const unsign
     }
 }
 
+// The same over NBATCH batches, software-pipelined: the loads of batch i + 1 are issued BEFORE the stores of batch i.  vmcnt counts
+// loads and stores in issue order, so a load that follows stores is only seen once those stores are acknowledged; issued ahead of
+// them, the next batch's parameters arrive while this batch is computed and written.
+template <int NB, int NBATCH, class OFF, class G>
+__device__ __forceinline__ void adam_pipelined(const dmvae_adam_ctx& c, OFF&& off_of, G&& grad_of) {      // off_of(i, b) -> element offset; grad_of(i, b, g[4])
+    const dmvae_state* st = reinterpret_cast<const dmvae_state*>(c.state);
+    const float lr_t = st->lr_t;
+    float4 p[2][NB], m[2][NB], v[2][NB];
+    auto load = [&](int i, int buf) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const unsigned o = off_of(i, b);
+            p[buf][b] = *reinterpret_cast<const float4*>(c.param + o);
+            m[buf][b] = *reinterpret_cast<const float4*>(c.m + o);
+            v[buf][b] = *reinterpret_cast<const float4*>(c.v + o);
+        }
+    };
+    load(0, 0);
+#pragma unroll
+    for (int i = 0; i < NBATCH; ++i) {
+        const int buf = i & 1;
+        if (i + 1 < NBATCH) load(i + 1, buf ^ 1);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const unsigned o = off_of(i, b);
+            float g[4];
+            grad_of(i, b, g);
+            float* pp = &p[buf][b].x; float* mp = &m[buf][b].x; float* vp = &v[buf][b].x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) adam_elem(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);
+            *reinterpret_cast<float4*>(c.param + o) = p[buf][b];
+            *reinterpret_cast<float4*>(c.m + o) = m[buf][b];
+            *reinterpret_cast<float4*>(c.v + o) = v[buf][b];
+            if (c.param_bf16) {
+                uint2 q;
+                q.x = pack2bf(p[buf][b].x, p[buf][b].y);
+                q.y = pack2bf(p[buf][b].z, p[buf][b].w);
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(c.param_bf16) + o) = q;
+            }
+            if (c.store_grad) *reinterpret_cast<float4*>(c.grad + o) = make_float4(g[0], g[1], g[2], g[3]);
+        }
+    }
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // XCD-aware order (speed only, never correctness): workgroups are dealt round-robin over the 8
