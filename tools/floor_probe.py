@@ -10,9 +10,12 @@ torch.cuda.set_device(0)
 s = torch.cuda.Stream()
 st = C.c_void_p(s.cuda_stream)
 M = 4096
+if os.environ.get("FLOOR_TILE"):            # e.g. FLOOR_TILE=64,64: force the tile shape (dmvae_debug_set_tile)
+    bm, bn = (int(v) for v in os.environ["FLOOR_TILE"].split(","))
+    L.check(L.lib.dmvae_debug_set_tile(bm, bn))
 for lay, name, epi in ((0, "fwd bias+relu", L.EPI_BIAS_RELU), (1, "dX relu-gate", L.EPI_RELU_MASK)):
     for N in (512, 2048):
-        for K in (64, 256, 512, 1024, 2048):
+        for K in ((64, 2048) if os.environ.get("FLOOR_SHORT") else (64, 256, 512, 1024, 2048)):
             A = torch.relu(torch.randn(M, K, device="cuda")).bfloat16()
             B = (0.02 * torch.randn(K, N, device="cuda") if lay == 0 else 0.02 * torch.randn(N, K, device="cuda")).bfloat16()
             out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16); Y = torch.ones(M, N, device="cuda", dtype=torch.bfloat16)

@@ -78,6 +78,58 @@ static void run(const char* name, const char* buf, size_t region, int wgs, int r
            bytes / (sum / wgs * 10e-9) / 1e9, bytes / (worst * 10e-9) / 1e9, bytes * wgs / (worst * 10e-9) / 1e12);
 }
 
+// mode 4: the GEMM K loop's skeleton without the arithmetic: a ring of NST stages of IPW x 8 KB per workgroup; per iteration every wave
+// issues its IPW instructions of the next stage, waits until its share of the oldest stage has landed (counted vmcnt), s_barrier.
+template <int NST, int IPW, bool BARRIER>
+__global__ __launch_bounds__(512) void ring_kernel(const char* base, size_t region, int iters, unsigned long long* ticks, float* sink) {
+    __shared__ __attribute__((aligned(16))) char lds[NST * IPW * 8192];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const char* mine = base + (size_t)blockIdx.x * region;
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)lds) + 1024u * wave);
+    const int nchunk = (int)(region / (IPW * 8192));
+    auto issue = [&](int it, int slot) {
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const char* src = mine + (size_t)(it % nchunk) * (IPW * 8192) + i * 8192 + wave * 1024;
+            const unsigned off = lane * 16, dst = lds_w + (slot * IPW + i) * 8192;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(src), "v"(off), "s"(dst) : "memory");
+        }
+    };
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+    for (int s = 0; s < NST; ++s) issue(s, s);
+    for (int it = 0; it < iters; it += NST) {
+#pragma unroll
+        for (int s = 0; s < NST; ++s) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW * (NST - 1)) : "memory");       // stage it + s has landed (this wave's share)
+            if (BARRIER) __builtin_amdgcn_s_barrier();
+            issue(it + s + NST, s);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) ticks[blockIdx.x] = t1 - t0;
+    if (*reinterpret_cast<float*>(lds + tid * 16) == 123.456f) sink[0] = 1.f;
+}
+
+template <int NST, int IPW, bool BARRIER>
+static void run_ring(const char* buf, size_t region, int wgs, int iters, unsigned long long* dticks, float* sink) {
+    std::vector<unsigned long long> h(wgs);
+    for (int it = 0; it < 3; ++it) {
+        hipLaunchKernelGGL((ring_kernel<NST, IPW, BARRIER>), dim3(wgs), dim3(512), 0, 0, buf, region, iters, dticks, sink);
+        CK(hipDeviceSynchronize());
+    }
+    CK(hipMemcpy(h.data(), dticks, sizeof(unsigned long long) * wgs, hipMemcpyDeviceToHost));
+    double worst = 0, sum = 0;
+    for (auto t : h) { worst = t > worst ? (double)t : worst; sum += (double)t; }
+    const double bytes = (double)(iters + NST) * IPW * 8192;
+    printf("ring: %d stages x %2d KB, %s, %4d WGs, region %4zu KB : per-WG %6.1f GB/s (mean)  %6.1f (slowest)  %.3f us per stage\n", NST, IPW * 8, BARRIER ? "barrier" : "no barrier", wgs,
+           region >> 10, bytes / (sum / wgs * 10e-9) / 1e9, bytes / (worst * 10e-9) / 1e9, sum / wgs / 100.0 / (iters + NST));
+}
+
 int main() {
     const size_t total = (size_t)1 << 30;
     char* buf; unsigned long long* dt; float* sink;
@@ -95,6 +147,15 @@ int main() {
         }
     }
     // the GEMM's tile pattern: 64 rows x (stride / 128) K tiles per workgroup = stride * 64 bytes, re-read `reps` times (L2-resident)
+    for (size_t kb : {64, 1024}) {       // 64 KB per WG: L2-resident; 1 MB per WG (256 MB): Infinity Cache / HBM
+        const size_t region = kb << 10; const int iters = 1200;
+        run_ring<3, 3, true>(buf, region, 256, iters, dt, sink);
+        run_ring<3, 3, false>(buf, region, 256, iters, dt, sink);
+        run_ring<6, 3, true>(buf, region, 256, iters, dt, sink);
+        run_ring<2, 4, true>(buf, region, 256, iters, dt, sink);
+        run_ring<3, 6, true>(buf, region, 256, iters, dt, sink);
+        run_ring<3, 2, true>(buf, region, 256, iters, dt, sink);
+    }
     // one pass over data that sits in the Infinity Cache but not in L2 (a launch boundary invalidates the L2s): what a GEMM's first touch sees
     for (size_t kb : {64, 128, 256, 512}) {
         run<0, 4>("LDS-DMA, ONE pass, Infinity-Cache", buf, kb << 10, 256, 1, dt, sink);
