@@ -1096,6 +1096,11 @@ extern "C" int dmvae_debug_anatomy(void** device_ptr) {
     *device_ptr = gemm_bf16_anatomy();
     return *device_ptr ? 0 : DMVAE_ESTATE;
 }
+extern "C" int dmvae_debug_anatomy256(void** device_ptr) {
+    if (!device_ptr) return DMVAE_EINVAL;
+    *device_ptr = gemm_bf16_256_anatomy();
+    return *device_ptr ? 0 : DMVAE_ESTATE;
+}
 
 extern "C" int dmvae_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

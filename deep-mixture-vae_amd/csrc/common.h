@@ -32,6 +32,11 @@ __device__ __forceinline__ float adam_lr_t(float lr, float b1, float b2, uint64_
     const double b1t = pow((double)b1, (double)t), b2t = pow((double)b2, (double)t);
     return (float)((double)lr * sqrt(1.0 - b2t) / (1.0 - b1t));
 }
+// FAST (the bf16 throughput mode: fused dW epilogues and the stand-alone kernel whenever a bf16 shadow is written): the update
+// quotient lr_t m / (sqrt(v) + eps) with the hardware square root and reciprocal (v_sqrt_f32, v_rcp_f32: 1 ulp each) instead
+// of the IEEE sequences (~25 of the ~35 instructions per element; the fused epilogue of a 256x256 tile was ALU-bound on them).
+// The fp32 parity mode keeps IEEE sqrt and division.  Both forms of one mode share this function: same bits.
+template <bool FAST = false>
 __device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, float gscale, float b1, float b2, float eps, float lr_t) {
     // plain operators under contract(off): HIP's __fmul_rn / __fadd_rn are header functions whose * and +
     // still carry the contract flag, so each caller fused them differently (1-ulp differences in m)
@@ -41,8 +46,14 @@ __device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g,
     m = m1 + m2;
     const float v1 = b2 * v, v2 = ((1.f - b2) * gj) * gj;
     v = v1 + v2;
-    const float num = lr_t * m, den = sqrtf(v) + eps;
-    p = p - num / den;
+    if constexpr (FAST) {
+        const float num = lr_t * m, den = __builtin_amdgcn_sqrtf(v) + eps;
+        const float quo = num * __builtin_amdgcn_rcpf(den);
+        p = p - quo;
+    } else {
+        const float num = lr_t * m, den = sqrtf(v) + eps;
+        p = p - num / den;
+    }
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global

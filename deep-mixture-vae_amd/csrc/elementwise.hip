@@ -25,8 +25,13 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(AdamArgs a) {
         float4 m = reinterpret_cast<float4*>(a.m)[i];
         float4 v = reinterpret_cast<float4*>(a.v)[i];
         float* pp = &p.x; float* gp = &g.x; float* mp = &m.x; float* vp = &v.x;
+        if (a.pb) {           // bf16 mode: the same arithmetic as the fused dW epilogues (adam_elem<true>)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) adam_elem(pp[j], mp[j], vp[j], gp[j], a.gscale, a.b1, a.b2, a.eps, lr_t);
+            for (int j = 0; j < 4; ++j) adam_elem<true>(pp[j], mp[j], vp[j], gp[j], a.gscale, a.b1, a.b2, a.eps, lr_t);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) adam_elem<false>(pp[j], mp[j], vp[j], gp[j], a.gscale, a.b1, a.b2, a.eps, lr_t);
+        }
         reinterpret_cast<float4*>(a.p)[i] = p;
         reinterpret_cast<float4*>(a.m)[i] = m;
         reinterpret_cast<float4*>(a.v)[i] = v;

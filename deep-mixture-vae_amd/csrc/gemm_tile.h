@@ -141,7 +141,10 @@ __device__ __forceinline__ void adam_quad(const dmvae_adam_ctx& c, int64_t off, 
     float4 v = *reinterpret_cast<const float4*>(c.v + off);
     float* pp = &p.x; float* mp = &m.x; float* vp = &v.x;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) adam_elem(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);
+    for (int j = 0; j < 4; ++j) {
+        if (c.param_bf16) adam_elem<true>(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);       // (wave-uniform: the arithmetic follows the mode, see adam_elem)
+        else adam_elem<false>(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);
+    }
     *reinterpret_cast<float4*>(c.param + off) = p;
     *reinterpret_cast<float4*>(c.m + off) = m;
     *reinterpret_cast<float4*>(c.v + off) = v;
@@ -177,7 +180,10 @@ __device__ __forceinline__ void adam_quads(const dmvae_adam_ctx& c, const unsign
         grad_of(b, g);
         float* pp = &p[b].x; float* mp = &m[b].x; float* vp = &v[b].x;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) adam_elem(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);
+        for (int j = 0; j < 4; ++j) {
+            if (c.param_bf16) adam_elem<true>(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);       // (wave-uniform: the arithmetic follows the mode, see adam_elem)
+            else adam_elem<false>(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);
+        }
         *reinterpret_cast<float4*>(c.param + off[b]) = p[b];
         *reinterpret_cast<float4*>(c.m + off[b]) = m[b];
         *reinterpret_cast<float4*>(c.v + off[b]) = v[b];
@@ -220,7 +226,10 @@ __device__ __forceinline__ void adam_pipelined(const dmvae_adam_ctx& c, OFF&& of
             grad_of(i, b, g);
             float* pp = &p[buf][b].x; float* mp = &m[buf][b].x; float* vp = &v[buf][b].x;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) adam_elem(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);
+            for (int j = 0; j < 4; ++j) {
+                if (c.param_bf16) adam_elem<true>(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);       // (wave-uniform: the arithmetic follows the mode, see adam_elem)
+                else adam_elem<false>(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);
+            }
             *reinterpret_cast<float4*>(c.param + o) = p[buf][b];
             *reinterpret_cast<float4*>(c.m + o) = m[buf][b];
             *reinterpret_cast<float4*>(c.v + o) = v[buf][b];

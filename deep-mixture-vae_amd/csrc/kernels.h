@@ -61,6 +61,7 @@ int cast_launch(hipStream_t s, const void* in, void* out, int64_t n, int to_bf16
 int spin_launch(hipStream_t s, int us);
 void* gemm_bf16_stamps();
 void* gemm_bf16_anatomy();
+void* gemm_bf16_256_anatomy();
 int chain_probe_launch(hipStream_t s, int variant, int nlayer, const GemmArgs* layers, unsigned* sync, int* err);
 // CNN trunk (conv.hip)
 int conv_first_fwd_launch(hipStream_t s, int dtype, const void* x, int64_t bstride, int H, int64_t n_img, const void* W, int ldw,

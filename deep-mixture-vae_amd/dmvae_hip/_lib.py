@@ -34,7 +34,7 @@ EXPORTS = [
     "dmvae_plan_create", "dmvae_plan_destroy", "dmvae_plan_sizes", "dmvae_plan_tensor",
     "dmvae_plan_bind", "dmvae_plan_load_batch", "dmvae_plan_forward_backward",
     "dmvae_plan_update", "dmvae_plan_encode", "dmvae_plan_decode", "dmvae_plan_view",
-    "dmvae_prof_enable", "dmvae_prof_collect", "dmvae_debug_spin", "dmvae_debug_stamps", "dmvae_debug_anatomy", "dmvae_debug_chain", "dmvae_debug_set_tile", "dmvae_debug_set_knob", "dmvae_abi_version", "dmvae_last_error",
+    "dmvae_prof_enable", "dmvae_prof_collect", "dmvae_debug_spin", "dmvae_debug_stamps", "dmvae_debug_anatomy", "dmvae_debug_anatomy256", "dmvae_debug_chain", "dmvae_debug_set_tile", "dmvae_debug_set_knob", "dmvae_abi_version", "dmvae_last_error",
 ]
 
 
@@ -179,6 +179,7 @@ def _load():
         "dmvae_debug_spin": [vp, i32],
         "dmvae_debug_stamps": [P(vp)],
         "dmvae_debug_anatomy": [P(vp)],
+        "dmvae_debug_anatomy256": [P(vp)],
         "dmvae_debug_chain": [vp, i32, i32, i32, i32, vp, vp, P(vp), P(vp), vp, vp],
         "dmvae_prof_collect": [P(ProfRow), i32],
         "dmvae_debug_set_tile": [i32, i32],

@@ -377,6 +377,8 @@ int dmvae_debug_stamps(void** device_ptr);
 /* DMVAE_ABLATE=6 builds: per-workgroup phase stamps of the last small-tile bf16 GEMM launch, 2048 x 8 uint64 (100 MHz ticks):
  * {entry, first K tile landed, K loop done, epilogue issued, stores acknowledged, HW_ID << 32 | XCC_ID} (tools/anatomy.py) */
 int dmvae_debug_anatomy(void** device_ptr);
+/* likewise for the last 256x256 macro-tile launch: 4096 x 4 uint64 {entry, K loop done, epilogue done, HW_ID << 32 | XCC_ID} (tools/anatomy256.py) */
+int dmvae_debug_anatomy256(void** device_ptr);
 /* probe (tools/chain_probe.py): nlayer (1..8) square bias + ReLU layers [M x N] x [N x N] (bf16, M % 1024 == 0, N % 64 == 0)
  * as ONE launch in which the workgroups of a physical XCD own one eighth of the rows through every layer; layer l reads
  * act[l % 2] and writes act[(l + 1) % 2].  variant 0: L1 invalidate between layers, 1: agent-scope fences.  sync: 2112 B of
