@@ -215,6 +215,10 @@ int dmvae_loss_finalize(void* stream, const float* recon_partials, int n_recon,
  * lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t*m/(sqrt(v)+eps).  t = state->adam_t+1
  * (or t_host when state is NULL).  grad is multiplied by grad_scale first (1/world).
  * Optionally refreshes a bf16 shadow of the parameters and zeroes grad.
+ * Arithmetic follows the mode: param_bf16 == NULL (fp32 parity mode) -> IEEE sqrt and division; param_bf16 != NULL (bf16
+ * throughput mode, where the forward pass reads the 8-bit-mantissa shadow) -> the quotient lr_t*m / (sqrt(v)+eps) with
+ * the hardware square root and reciprocal (1 ulp each), exactly as the fused dW + Adam epilogues of that mode compute it
+ * (DMVAE_EPI_ADAM: bit-identical to this kernel on the same inputs).
  * dmvae_adam_finish bumps state->adam_t (separate 1-thread kernel so that all
  * chunks of one update see the same t). */
 int dmvae_adam_tf(void* stream, int64_t n, float* param, float* grad, float* m, float* v,
