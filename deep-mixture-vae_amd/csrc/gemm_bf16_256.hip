@@ -69,10 +69,22 @@ struct BiasSeg {
     float* out;                               // db in the gradient arena (ADAM: locates the arena offset; written only when store_grad)
 };
 
-__global__ __launch_bounds__(256) void colsum_slabs_kernel(const bf16_t* in, int64_t ld, int rows, int rows_per_slab, int N, float* part) {
+// up to COLSUM_MAX problems (same row count) in one launch: the column blocks of problem i are blockIdx.x in [xb[i], xb[i + 1])
+constexpr int COLSUM_MAX = 4;
+struct ColsumBatch {
+    int n, rows, rows_per_slab;
+    int xb[COLSUM_MAX + 1];
+    const bf16_t* in[COLSUM_MAX]; int64_t ld[COLSUM_MAX]; int N[COLSUM_MAX]; float* part[COLSUM_MAX];
+};
+__global__ __launch_bounds__(256) void colsum_slabs_kernel(ColsumBatch cb) {
     __shared__ float red[4][512 + 8];
+    int pi = 0;
+    while (pi + 1 < cb.n && (int)blockIdx.x >= cb.xb[pi + 1]) ++pi;
+    const bf16_t* in = cb.in[pi]; const int64_t ld = cb.ld[pi]; const int rows = cb.rows, rows_per_slab = cb.rows_per_slab, N = cb.N[pi];
+    float* part = cb.part[pi];
+    const int bx = (int)blockIdx.x - cb.xb[pi];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = blockIdx.x * 512 + lane * 8;
+    const int n = bx * 512 + lane * 8;
     const int r0 = blockIdx.y * rows_per_slab, r1 = min(rows, r0 + rows_per_slab);
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (n < N)
@@ -90,8 +102,8 @@ __global__ __launch_bounds__(256) void colsum_slabs_kernel(const bf16_t* in, int
     for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = s[j];
     __syncthreads();
     for (int c = threadIdx.x; c < 512; c += 256)
-        if (blockIdx.x * 512 + c < N)
-            part[(int64_t)blockIdx.y * N + blockIdx.x * 512 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        if (bx * 512 + c < N)
+            part[(int64_t)blockIdx.y * N + bx * 512 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 // bias gradient from its partials (slab column sums, or the per-tile column sums dY's producer left) + its Adam update:
@@ -440,8 +452,11 @@ static int launch256(hipStream_t s, const GemmArgs& a0, const dmvae_adam_ctx* ct
         const int nslab = (a.K + rps - 1) / rps;
         if ((int64_t)nslab * a.N > ws_elems) { set_error("gemm_bf16_256: bias-gradient scratch too small (%lld < %lld floats)", (long long)ws_elems, (long long)nslab * a.N); return DMVAE_ESTATE; }
         {
+            ColsumBatch cb{};
+            cb.n = 1; cb.rows = a.K; cb.rows_per_slab = rps; cb.xb[0] = 0; cb.xb[1] = (a.N + 511) / 512;
+            cb.in[0] = reinterpret_cast<const bf16_t*>(a.B); cb.ld[0] = a.ldb; cb.N[0] = a.N; cb.part[0] = ws;
             ProfScope ps(s, "colsum_slabs", (double)a.K * a.N, 2.0 * a.K * a.N + 4.0 * nslab * a.N);
-            hipLaunchKernelGGL(colsum_slabs_kernel, dim3((a.N + 511) / 512, nslab), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(a.B), a.ldb, a.K, rps, a.N, ws);
+            hipLaunchKernelGGL(colsum_slabs_kernel, dim3(cb.xb[1], nslab), dim3(256), 0, s, cb);
         }
         bs.part = ws; bs.nslab = nslab; bs.n = a.N; bs.out = reinterpret_cast<float*>(a.epi.out2);
         extra = std::min(8, (a.N / 4 + 511) / 512);
@@ -498,22 +513,48 @@ static int launch256_dw_multi(hipStream_t s, const GemmArgs* probs, int n, const
 }
 bool gemm_bf16_256_rides() { return g_policy256 >= 1 && g_stagger >= 0; }
 
-// slab column sums of dY for a problem whose producer left none: into [nslab][N] floats at ws
-static int colsum_slabs_into(hipStream_t s, const GemmArgs& a, float* ws, int* nslab_out) {
+// slab column sums of dY for problems whose producers left none ([nslab][N] floats each, at a.csum_in -- already pointed into the
+// scratch by the caller): ONE launch for up to COLSUM_MAX problems of the same K
+static int colsum_slabs_batch(hipStream_t s, GemmArgs* const* probs, int n) {
     constexpr int SLABS = 64;
-    const int rps = std::max(8, (a.K + SLABS - 1) / SLABS);
-    const int nslab = (a.K + rps - 1) / rps;
-    ProfScope ps(s, "colsum_slabs", (double)a.K * a.N, 2.0 * a.K * a.N + 4.0 * nslab * a.N);
-    hipLaunchKernelGGL(colsum_slabs_kernel, dim3((a.N + 511) / 512, nslab), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(a.B), a.ldb, a.K, rps, a.N, ws);
-    *nslab_out = nslab;
-    return check_launch("colsum_slabs");
+    for (int lo = 0; lo < n;) {
+        ColsumBatch cb{};
+        const int K = probs[lo]->K;
+        const int rps = std::max(8, (K + SLABS - 1) / SLABS), nslab = (K + rps - 1) / rps;
+        cb.rows = K; cb.rows_per_slab = rps; cb.xb[0] = 0;
+        double work = 0.0, bytes = 0.0;
+        int cnt = 0;
+        while (lo + cnt < n && cnt < COLSUM_MAX && probs[lo + cnt]->K == K) {
+            GemmArgs& a = *probs[lo + cnt];
+            cb.in[cnt] = reinterpret_cast<const bf16_t*>(a.B); cb.ld[cnt] = a.ldb; cb.N[cnt] = a.N; cb.part[cnt] = const_cast<float*>(a.csum_in);
+            cb.xb[cnt + 1] = cb.xb[cnt] + (a.N + 511) / 512;
+            a.csum_ld = a.N; a.csum_rows = nslab;
+            work += (double)K * a.N; bytes += 2.0 * K * a.N + 4.0 * nslab * a.N;
+            ++cnt;
+        }
+        cb.n = cnt;
+        ProfScope ps(s, "colsum_slabs", work, bytes);
+        hipLaunchKernelGGL(colsum_slabs_kernel, dim3(cb.xb[cnt], nslab), dim3(256), 0, s, cb);
+        const int rc = check_launch("colsum_slabs");
+        if (rc) return rc;
+        lo += cnt;
+    }
+    return 0;
 }
 
 // the large weight-gradient problems of a step: merged into grids of up to MULTI_MAX, singles launched alone
 int gemm_bf16_256_dw_all(hipStream_t s, const GemmArgs* probs, int n, const dmvae_adam_ctx* ctx) {
     std::vector<GemmArgs> merge;
+    std::vector<size_t> need_sums;     // indices into merge: problems whose slab column sums are still to be computed
     int64_t ws_used = 0;         // the problems of one call share the caller's scratch (GemmArgs::ws): sub-allocated here
     auto flush = [&]() -> int {  // launch what has been collected (its slab sums live in [0, ws_used) of the scratch)
+        if (!need_sums.empty()) {
+            std::vector<GemmArgs*> ps;
+            for (size_t i : need_sums) ps.push_back(&merge[i]);
+            const int rc = colsum_slabs_batch(s, ps.data(), (int)ps.size());
+            if (rc) return rc;
+            need_sums.clear();
+        }
         for (size_t lo = 0; lo < merge.size(); lo += MULTI_MAX) {
             const int cnt = (int)std::min<size_t>(MULTI_MAX, merge.size() - lo);
             int rc;
@@ -539,11 +580,9 @@ int gemm_bf16_256_dw_all(hipStream_t s, const GemmArgs* probs, int n, const dmva
         }
         if (a.epi.out2 && !has_part) {      // no partials from dY's producer: slab column sums now, into this problem's part of the scratch
             if (ws_used + (int64_t)64 * a.N > a.ws_elems) { const int rc = flush(); if (rc) return rc; }
-            int nslab = 0;
-            const int rc = colsum_slabs_into(s, a, a.ws + ws_used, &nslab);
-            if (rc) return rc;
-            a.csum_in = a.ws + ws_used; a.csum_ld = a.N; a.csum_rows = nslab;
+            a.csum_in = a.ws + ws_used; a.csum_ld = a.N; a.csum_rows = 0;      // (rows: set by the batched launch in flush)
             ws_used += (int64_t)64 * a.N;
+            need_sums.push_back(merge.size());
         }
         merge.push_back(a);
     }
