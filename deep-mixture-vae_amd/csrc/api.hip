@@ -161,6 +161,8 @@ struct dmvae_plan {
     bool side_busy = false;
     bool fused_update = false;        // set for the duration of dmvae_plan_train_step on a bf16 plan
     bool staged = false;              // dmvae_plan_forward_backward_stage: every segment launches its own dW group
+    GatherSrc xsrc{};                 // dmvae_plan_load_batch_deferred: the batch gather waits for the first dense layer's launch
+    bool xsrc_pending = false;
     bool split_odd_dw = false;        // DMVAE_DW_SPLIT=1: 128-aligned part + remainder strip as two dW problems (see grad_dense)
     bool overlap_dw = true;
     bool finalize_rides = true;       // DMVAE_FINALIZE_INLINE=1: step_finalize as its own launch (A/B)
@@ -417,6 +419,32 @@ extern "C" int dmvae_plan_load_batch(dmvae_plan* p, void* stream, const float* d
                          reinterpret_cast<float*>(WS(p, p->o_xf)), p->Ip, p->Ip, use_state_cursor ? p->buf.state : nullptr);
 }
 
+// Does the first dense layer take the batch gather into its own launch (gemm_bf16_gather_kernel)?  bf16, MLP trunk, a layer
+// the small-tile kernel runs (the 256x256 macro tile has no gather mode).
+static bool gather_folds(const dmvae_plan* p) {
+    return p->cfg.dtype == DMVAE_BF16 && p->conv.empty() && !p->enc.empty() && gemm_bf16_gather_ok(p->Bp, p->enc[0].out_pad, p->Ip);
+}
+extern "C" int dmvae_plan_gather_folds(const dmvae_plan* p) { return p && gather_folds(p) ? 1 : 0; }
+
+// As dmvae_plan_load_batch, for a caller that goes straight on to dmvae_plan_encode / _forward_backward / _train_step: `shadow`
+// is a bf16 copy of `data`, [shadow_rows >= n_rows + 1][input_dim padded to 64] with its pad columns and every row >= n_rows zero
+// (dmvae_gather_rows with perm = NULL makes one).  When dmvae_plan_gather_folds(p) the gather is NOT launched here: the first
+// dense layer reads the shadow through perm and the same launch writes the batch's copies; otherwise exactly dmvae_plan_load_batch.
+extern "C" int dmvae_plan_load_batch_deferred(dmvae_plan* p, void* stream, const float* data, const void* shadow, int64_t shadow_rows, int64_t n_rows,
+                                              const int32_t* perm, int64_t first, int n_valid, int use_state_cursor) {
+    DMVAE_REQUIRE(p && p->bound && data, "dmvae_plan_load_batch_deferred: plan not bound / null data");
+    DMVAE_REQUIRE(n_valid >= 0 && n_valid <= p->cfg.max_batch, "dmvae_plan_load_batch_deferred: n_valid=%d exceeds max_batch=%d", n_valid, p->cfg.max_batch);
+    if (!shadow || shadow_rows <= n_rows || !gather_folds(p)) return dmvae_plan_load_batch(p, stream, data, n_rows, perm, first, n_valid, use_state_cursor);
+    GatherSrc& g = p->xsrc;
+    g.shadow = reinterpret_cast<const bf16_t*>(shadow); g.ld_s = p->Ip; g.zero_row = n_rows;
+    g.data = data; g.dim = p->cfg.input_dim; g.n_rows = n_rows; g.perm = perm; g.first = first; g.batch = p->cfg.max_batch;
+    g.n_valid = n_valid; g.B_pad = p->Bp;
+    g.out_act = reinterpret_cast<bf16_t*>(WS(p, p->o_x)); g.ld_act = p->Ip; g.out_f32 = reinterpret_cast<float*>(WS(p, p->o_xf)); g.ld_f32 = p->Ip;
+    g.cols_pad = p->Ip; g.st = use_state_cursor ? p->buf.state : nullptr;
+    p->xsrc_pending = true;
+    return 0;
+}
+
 static int fwd_dense(dmvae_plan* p, hipStream_t s, const void* A, int64_t lda, int Kdim, const PLayer& L, int N, int64_t w_col,
                      int kind, void* out, int64_t ldo, GemmArgs* deferred = nullptr) {
     dmvae_epilogue e;
@@ -546,6 +574,12 @@ static int encode_impl(dmvae_plan* p, hipStream_t s) {
     }
     for (size_t i = 0; i < p->enc.size(); ++i) {
         const PLayer& L = p->enc[i];
+        if (i == 0 && p->xsrc_pending) {     // the deferred batch gather rides in this launch (dmvae_plan_load_batch_deferred)
+            p->xsrc_pending = false;
+            GemmArgs a;
+            TRY(fwd_dense(p, s, in, ld, kd, L, L.out_pad, 0, DMVAE_EPI_BIAS_RELU, WS(p, p->o_enc[i]), L.out_pad, &a));
+            TRY(gemm_bf16_gather_launch(s, a, p->xsrc));
+        } else
         TRY(fwd_dense(p, s, in, ld, kd, L, L.out_pad, 0, DMVAE_EPI_BIAS_RELU, WS(p, p->o_enc[i]), L.out_pad));
         in = WS(p, p->o_enc[i]); ld = L.out_pad; kd = L.out_pad;
     }

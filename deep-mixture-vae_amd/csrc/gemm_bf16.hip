@@ -72,9 +72,11 @@ namespace dmvae {
 // BKT = K depth of one ring slot (64; 32 is available to the dW layout: a 128x128 tile then gets a
 // 4-slot ring in the same 64 KiB, i.e. 48 KiB instead of 32 KiB in flight).
 // CONV: conv mode (GemmArgs::conv_c, gemm_epilogue.h) -- a compile-time variant, so the dense kernels carry none of it.
-template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW, int BKT = BK, bool CONV = false>
+// GATHER: the k-contiguous A operand's rows are rows of a bf16 dataset copy picked through the epoch's permutation (GatherSrc, kernels.h).
+template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW, int BKT = BK, bool CONV = false, bool GATHER = false>
 __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_raw, const int gstart, const int nwg, bf16_t* smem,
-                                               const dmvae_adam_ctx* ac = nullptr, const int kslice = -1) {
+                                               const dmvae_adam_ctx* ac = nullptr, const int kslice = -1, const GatherSrc* gs = nullptr) {
+    static_assert(!GATHER || (LAYOUT == DMVAE_GEMM_FWD && !CONV), "gather mode: the forward layout's A operand");
     constexpr bool A_KC = (LAYOUT != DMVAE_GEMM_DW);
     constexpr bool B_KC = (LAYOUT == DMVAE_GEMM_DX);
     constexpr int A_ELEMS = BM * BKT, B_ELEMS = BN * BKT, STAGE = A_ELEMS + B_ELEMS;
@@ -140,6 +142,22 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     unsigned goA[BM * BKT / (512 * NW)], goB[BN * BKT / (512 * NW)];
     stage_offsets<BM, A_KC, NW, BKT>(a.lda, wave, lane, goA);
     stage_offsets<BN, B_KC, NW, BKT>(a.ldb, wave, lane, goB);
+    if constexpr (GATHER) {       // row m of the batch = dataset row perm[first + m]; rows past n_valid: the all-zero row
+        const dmvae_state* gst = reinterpret_cast<const dmvae_state*>(gs->st);
+        const int64_t first = gst ? (int64_t)gst->batch_cursor * gs->batch : gs->first;
+        Ag = gs->shadow + kbeg;
+#pragma unroll
+        for (int i = 0; i < BM * BKT / (512 * NW); ++i) {
+            const int row = i * (8 * NW) + wave * 8 + (lane >> 3), m = m0 + row;
+            int64_t src = gs->zero_row;
+            if (m < gs->n_valid) {
+                src = first + m;
+                if (gs->perm) src = gs->perm[src];
+                if (src < 0 || src >= gs->n_rows) src = gs->zero_row;
+            }
+            goA[i] = 2u * (unsigned)(src * gs->ld_s + swz_kc(row, lane & 7) * 8);
+        }
+    }
     // Conv mode: K (or, for the weight gradient, M) runs over (tap, channel) with conv_c channels per tap, and an
     // operand row holds lda >= conv_c channels.  conv_c >= 64: a 64-wide tile lies inside one tap.  conv_c = 32 (the
     // 32-channel layers, stored with 32 zero pad channels): a tile covers TWO taps -- 16-byte chunks 0..3 belong to
@@ -948,6 +966,74 @@ int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split) 
 #undef CASE
     set_error("dmvae_gemm(bf16): layout %d with epilogue %d is not instantiated", layout, epi);
     return DMVAE_EUNSUPPORTED;
+}
+
+// ---------------------------------------------------------------- first layer with the batch gather folded in
+// workgroups [0, ntiles): output tiles in gather mode; the rest: the batch's act / f32 copies (gather_kernel's loop, elementwise.hip)
+__device__ __forceinline__ void gather_rows_block(const GatherSrc& g, const int bid, const int nb, const int nthreads) {
+    const dmvae_state* gst = reinterpret_cast<const dmvae_state*>(g.st);
+    const int64_t first = gst ? (int64_t)gst->batch_cursor * g.batch : g.first;
+    const int quads = g.cols_pad >> 2;
+    const int64_t total = (int64_t)g.B_pad * quads;
+    for (int64_t i = (int64_t)bid * nthreads + threadIdx.x; i < total; i += (int64_t)nb * nthreads) {
+        const int r = (int)(i / quads), c = (int)(i % quads) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < g.n_valid) {
+            int64_t src = first + r;
+            if (g.perm) src = g.perm[src];
+            if (src >= 0 && src < g.n_rows) {
+                const float* p = g.data + src * g.dim + c;
+                if (c + 3 < g.dim && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                    const float4 q = *reinterpret_cast<const float4*>(p);
+                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (c + j < g.dim) ? p[j] : 0.f;
+                }
+            }
+        }
+        if (g.out_act) ActIO<bf16_t>::store4(g.out_act, (int64_t)r * g.ld_act + c, v);
+        if (g.out_f32) ActIO<float>::store4(g.out_f32, (int64_t)r * g.ld_f32 + c, v);
+    }
+}
+
+template <int BM, int BN, int NSTAGE, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_bf16_gather_kernel(GemmArgs a, GatherSrc g, int ntiles) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * (BM + BN) * BK];
+    if ((int)blockIdx.x >= ntiles) {
+        gather_rows_block(g, (int)blockIdx.x - ntiles, (int)gridDim.x - ntiles, 64 * NW);
+        return;
+    }
+    gemm_bf16_body<BM, BN, DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_RELU, NSTAGE, NW, BK, false, true>(a, blockIdx.x, 0, ntiles, smem, nullptr, -1, &g);
+}
+
+bool gemm_bf16_gather_ok(int M, int N, int K) {
+    return M % 64 == 0 && N % 64 == 0 && K % 64 == 0 && !gemm_bf16_256_ok(DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_RELU, M, N, K, false);
+}
+
+template <int BM, int BN, int NSTAGE, int NW>
+static int launch_gather(hipStream_t s, const GemmArgs& a, const GatherSrc& g) {
+    const int ntiles = (a.M / BM) * (a.N / BN);
+    // riders: the copies are ~B x cols x 10 bytes; as many workgroups as fill the CUs' second slots, at least 64
+    const int riders = std::max(64, std::min(256, 512 - std::min(ntiles, 512)));
+    ProfScope ps(s, "gemm_bf16_gather_kernel", 2.0 * a.M * a.N * (double)a.K,
+                 gemm_bytes(a) + (double)g.n_valid * g.dim * 4.0 + (double)g.B_pad * g.cols_pad * 6.0);
+    hipLaunchKernelGGL((gemm_bf16_gather_kernel<BM, BN, NSTAGE, NW>), dim3(ntiles + riders), dim3(64 * NW), 0, s, a, g, ntiles);
+    return check_launch("gemm_bf16_gather");
+}
+
+int gemm_bf16_gather_launch(hipStream_t s, const GemmArgs& a0, const GatherSrc& g) {
+    GemmArgs a = a0;
+    if (a.epi.kind != DMVAE_EPI_BIAS_RELU || !gemm_bf16_gather_ok(a.M, a.N, a.K) || a.conv_c) { set_error("gemm_bf16_gather: bias + ReLU forward layer, not the macro tile's"); return DMVAE_EUNSUPPORTED; }
+    if ((g.zero_row + 1) * g.ld_s * 2 >= ((int64_t)1 << 32)) { set_error("gemm_bf16_gather: dataset copy larger than 4 GiB"); return DMVAE_EUNSUPPORTED; }
+    const int t = gemm_bf16_tile_m(a.M, a.N, 1);
+    a.group_m = gemm_auto_group_m(a.M / (t / 1000), a.N / (t % 1000), t / 1000, t % 1000);
+    switch (t) {
+        case 128128: return launch_gather<128, 128, 2, 8>(s, a, g);
+        case 128064: return launch_gather<128, 64, 3, 8>(s, a, g);
+        case 64128: return launch_gather<64, 128, 3, 4>(s, a, g);
+        default: return launch_gather<64, 64, 4, 4>(s, a, g);
+    }
 }
 
 // ---------------------------------------------------------------- XCD-sliced layer chain (probe)

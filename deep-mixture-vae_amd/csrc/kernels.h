@@ -62,6 +62,18 @@ int spin_launch(hipStream_t s, int us);
 void* gemm_bf16_stamps();
 void* gemm_bf16_anatomy();
 void* gemm_bf16_256_anatomy();
+// Batch assembly folded into the first dense layer (Dataset.get_batches, includes/utils.py:449-463): the forward GEMM reads its
+// rows straight from a bf16 copy of the dataset through the epoch's permutation, and spare workgroups of the same launch write
+// the batch's act / f32 copies (weight gradient of the first layer, reconstruction targets) -- no gather launch in front.
+struct GatherSrc {
+    const bf16_t* shadow; int64_t ld_s; int64_t zero_row;      // bf16 dataset [>= n_rows + 1][ld_s], pad columns and row zero_row all zero
+    const float* data; int dim; int64_t n_rows;
+    const int32_t* perm; int64_t first; int batch, n_valid, B_pad;
+    bf16_t* out_act; int64_t ld_act; float* out_f32; int64_t ld_f32; int cols_pad;
+    const void* st;                                             // dmvae_state: first = batch_cursor * batch when set
+};
+bool gemm_bf16_gather_ok(int M, int N, int K);
+int gemm_bf16_gather_launch(hipStream_t s, const GemmArgs& a, const GatherSrc& g);
 int chain_probe_launch(hipStream_t s, int variant, int nlayer, const GemmArgs* layers, unsigned* sync, int* err);
 // CNN trunk (conv.hip)
 int conv_first_fwd_launch(hipStream_t s, int dtype, const void* x, int64_t bstride, int H, int64_t n_img, const void* W, int ldw,

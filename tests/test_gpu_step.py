@@ -177,6 +177,41 @@ def test_fused_update_equals_backward_then_adam(mode):
     assert engs[0].param.abs().sum().item() > 0
 
 
+@pytest.mark.parametrize("B", [256, 4096])
+def test_gather_folded_into_first_layer_equals_plain_gather(B, monkeypatch):
+    """train_step with the batch gather folded into the first dense layer's launch (dmvae_plan_load_batch_deferred: rows read
+    from a bf16 dataset copy through the permutation, spare workgroups write the batch's copies) must leave the bits of the
+    plain gather + step: batch buffers, loss, parameters -- shuffled rows, a ragged last batch, several steps, eager and replayed."""
+    kw = dict(input_dim=784, latent_dim=64, n_classes=10)
+    N = 3 * B + 77
+    X = torch.as_tensor(O.synthetic_images(N, 784, seed=8)).cuda()
+    perm = torch.randperm(N, device="cuda").to(torch.int32)
+    plain = make(kw, "bf16", B, seed=4)
+    monkeypatch.setenv("DMVAE_GATHER_FOLD", "1")          # (measured slower than the plain gather at cfg2: opt-in, runtime.py)
+    fold = make(kw, "bf16", B, seed=4)
+    monkeypatch.delenv("DMVAE_GATHER_FOLD")
+    assert fold._folds and not plain._folds
+    rng = np.random.RandomState(2)
+    for step, (first, n) in enumerate(((0, B), (B, B), (2 * B, B), (3 * B, 77))):
+        ed = torch.as_tensor(rng.randn(n, 64).astype(np.float32)).cuda()
+        for eng in (plain, fold):
+            eng.train_step(X, perm, n, ed, None, first, False)
+        torch.cuda.synchronize()
+        assert plain.read_state().last_loss == fold.read_state().last_loss
+        for name in ("param", "m", "v", "param_bf16"):
+            assert torch.equal(getattr(plain, name), getattr(fold, name)), (step, name)
+        assert torch.equal(plain.view("x", B, 784), fold.view("x", B, 784)), step
+    # device-side cursor + graph replay (the bench's form)
+    for eng in (plain, fold):
+        eng.reset_epoch(3)
+    reps = [eng.capture_step(X, perm) for eng in (plain, fold)]
+    for _ in range(3):
+        for rp in reps: rp()
+    torch.cuda.synchronize()
+    assert plain.read_state().last_loss == fold.read_state().last_loss
+    assert torch.equal(plain.param, fold.param)
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
 def test_staged_backward_equals_whole_and_buckets_cover_the_arena(dtype):
     """dmvae_plan_forward_backward_stage 0, 1, 2 (the data-parallel form: one dW launch and one
