@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                     for (int u = 0; u < 4; ++u) nz[4 * j + u] = q4[u];
                 }
             }
+            LAT_STAMP(7);
 #pragma unroll
             for (int i = 0; i < DSL; ++i) {
                 const int d = lr + 16 * i;
@@ -275,25 +276,28 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                     a.clv[(int64_t)b * a.ld_g + dg] = cl;
                 }
             }
+            LAT_STAMP(8);
             if (MODE == 0) {
                 float gm[DSL], A[DSL];
 #pragma unroll
                 for (int i = 0; i < DSL; ++i) { gm[i] = 0.f; A[i] = 0.f; }
                 // one wave per SIMD: nothing hides an LDS round trip, so every loop below is unrolled
                 // to keep a batch of independent reads in flight
+                // (columns past the chunk read table padding and are never stored: no branch in the loop, so the LDS reads of an
+                //  unrolled trip are issued together -- with `if (ok[i])` around the body every (k, column) pair was its own LDS
+                //  round trip: 1.8 us of the 4 us this phase took at D = 64, K = 10)
 #pragma unroll 5
                 for (int k = 0; k < K; ++k) {
                     const float wk = ws[r * K + k];
 #pragma unroll
                     for (int i = 0; i < DSL; ++i) {
-                        if (ok[i]) {
-                            const int d = lr + 16 * i;
-                            const float ipk = t2[k * DCP + d];
-                            gm[i] += wk * (mu[i] - t1[k * DCP + d]) * ipk;
-                            A[i] += wk * ipk;
-                        }
+                        const int d = lr + 16 * i;
+                        const float ipk = t2[k * DCP + d];
+                        gm[i] += wk * (mu[i] - t1[k * DCP + d]) * ipk;
+                        A[i] += wk * ipk;
                     }
                 }
+                LAT_STAMP(9);
                 lvsum = row_sum16(lvsum);
                 if (lr == 0) rowlv[r] += lvsum;
 #pragma unroll
@@ -315,11 +319,9 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                     const float wk = ws[r * K + k];
 #pragma unroll
                     for (int i = 0; i < DSL; ++i) {
-                        if (ok[i]) {
-                            const int d = lr + 16 * i;
-                            bm[i] += wk * t1[k * DCP + d];
-                            bl[i] += wk * t2[k * DCP + d];
-                        }
+                        const int d = lr + 16 * i;
+                        bm[i] += wk * t1[k * DCP + d];
+                        bl[i] += wk * t2[k * DCP + d];
                     }
                 }
                 float integ = 0.f;
@@ -346,6 +348,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                 if (lr == 0) rowlv[r] += integ;
             }
         }
+        LAT_STAMP(10);
         lds_barrier();
         LAT_STAMP(3);
 

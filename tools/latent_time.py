@@ -16,7 +16,7 @@ def run(B, D, K, host_eps, f32z, mode=0):
     Zb = torch.zeros(B, ldD, dtype=torch.bfloat16, device=dev); Zf = z(B, ldD); w = z(B, ldK)
     gmu, glv, clv = z(B, ldD), z(B, ldD), z(B, ldD); dlg = torch.zeros(B, ldK, dtype=torch.bfloat16, device=dev)
     nblk = lib.dmvae_latent_nblocks(B, D, K)
-    dpri, lp = z(nblk, 2 * K * D), z(nblk + 16, 2)
+    dpri, lp = z(nblk, 2 * K * D), z(nblk + 32, 2)
     a = _lib.LatentArgs()
     a.B, a.B_pad, a.D, a.K, a.mode, a.act_dtype = B, B, D, K, mode, _lib.BF16
     a.kl_ratio, a.temperature, a.inv_B, a.seed = 1.0, 0.5, 1.0 / B, 7
@@ -38,7 +38,8 @@ def run(B, D, K, host_eps, f32z, mode=0):
     t1.record(); torch.cuda.synchronize()
     print("B=%5d D=%3d K=%2d host_eps=%d f32z=%d blocks=%d : %.2f us" % (B, D, K, host_eps, f32z, nblk, t0.elapsed_time(t1) / 50 * 1e3), flush=True)
     if "abl7" in os.environ.get("DMVAE_HIP_LIB", ""):
-        t = lp.view(-1)[2 * nblk: 2 * nblk + 14].view(torch.int64).cpu().numpy()
+        t = lp.view(-1)[2 * nblk: 2 * nblk + 24].view(torch.int64).cpu().numpy()
+        print("     phase 1a of wave 0 (noise | columns: exp, z, 3 stores | k loop | gradient stores | wait for the other waves):", [round((t[j] - t[i]) / 100.0, 2) for i, j in ((2, 7), (7, 8), (8, 9), (9, 10), (10, 3))])
         print("     block 0 phases us (early loads | prologue | phase 1a | 1b | 2 | finalize):", [round((t[i + 1] - t[i]) / 100.0, 2) for i in range(6)])
 for B in (64, 256, 1024, 4096, 16384):
     run(B, 64, 10, 0, 1)
