@@ -390,7 +390,7 @@ def main():
         traffic = None      # HBM bytes per launch from PMC counters: a separate rocprofv3 --pmc run (tools/pmc_traffic.sh)
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         rocname = rocprof_name(dom["name"])
-        if os.path.exists(tp):
+        if os.path.exists(tp) and is_cfg2:      # (the PMC pass is of the metric config: other configs share kernel names, not traffic)
             try:
                 tj = json.load(open(tp))
                 hit = tj.get(dom["name"]) or tj.get(rocname)
