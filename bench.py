@@ -9,8 +9,10 @@ One "step" = batch assembly + forward + loss + backward + (gradient all-reduce)
 + Adam, i.e. one session.run([loss, train_step]) of code/base_models.py:126-129.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
-  "roofline"     : the dominant kernel family, measured with HIP events around
-                   every launch of a few eager steps (same process, same shapes)
+  "roofline"     : the dominant kernel family; durations are each dispatch's own
+                   begin -> end timestamps (event pair bound to the dispatch by
+                   hipExtLaunchKernelGGL: what rocprofv3 --kernel-trace reports) over a
+                   few eager steps of the same process and shapes
   "cpu_baseline" : the oracle (CPU restatement of the reference step, float32,
                    NumPy/OpenBLAS on the box's host cores) on a bounded sample.
 """
@@ -35,6 +37,8 @@ PRESETS = {
     "cfg2": dict(batch=4096, latent_dim=64, n_clusters=10),
     "cfg3": dict(batch=16384, latent_dim=128, n_clusters=10),
     "cfg4": dict(batch=8192, latent_dim=256, n_clusters=50),
+    # the north star's scaling statement, ">= 4x images/sec 1 -> 8 GPUs at batch 65 536": the SAME global batch at every N
+    "cfg4-strong": dict(global_batch=65536, latent_dim=256, n_clusters=50),
     "cfg5": dict(batch=8192, latent_dim=512, n_clusters=256, input_dim=4096, enc_layers="4096,4096,4096,4096", head_dim=4096,
                  dec_layers="4096,4096,4096,4096", lr=1e-4),
 }
@@ -50,6 +54,8 @@ def parse():
     ap.add_argument("--config", default="", choices=[""] + sorted(PRESETS), help="a BASELINE.json config as a preset of the shape flags "
                     "below (per-GPU batch; cfg4 = the north star's scaling point, 8192 per GPU, D=256, K=50); default = cfg2, the metric")
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch (cfg2: 4096)")
+    ap.add_argument("--global-batch", dest="global_batch", type=int, default=0, help="STRONG scaling: this many images per step over all "
+                    "--gpus ranks (per-GPU batch = global / N, which must be a whole number); the line then says scaling: strong")
     ap.add_argument("--lr", type=float, default=0.002, help="Adam learning rate (train.py default 0.002; the 4096-wide cfg5 "
                     "stack overflows exp(log_var) after one step at that rate in fp32 and bf16 alike: use 1e-4 there)")
     ap.add_argument("--input_dim", type=int, default=784)
@@ -248,6 +254,11 @@ def main():
 
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if args.global_batch:      # strong scaling: one global batch cut over the ranks
+        if args.global_batch % world:
+            raise SystemExit("bench.py: --global-batch %d is not a multiple of %d ranks" % (args.global_batch, world))
+        args.batch = args.global_batch // world
+        args.rows = max(args.rows, args.batch)
     I, D, K, B = args.input_dim, args.latent_dim, args.n_clusters, args.batch
     enc = tuple(int(v) for v in args.enc_layers.split(","))
     if args.cnn:
@@ -344,11 +355,15 @@ def main():
         "metric": "images/sec (train), MNIST K=10 z=64 batch=4096/GPU bf16" if is_cfg2
                   else "images/sec (train), DMVAE %s batch=%d/GPU %s" % (arch, B, args.dtype),
         "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "%sDMVAE MLP %s, one ELBO training step (gather+fwd+loss+bwd+Adam), synthetic rows resident in HBM"
                                % ("configs[1]: " if is_cfg2 else "", arch),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                   # ranks of the RCCL communicator the gradient exchange ran on (0: single process, no communicator;
+                   # a gloo rehearsal on one card also says 0 and names its backend)
+                   "rccl_ranks": (world if (world > 1 or force_dp) and args.backend == "nccl" else 0),
+                   "collective_backend": (("rccl (torch.distributed nccl)" if args.backend == "nccl" else "gloo (rehearsal)") if (world > 1 or force_dp) else None),
                    "hip_graph": (not args.no_graph) and sync is None, "float_atomics": False,
                    "update": "stand-alone adam" if args.cnn and sync is None else "adam fused into the dW launch" if sync is None else
                              ("%s, %s" % ("reduce-scatter -> adam on the owned 1/world slice -> all-gather" if getattr(sync, "sharded", False) else "all-reduce -> replicated adam",
@@ -361,24 +376,27 @@ def main():
     out["timing"] = "median of %d regions of %d steps, each bracketed by barrier + synchronize" % (len(regions), args.steps)
     if rows:
         ps = float(args.profile_steps)
-        # Event brackets are taken on EAGER launches (an event pair cannot be read back from inside a graph on this
-        # ROCm); besides the kernel each bracket holds its dispatch, so their sum exceeds the graph-replayed step the
-        # line reports (r01: 0.344 vs 0.308 ms).  Per-kernel durations are therefore SCALED so that they add up to
-        # the timed step -- the durations the replay actually runs at, and what rocprofv3 --kernel-trace reports
-        # for the same command (profiles/): `event_scale` is the factor, avg_us_event the raw bracket.
+        # Per-kernel durations: each dispatch's OWN begin -> end timestamps (the event pair hipExtLaunchKernelGGL binds to
+        # the dispatch: the completion signal's start / end, the figure rocprofv3 --kernel-trace prints), taken on eager
+        # launches after the timed region.  No scaling of any kind (r02 scaled event BRACKETS by one factor so that they
+        # summed to the graph-replayed step; a bracket's excess over the kernel is additive -- its dispatch and markers --
+        # so that took time from the long kernels and gave it to the short ones: VERDICT r2 weak #3 / ADVICE r2).  The
+        # bracket is kept as avg_us_event.  Were the runtime to return no dispatch timestamps the bracket itself would
+        # be used, unscaled (the conservative figure), and `method` would say so.
+        have_k = all(r["kernel_launches"] > 0 and r["kernel_ms"] > 0 for r in rows)
+        dur = (lambda r: r["kernel_ms"]) if have_k else (lambda r: r["total_ms"])
         ev_sum = sum(r["total_ms"] for r in rows) / ps
-        scale = min(1.0, ms_step / ev_sum) if (ev_sum > 0 and sync is None and not args.no_graph) else 1.0
         table = []
         for r in rows:
-            ms = scale * r["total_ms"] / ps
-            tot = scale * r["total_ms"]
-            table.append({"kernel": r["name"], "launches_per_step": r["launches"] / ps, "ms_per_step": round(ms, 4),
+            tot = dur(r)
+            table.append({"kernel": r["name"], "launches_per_step": r["launches"] / ps, "ms_per_step": round(tot / ps, 4),
                           "avg_us": round(1e3 * tot / max(1, r["launches"]), 3),
                           "avg_us_event": round(1e3 * r["total_ms"] / max(1, r["launches"]), 3),
+                          "dispatches_per_launch": round(r["kernel_launches"] / max(1, r["launches"]), 2),
                           "tflops": round(r["flops"] / (tot * 1e-3) / 1e12, 2) if tot > 0 else 0.0,
                           "gbs": round(r["bytes"] / (tot * 1e-3) / 1e9, 1) if tot > 0 else 0.0})
-        dom = max(rows, key=lambda r: r["total_ms"])
-        dom_ms = scale * dom["total_ms"]
+        dom = max(rows, key=dur)
+        dom_ms = dur(dom)
         # which roof bounds the dominant kernel: its algorithmic intensity against the ridge point
         # (dense MFMA peak / HBM peak = 312 flop/B for bf16).  The fused dW + Adam launch moves
         # ~300 MB for 41 GFLOP = 137 flop/B: HBM side of the ridge.
@@ -387,10 +405,13 @@ def main():
         is_gemm = dom["name"].startswith("gemm") and ai >= peak_fl * 1e12 / (PEAK_HBM_GBS * 1e9)
         ach = (dom["flops"] if is_gemm else dom["bytes"]) / (dom_ms * 1e-3) / (1e12 if is_gemm else 1e9)
         peak = peak_fl if is_gemm else PEAK_HBM_GBS
-        traffic = None      # HBM bytes per launch from PMC counters: a separate rocprofv3 --pmc run (tools/pmc_traffic.sh)
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        # HBM bytes per launch: NOT measured in this run -- PMC counters need their own rocprofv3 --pmc passes
+        # (tools/pmc_traffic.sh); the figure for this kernel is read from the committed file named in traffic_source
+        traffic, traffic_source = None, None
         rocname = rocprof_name(dom["name"])
-        if os.path.exists(tp) and is_cfg2:      # (the PMC pass is of the metric config: other configs share kernel names, not traffic)
+        tname = "traffic.json" if is_cfg2 else ("traffic_%s.json" % args.config if args.config else None)
+        tp = os.path.join(ROOT, "profiles", tname) if tname else None
+        if tp and os.path.exists(tp) and not args.cnn:      # (a PMC pass is of ONE config: other configs share kernel names, not traffic)
             try:
                 tj = json.load(open(tp))
                 hit = tj.get(dom["name"]) or tj.get(rocname)
@@ -398,23 +419,27 @@ def main():
                     stem = rocname.rstrip(">")
                     hit = next((v for k, v in tj.items() if k.startswith(stem)), {})
                 traffic = hit.get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic_source = ("committed PMC pass profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+                                      "FETCH_SIZE x 2 per the gfx950 correction; not collected in this run" % tname)
             except Exception:
                 traffic = None
         out["roofline"] = {"kernel": dom["name"], "rocprof_kernel": rocname,
                            "bound": "mfma" if is_gemm else "hbm", "achieved": round(ach, 2),
                            "peak": peak, "unit": "TFLOP/s" if is_gemm else "GB/s", "frac": round(ach / peak, 4),
-                           "traffic": traffic,
+                           "traffic": traffic, "traffic_source": traffic_source,
                            "launches_per_step": dom["launches"] / ps,
                            "avg_launch_us": round(1e3 * dom_ms / dom["launches"], 3),
                            "avg_launch_us_event": round(1e3 * dom["total_ms"] / dom["launches"], 3),
-                           "event_scale": round(scale, 4),
                            "algorithmic_per_launch": (dom["flops"] if is_gemm else dom["bytes"]) / dom["launches"],
                            "flops_per_launch": dom["flops"] / dom["launches"], "bytes_per_launch": dom["bytes"] / dom["launches"],
                            "flop_per_byte": round(ai, 1),
                            "mfma_frac": round(dom["flops"] / (dom_ms * 1e-3) / (peak_fl * 1e12), 4),
                            "hbm_frac": round(dom["bytes"] / (dom_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
-                           "method": "hipEvent pair around every launch of %d eager steps after the timed region, scaled by event_scale "
-                                     "so that the per-kernel durations sum to the timed (graph-replayed) step" % args.profile_steps}
+                           "method": ("dispatch timestamps: an event pair bound to every kernel dispatch (hipExtLaunchKernelGGL) of %d eager steps after the "
+                                      "timed region; unscaled; the durations rocprofv3 --kernel-trace reports" if have_k else
+                                      "hipEvent BRACKET around every launch of %d eager steps after the timed region (the runtime returned no dispatch "
+                                      "timestamps); unscaled: holds the dispatch besides the kernel") % args.profile_steps}
         assert out["roofline"]["frac"] <= 1.0, "roofline.frac %.4f > 1: the kernel's algorithmic bytes / flops are over-counted" % out["roofline"]["frac"]
         out["kernels"] = table
         out["kernels_per_step"] = round(sum(t["launches_per_step"] for t in table), 2)

@@ -32,11 +32,14 @@ int check_launch(const char* what) {
 }
 
 // ------------------------------------------------------------------ profiling
-struct ProfRec { const char* name; double flops, bytes; hipEvent_t e0, e1; };
+// One record per ProfScope: the event BRACKET around the scope's launches (e0, e1: holds the launches' dispatch besides the
+// kernels) and, per kernel launched inside it, the pair bound to that dispatch (k: the kernel's own begin -> end).
+struct ProfRec { const char* name; double flops, bytes; hipEvent_t e0, e1; std::vector<std::pair<hipEvent_t, hipEvent_t>> k; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_event_pool;
 static std::mutex g_prof_mu;
+static thread_local int g_prof_cur = -1;       // slot of the innermost open ProfScope of this thread
 
 static hipEvent_t get_event() {
     if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
@@ -44,18 +47,30 @@ static hipEvent_t get_event() {
     (void)hipEventCreate(&e);
     return e;
 }
-ProfScope::ProfScope(hipStream_t s_, const char* name, double flops, double bytes) : s(s_), slot(-1) {
+ProfScope::ProfScope(hipStream_t s_, const char* name, double flops, double bytes) : s(s_), slot(-1), outer(-1) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    ProfRec r{name, flops, bytes, get_event(), get_event()};
+    ProfRec r{name, flops, bytes, get_event(), get_event(), {}};
     (void)hipEventRecord(r.e0, s);
     slot = (int)g_prof.size();
     g_prof.push_back(r);
+    outer = g_prof_cur;
+    g_prof_cur = slot;
 }
 ProfScope::~ProfScope() {
     if (slot < 0) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     (void)hipEventRecord(g_prof[slot].e1, s);
+    g_prof_cur = outer;
+}
+bool prof_launch_events(hipEvent_t* e0, hipEvent_t* e1) {
+    if (!g_prof_on || g_prof_cur < 0) return false;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof_cur >= (int)g_prof.size()) return false;
+    *e0 = get_event();
+    *e1 = get_event();
+    g_prof[g_prof_cur].k.emplace_back(*e0, *e1);
+    return true;
 }
 
 static const char* gemm_name(int dtype, int layout) {
@@ -713,6 +728,7 @@ static int launch_dw_queue(dmvae_plan* p, hipStream_t target, bool with_prior) {
         c.param = p->buf.param; c.grad = p->buf.grad; c.m = p->buf.m; c.v = p->buf.v; c.param_bf16 = p->buf.param_bf16;
         c.state = p->buf.state; c.beta1 = p->cfg.beta1; c.beta2 = p->cfg.beta2; c.epsilon = p->cfg.adam_eps; c.grad_scale = 1.f;
         c.store_grad = 0;
+        c.ieee = p->cfg.adam_ieee;
         c.seg_off = p->prior_off;                       // prior tables: gradient written by step_finalize
         c.seg_n = with_prior ? ((2 * (int64_t)p->cfg.n_classes * p->cfg.latent_dim + 3) & ~(int64_t)3) : 0;
         rc = gemm_bf16_grouped_dw_adam(target, p->dw_queue.data(), (int)p->dw_queue.size(), c);
@@ -968,6 +984,7 @@ extern "C" int dmvae_plan_update_range(dmvae_plan* p, void* stream, float grad_s
     a.pb = p->cfg.dtype == DMVAE_BF16 ? reinterpret_cast<bf16_t*>(p->buf.param_bf16) + lo : nullptr;
     a.lr = 0.f; a.b1 = p->cfg.beta1; a.b2 = p->cfg.beta2; a.eps = p->cfg.adam_eps; a.gscale = grad_scale;
     a.zero_grad = 0;    // every gradient element is overwritten each step (no atomic accumulation)
+    a.ieee = p->cfg.adam_ieee;
     a.t_host = ~0ull;    // t = state->adam_t, already advanced by this step's loss_finalize (saves a launch)
     a.st = reinterpret_cast<const dmvae_state*>(p->buf.state);
     return adam_launch(s, a);
@@ -1066,12 +1083,12 @@ extern "C" int dmvae_loss_finalize(void* stream, const float* rp, int nr, const 
     return loss_finalize_launch((hipStream_t)stream, rp, nr, lp, nl, inv_B, state, 0);
 }
 extern "C" int dmvae_adam_tf(void* stream, int64_t n, float* param, float* grad, float* m, float* v, void* param_bf16, float lr,
-                             float beta1, float beta2, float epsilon, float grad_scale, int zero_grad, uint64_t t_host, const void* state) {
+                             float beta1, float beta2, float epsilon, float grad_scale, int flags, uint64_t t_host, const void* state) {
     DMVAE_REQUIRE(param && grad && m && v && n > 0 && n % 4 == 0, "dmvae_adam_tf: n must be a positive multiple of 4");
     DMVAE_REQUIRE(state || t_host >= 1, "dmvae_adam_tf: t starts at 1");
     AdamArgs a;
     a.n = n; a.p = param; a.g = grad; a.m = m; a.v = v; a.pb = reinterpret_cast<bf16_t*>(param_bf16);
-    a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = epsilon; a.gscale = grad_scale; a.zero_grad = zero_grad;
+    a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = epsilon; a.gscale = grad_scale; a.zero_grad = (flags & DMVAE_ADAM_ZERO_GRAD) != 0; a.ieee = (flags & DMVAE_ADAM_IEEE) != 0;
     a.t_host = t_host; a.st = reinterpret_cast<const dmvae_state*>(state);
     return adam_launch((hipStream_t)stream, a);
 }
@@ -1149,6 +1166,17 @@ extern "C" int dmvae_prof_collect(dmvae_prof_row* rows, int max_rows) {
         (void)hipEventSynchronize(r.e1);
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        // the kernels' own durations: per dispatch, stop - start of the pair hipExtLaunchKernelGGL bound to it
+        double kms = 0.0;
+        bool kok = !r.k.empty();
+        for (auto& pr : r.k) {
+            float d = 0.f;
+            if (hipEventSynchronize(pr.second) != hipSuccess || hipEventElapsedTime(&d, pr.first, pr.second) != hipSuccess || !(d > 0.f)) kok = false;
+            kms += d;
+            g_event_pool.push_back(pr.first);
+            g_event_pool.push_back(pr.second);
+        }
+        (void)hipGetLastError();
         auto it = agg.find(r.name);
         if (it == agg.end()) {
             dmvae_prof_row row;
@@ -1159,12 +1187,15 @@ extern "C" int dmvae_prof_collect(dmvae_prof_row* rows, int max_rows) {
         }
         it->second.launches += 1;
         it->second.total_ms += ms;
+        it->second.kernel_ms += kok ? kms : 0.0;
+        it->second.kernel_launches += kok ? (int64_t)r.k.size() : 0;
         it->second.flops += r.flops;
         it->second.bytes += r.bytes;
         g_event_pool.push_back(r.e0);
         g_event_pool.push_back(r.e1);
     }
     g_prof.clear();
+    g_prof_cur = -1;
     int n = 0;
     for (auto& k : order) {
         if (n >= max_rows) break;

@@ -1,9 +1,10 @@
 // Shared device/host helpers for the gfx950 DMVAE kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
-#include "../../include/dmvae_hip.h"
+#include "../../include/dmvae_hip_debug.h"
 
 typedef unsigned short bf16_t;   // raw bf16 bits in memory
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -210,10 +211,26 @@ void set_error(const char* fmt, ...);
 struct ProfScope {   // brackets a launch with a hipEvent pair when profiling is on
     ProfScope(hipStream_t s, const char* name, double flops, double bytes);
     ~ProfScope();
-    hipStream_t s; int slot;
+    hipStream_t s; int slot, outer;
 };
+// profiling on and a ProfScope open on this thread: a fresh event pair for ONE kernel dispatch, kept with that scope.
+// The pair goes to hipExtLaunchKernelGGL, which binds both events to the dispatch itself, so their elapsed time is the
+// kernel's own begin -> end timestamps (the dispatch's completion signal: what rocprofv3 --kernel-trace reports),
+// with none of the dispatch / event-marker time an event BRACKET around the launch contains.
+bool prof_launch_events(hipEvent_t* e0, hipEvent_t* e1);
 int check_launch(const char* what);
 }  // namespace dmvae
+
+// every kernel launch of the library: a plain launch, or -- while bench.py's roofline leg profiles eager steps -- the same
+// launch with its dispatch timestamps captured (never under stream capture: profiling is an eager-mode facility)
+#define DMVAE_LAUNCH(kernel, grid, block, lds, stream, ...)                                                        \
+    do {                                                                                                           \
+        hipEvent_t pe0_ = nullptr, pe1_ = nullptr;                                                                 \
+        if (::dmvae::prof_launch_events(&pe0_, &pe1_))                                                             \
+            hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)(lds), stream, pe0_, pe1_, 0u, __VA_ARGS__);      \
+        else                                                                                                       \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                     \
+    } while (0)
 
 #define DMVAE_REQUIRE(cond, ...)                      \
     do {                                              \

@@ -301,8 +301,8 @@ int conv_first_fwd_launch(hipStream_t s, int dtype, const void* x, int64_t bstri
     if ((ld != 32 && ld != 64) || cout != 32 || H % 4 || n_units >= (1ll << 31)) { set_error("conv_first_fwd: 32 channels, side a multiple of 4 (ld=%d cout=%d H=%d)", ld, cout, H); return DMVAE_EINVAL; }
     ProfScope ps(s, "conv_first_fwd", 2.0 * n_img * H * H * 9 * cout, (double)n_img * H * H * ld * esize(dtype));
     const int nb = (int)std::min<int64_t>((n_units + 63) / 64, 256 * 16);
-    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((conv_first_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, bstride, H, (int)n_units, (const bf16_t*)W, ldw, bias, (bf16_t*)out, ld);
-    else hipLaunchKernelGGL((conv_first_fwd_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)x, bstride, H, (int)n_units, (const float*)W, ldw, bias, (float*)out, ld);
+    if (dtype == DMVAE_BF16) DMVAE_LAUNCH((conv_first_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, bstride, H, (int)n_units, (const bf16_t*)W, ldw, bias, (bf16_t*)out, ld);
+    else DMVAE_LAUNCH((conv_first_fwd_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)x, bstride, H, (int)n_units, (const float*)W, ldw, bias, (float*)out, ld);
     return check_launch("conv_first_fwd");
 }
 
@@ -316,9 +316,9 @@ int conv_first_dw_launch(hipStream_t s, int dtype, const void* x, int64_t bstrid
     ProfScope ps(s, "conv_first_dw", 2.0 * n_img * H * H * 9 * cout, (double)n_img * H * H * ld * esize(dtype));
     const int nb = conv_first_dw_blocks(H, n_img);
     const int upb = (int)((n_units + nb - 1) / nb);
-    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((conv_first_dw_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, bstride, H, (int)n_units, (const bf16_t*)dY, part, upb, ld);
-    else hipLaunchKernelGGL((conv_first_dw_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)x, bstride, H, (int)n_units, (const float*)dY, part, upb, ld);
-    hipLaunchKernelGGL(conv_first_dw_reduce_kernel, dim3(10), dim3(1024), 0, s, (const float*)part, nb, dW, ldw, db);
+    if (dtype == DMVAE_BF16) DMVAE_LAUNCH((conv_first_dw_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, bstride, H, (int)n_units, (const bf16_t*)dY, part, upb, ld);
+    else DMVAE_LAUNCH((conv_first_dw_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)x, bstride, H, (int)n_units, (const float*)dY, part, upb, ld);
+    DMVAE_LAUNCH(conv_first_dw_reduce_kernel, dim3(10), dim3(1024), 0, s, (const float*)part, nb, dW, ldw, db);
     return check_launch("conv_first_dw");
 }
 
@@ -326,8 +326,8 @@ int zero_border_launch(hipStream_t s, int dtype, void* a, int P, int ld, int64_t
     if (ld % 32) { set_error("zero_border: channel stride %d must be a multiple of 32", ld); return DMVAE_EINVAL; }
     const int64_t n = n_img * (4 * P - 4) * (ld / (16 / esize(dtype)));
     ProfScope ps(s, "zero_border", 0.0, (double)n * 16);
-    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((zero_border_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (bf16_t*)a, P, ld, n_img);
-    else hipLaunchKernelGGL((zero_border_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (float*)a, P, ld, n_img);
+    if (dtype == DMVAE_BF16) DMVAE_LAUNCH((zero_border_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (bf16_t*)a, P, ld, n_img);
+    else DMVAE_LAUNCH((zero_border_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (float*)a, P, ld, n_img);
     return check_launch("zero_border");
 }
 
@@ -337,8 +337,8 @@ int maxpool2_fwd_launch(hipStream_t s, int dtype, const void* in, int H, int ld,
     if (ld % 32) { set_error("maxpool2: channel stride %d must be a multiple of 32", ld); return DMVAE_EINVAL; }
     ProfScope ps(s, "maxpool2_fwd", 0.0, ((double)n_img * H * H + n_win) * ld * esize(dtype));
     const int nb = grid_for(n_win * (ld / (16 / esize(dtype))));
-    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((maxpool2_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)in, H, ld, n_win, (bf16_t*)out, out_border);
-    else hipLaunchKernelGGL((maxpool2_fwd_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)in, H, ld, n_win, (float*)out, out_border);
+    if (dtype == DMVAE_BF16) DMVAE_LAUNCH((maxpool2_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)in, H, ld, n_win, (bf16_t*)out, out_border);
+    else DMVAE_LAUNCH((maxpool2_fwd_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)in, H, ld, n_win, (float*)out, out_border);
     return check_launch("maxpool2_fwd");
 }
 
@@ -348,8 +348,8 @@ int maxpool2_bwd_relu_launch(hipStream_t s, int dtype, const void* in, const voi
     if (ld % 32) { set_error("maxpool2: channel stride %d must be a multiple of 32", ld); return DMVAE_EINVAL; }
     ProfScope ps(s, "maxpool2_bwd_relu", 0.0, (2.0 * n_img * H * H + n_win) * ld * esize(dtype));
     const int nb = grid_for(n_win * (ld / (16 / esize(dtype))));
-    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((maxpool2_bwd_relu_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)in, (const bf16_t*)dout, H, ld, n_win, (bf16_t*)din, dout_border);
-    else hipLaunchKernelGGL((maxpool2_bwd_relu_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)in, (const float*)dout, H, ld, n_win, (float*)din, dout_border);
+    if (dtype == DMVAE_BF16) DMVAE_LAUNCH((maxpool2_bwd_relu_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)in, (const bf16_t*)dout, H, ld, n_win, (bf16_t*)din, dout_border);
+    else DMVAE_LAUNCH((maxpool2_bwd_relu_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)in, (const float*)dout, H, ld, n_win, (float*)din, dout_border);
     return check_launch("maxpool2_bwd_relu");
 }
 
@@ -357,8 +357,8 @@ int conv_wflip_launch(hipStream_t s, int dtype, const void* W, int cin, int cin_
     if (Kt < 9 * cout || cin_ld < cin) { set_error("conv_wflip: pads smaller than the kernel"); return DMVAE_EINVAL; }
     ProfScope ps(s, "conv_wflip", 0.0, 2.0 * cin_ld * Kt * esize(dtype));
     const int nb = grid_for((int64_t)cin_ld * Kt);
-    if (dtype == DMVAE_BF16) hipLaunchKernelGGL((conv_wflip_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)W, cin, cin_ld, cout, ldw, (bf16_t*)Wt, Kt);
-    else hipLaunchKernelGGL((conv_wflip_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)W, cin, cin_ld, cout, ldw, (float*)Wt, Kt);
+    if (dtype == DMVAE_BF16) DMVAE_LAUNCH((conv_wflip_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)W, cin, cin_ld, cout, ldw, (bf16_t*)Wt, Kt);
+    else DMVAE_LAUNCH((conv_wflip_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)W, cin, cin_ld, cout, ldw, (float*)Wt, Kt);
     return check_launch("conv_wflip");
 }
 

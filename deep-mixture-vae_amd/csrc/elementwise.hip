@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(AdamArgs a) {
         float4 m = reinterpret_cast<float4*>(a.m)[i];
         float4 v = reinterpret_cast<float4*>(a.v)[i];
         float* pp = &p.x; float* gp = &g.x; float* mp = &m.x; float* vp = &v.x;
-        if (a.pb) {           // bf16 mode: the same arithmetic as the fused dW epilogues (adam_elem<true>)
+        if (a.pb && !a.ieee) {           // bf16 mode: the same arithmetic as the fused dW epilogues (adam_elem<true>)
 #pragma unroll
             for (int j = 0; j < 4; ++j) adam_elem<true>(pp[j], mp[j], vp[j], gp[j], a.gscale, a.b1, a.b2, a.eps, lr_t);
         } else {
@@ -52,11 +52,11 @@ int adam_launch(hipStream_t s, const AdamArgs& a) {
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     ProfScope ps(s, "adam_tf", 12.0 * a.n, (28.0 + (a.pb ? 2.0 : 0.0) + (a.zero_grad ? 4.0 : 0.0)) * a.n);
-    hipLaunchKernelGGL(adam_tf_kernel, dim3(blocks), dim3(256), 0, s, a);
+    DMVAE_LAUNCH(adam_tf_kernel, dim3(blocks), dim3(256), 0, s, a);
     return check_launch("adam_tf");
 }
 int adam_finish_launch(hipStream_t s, void* st) {
-    hipLaunchKernelGGL(adam_finish_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<dmvae_state*>(st));
+    DMVAE_LAUNCH(adam_finish_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<dmvae_state*>(st));
     return check_launch("adam_finish");
 }
 
@@ -113,8 +113,8 @@ int colsum_launch(hipStream_t s, int in_dtype, const void* in, int64_t ld, int M
     const double bytes = (double)M * N * (in_dtype == DMVAE_BF16 ? 2 : 4);
     ProfScope ps(s, "colsum", (double)M * N, bytes);
     if (M <= 64) {
-        if (in_dtype == DMVAE_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(strips, 1), dim3(256), 0, s, (const bf16_t*)in, ld, M, N, M, out, (int64_t)0);
-        else hipLaunchKernelGGL(colsum_kernel<float>, dim3(strips, 1), dim3(256), 0, s, (const float*)in, ld, M, N, M, out, (int64_t)0);
+        if (in_dtype == DMVAE_BF16) DMVAE_LAUNCH(colsum_kernel<bf16_t>, dim3(strips, 1), dim3(256), 0, s, (const bf16_t*)in, ld, M, N, M, out, (int64_t)0);
+        else DMVAE_LAUNCH(colsum_kernel<float>, dim3(strips, 1), dim3(256), 0, s, (const float*)in, ld, M, N, M, out, (int64_t)0);
         return check_launch("colsum");
     }
     if (!ws) { ws = g_colsum_ws; ws_elems = g_colsum_ws_elems; }
@@ -125,9 +125,9 @@ int colsum_launch(hipStream_t s, int in_dtype, const void* in, int64_t ld, int M
         set_error("dmvae_colsum: scratch too small (%lld < %lld); call through a bound plan or with N <= prepared", (long long)ws_elems, (long long)slabs * N);
         return DMVAE_ESTATE;
     }
-    if (in_dtype == DMVAE_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(strips, slabs), dim3(256), 0, s, (const bf16_t*)in, ld, M, N, rps, ws, (int64_t)N);
-    else hipLaunchKernelGGL(colsum_kernel<float>, dim3(strips, slabs), dim3(256), 0, s, (const float*)in, ld, M, N, rps, ws, (int64_t)N);
-    hipLaunchKernelGGL(colsum_kernel<float>, dim3(strips, 1), dim3(256), 0, s, (const float*)ws, (int64_t)N, slabs, N, slabs, out, (int64_t)0);
+    if (in_dtype == DMVAE_BF16) DMVAE_LAUNCH(colsum_kernel<bf16_t>, dim3(strips, slabs), dim3(256), 0, s, (const bf16_t*)in, ld, M, N, rps, ws, (int64_t)N);
+    else DMVAE_LAUNCH(colsum_kernel<float>, dim3(strips, slabs), dim3(256), 0, s, (const float*)in, ld, M, N, rps, ws, (int64_t)N);
+    DMVAE_LAUNCH(colsum_kernel<float>, dim3(strips, 1), dim3(256), 0, s, (const float*)ws, (int64_t)N, slabs, N, slabs, out, (int64_t)0);
     return check_launch("colsum");
 }
 
@@ -161,7 +161,7 @@ int slab_reduce_launch(hipStream_t s, const float* slabs, int64_t n, int nslab, 
     if (n % 4 || stride % 4) { set_error("slab_reduce: sizes must be multiples of 4"); return DMVAE_EINVAL; }
     ProfScope ps(s, "slab_reduce", (double)n * nslab, 4.0 * n * (nslab + 1));
     const int blocks = (int)std::min<int64_t>(4096, (n / 4 + 15) / 16);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(std::max(1, blocks)), dim3(256), 0, s, slabs, n / 4, nslab, stride / 4, out);
+    DMVAE_LAUNCH(slab_reduce_kernel, dim3(std::max(1, blocks)), dim3(256), 0, s, slabs, n / 4, nslab, stride / 4, out);
     return check_launch("slab_reduce");
 }
 
@@ -207,8 +207,8 @@ int recon_launch(hipStream_t s, int act_dtype, int recon_kind, int B, int B_pad,
                  void* dl, int64_t ldd, float* partials) {
     const int nb = recon_nblocks(B_pad, I_pad);
     ProfScope ps(s, "recon_fwd_bwd", 10.0 * B * I, (double)B * I * (8 + (act_dtype == DMVAE_BF16 ? 2 : 4)));
-    if (act_dtype == DMVAE_BF16) hipLaunchKernelGGL(recon_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, recon_kind, B, B_pad, I, I_pad, logits, ldl, x, ldx, inv_B, dl, ldd, partials);
-    else hipLaunchKernelGGL(recon_kernel<float>, dim3(nb), dim3(256), 0, s, recon_kind, B, B_pad, I, I_pad, logits, ldl, x, ldx, inv_B, dl, ldd, partials);
+    if (act_dtype == DMVAE_BF16) DMVAE_LAUNCH(recon_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, recon_kind, B, B_pad, I, I_pad, logits, ldl, x, ldx, inv_B, dl, ldd, partials);
+    else DMVAE_LAUNCH(recon_kernel<float>, dim3(nb), dim3(256), 0, s, recon_kind, B, B_pad, I, I_pad, logits, ldl, x, ldx, inv_B, dl, ldd, partials);
     return check_launch("recon_fwd_bwd");
 }
 
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* rp, int
     }
 }
 int loss_finalize_launch(hipStream_t s, const float* rp, int nr, const float* lp, int nl, float inv_B, void* st, int bump_adam) {
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, rp, nr, lp, nl, inv_B, reinterpret_cast<dmvae_state*>(st), bump_adam);
+    DMVAE_LAUNCH(loss_finalize_kernel, dim3(1), dim3(256), 0, s, rp, nr, lp, nl, inv_B, reinterpret_cast<dmvae_state*>(st), bump_adam);
     return check_launch("loss_finalize");
 }
 
@@ -261,7 +261,7 @@ int step_finalize_launch(hipStream_t s, const float* rp, int nr, const float* lp
                          float b1, float b2, const float* part, int nblk, int ncol, float* gout) {
     ProfScope ps(s, "step_finalize", (double)nblk * ncol, 4.0 * ((double)nblk * ncol + nr + 2.0 * nl));
     const dmvae_finalize_args f = step_finalize_args(rp, nr, lp, nl, inv_B, st, bump_adam, b1, b2, part, nblk, ncol, gout);
-    hipLaunchKernelGGL(step_finalize_kernel, dim3(f.nblocks), dim3(256), 0, s, f);
+    DMVAE_LAUNCH(step_finalize_kernel, dim3(f.nblocks), dim3(256), 0, s, f);
     return check_launch("step_finalize");
 }
 
@@ -306,10 +306,10 @@ int gather_launch(hipStream_t s, int act_dtype, const float* data, int64_t n_row
     if (nb > 2048) nb = 2048;
     ProfScope ps(s, "gather_rows", 0.0, (double)n_valid * dim * (4 + 4 + (act_dtype == DMVAE_BF16 ? 2 : 4)));
     if (act_dtype == DMVAE_BF16)
-        hipLaunchKernelGGL(gather_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, data, n_rows, dim, perm, first, batch, n_valid, B_pad,
+        DMVAE_LAUNCH(gather_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, data, n_rows, dim, perm, first, batch, n_valid, B_pad,
                            (bf16_t*)out_act, ld_act, out_f32, ld_f32, cols_pad, (const dmvae_state*)st);
     else
-        hipLaunchKernelGGL(gather_kernel<float>, dim3(nb), dim3(256), 0, s, data, n_rows, dim, perm, first, batch, n_valid, B_pad,
+        DMVAE_LAUNCH(gather_kernel<float>, dim3(nb), dim3(256), 0, s, data, n_rows, dim, perm, first, batch, n_valid, B_pad,
                            (float*)out_act, ld_act, out_f32, ld_f32, cols_pad, (const dmvae_state*)st);
     return check_launch("gather_rows");
 }
@@ -325,7 +325,7 @@ __global__ void spin_kernel(unsigned long long ticks) {
 int spin_launch(hipStream_t s, int us) {
     if (us < 0) us = 0;
     if (us > 20000) us = 20000;
-    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, s, (unsigned long long)us * 100ull);
+    DMVAE_LAUNCH(spin_kernel, dim3(1), dim3(1), 0, s, (unsigned long long)us * 100ull);
     return check_launch("spin");
 }
 
@@ -338,7 +338,7 @@ int philox_launch(hipStream_t s, float* out, int64_t n, uint64_t seed, uint64_t 
     int nb = (int)((n + 255) / 256);
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(philox_kernel, dim3(nb), dim3(256), 0, s, out, n, seed, step, sid, gumbel);
+    DMVAE_LAUNCH(philox_kernel, dim3(nb), dim3(256), 0, s, out, n, seed, step, sid, gumbel);
     return check_launch("philox");
 }
 
@@ -358,8 +358,8 @@ int cast_launch(hipStream_t s, const void* in, void* out, int64_t n, int to_bf16
     int nb = (int)((n / 4 + 255) / 256);
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
-    if (to_bf16) hipLaunchKernelGGL(cast_f2b_kernel, dim3(nb), dim3(256), 0, s, (const float*)in, (bf16_t*)out, n);
-    else hipLaunchKernelGGL(cast_b2f_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)in, (float*)out, n);
+    if (to_bf16) DMVAE_LAUNCH(cast_f2b_kernel, dim3(nb), dim3(256), 0, s, (const float*)in, (bf16_t*)out, n);
+    else DMVAE_LAUNCH(cast_b2f_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)in, (float*)out, n);
     return check_launch("cast");
 }
 

@@ -635,7 +635,7 @@ template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4>
 static int launch(hipStream_t s, const GemmArgs& a, int split) {
     dim3 grid((a.M / BM) * (a.N / BN), split);
     ProfScope ps(s, kernel_name<BM, BN, LAYOUT, EPI, NSTAGE, NW>(false), 2.0 * a.M * a.N * (double)a.K, gemm_bytes(a));
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, LAYOUT, EPI, NSTAGE, NW>), grid, dim3(64 * NW), 0, s, a);
+    DMVAE_LAUNCH((gemm_bf16_kernel<BM, BN, LAYOUT, EPI, NSTAGE, NW>), grid, dim3(64 * NW), 0, s, a);
     return check_launch("gemm_bf16");
 }
 
@@ -651,7 +651,7 @@ static int launch_conv(hipStream_t s, const GemmArgs& a, int split) {
     const double P = a.conv_p, inner = (P - 2.0) * (P - 2.0) / (P * P), nv = a.epi.n_valid > 0 ? a.epi.n_valid : a.N;
     const double fl = 2.0 * (LAYOUT == DMVAE_GEMM_DW ? (double)a.K : (double)a.M) * inner * 9.0 * a.conv_c * nv;
     ProfScope ps(s, nm.c_str(), fl, gemm_bytes(a, LAYOUT));
-    hipLaunchKernelGGL((gemm_bf16_conv_kernel<BM, BN, LAYOUT, EPI, NSTAGE, NW>), grid, dim3(64 * NW), 0, s, a);
+    DMVAE_LAUNCH((gemm_bf16_conv_kernel<BM, BN, LAYOUT, EPI, NSTAGE, NW>), grid, dim3(64 * NW), 0, s, a);
     return check_launch("gemm_bf16_conv");
 }
 
@@ -769,11 +769,11 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
     // (8-wave workgroups in the grouped grids were measured too: 0.3071 vs 0.3014 ms/step, not kept)
     if constexpr (LAYOUT != DMVAE_GEMM_DW) {
         if (shortk) {
-            hipLaunchKernelGGL((gemm_bf16_grouped_kernel<64, 64, LAYOUT, EPI, 2, 4, true>), dim3(total + extra), dim3(256), 0, s, g);
+            DMVAE_LAUNCH((gemm_bf16_grouped_kernel<64, 64, LAYOUT, EPI, 2, 4, true>), dim3(total + extra), dim3(256), 0, s, g);
             return check_launch("gemm_bf16_grouped");
         }
     }
-    hipLaunchKernelGGL((gemm_bf16_grouped_kernel<64, 64, LAYOUT, EPI, 4, 4>), dim3(total + extra), dim3(256), 0, s, g);
+    DMVAE_LAUNCH((gemm_bf16_grouped_kernel<64, 64, LAYOUT, EPI, 4, 4>), dim3(total + extra), dim3(256), 0, s, g);
     return check_launch("gemm_bf16_grouped");
 }
 
@@ -843,7 +843,7 @@ int gemm_bf16_grouped_dw_adam(hipStream_t s, const GemmArgs* probs, int nprob, c
         AdamArgs a;
         a.n = ctx.seg_n; a.p = ctx.param + ctx.seg_off; a.g = ctx.grad + ctx.seg_off; a.m = ctx.m + ctx.seg_off; a.v = ctx.v + ctx.seg_off;
         a.pb = ctx.param_bf16 ? reinterpret_cast<bf16_t*>(ctx.param_bf16) + ctx.seg_off : nullptr;
-        a.lr = 0.f; a.b1 = ctx.beta1; a.b2 = ctx.beta2; a.eps = ctx.epsilon; a.gscale = ctx.grad_scale; a.zero_grad = 0;
+        a.lr = 0.f; a.b1 = ctx.beta1; a.b2 = ctx.beta2; a.eps = ctx.epsilon; a.gscale = ctx.grad_scale; a.zero_grad = 0; a.ieee = ctx.ieee;
         a.t_host = ~0ull; a.st = reinterpret_cast<const dmvae_state*>(ctx.state);
         return adam_launch(s, a);
     }
@@ -1018,7 +1018,7 @@ static int launch_gather(hipStream_t s, const GemmArgs& a, const GatherSrc& g) {
     const int riders = std::max(64, std::min(256, 512 - std::min(ntiles, 512)));
     ProfScope ps(s, "gemm_bf16_gather_kernel", 2.0 * a.M * a.N * (double)a.K,
                  gemm_bytes(a) + (double)g.n_valid * g.dim * 4.0 + (double)g.B_pad * g.cols_pad * 6.0);
-    hipLaunchKernelGGL((gemm_bf16_gather_kernel<BM, BN, NSTAGE, NW>), dim3(ntiles + riders), dim3(64 * NW), 0, s, a, g, ntiles);
+    DMVAE_LAUNCH((gemm_bf16_gather_kernel<BM, BN, NSTAGE, NW>), dim3(ntiles + riders), dim3(64 * NW), 0, s, a, g, ntiles);
     return check_launch("gemm_bf16_gather");
 }
 
@@ -1115,7 +1115,7 @@ int chain_probe_launch(hipStream_t s, int variant, int nlayer, const GemmArgs* l
     }
     hipError_t e = hipMemsetAsync(sync, 0, sizeof(unsigned) * (16 + 64 * 8), s);
     if (e != hipSuccess) { set_error("chain probe: memset: %s", hipGetErrorString(e)); return (int)e; }
-    hipLaunchKernelGGL((chain_probe_kernel<128, 64, 3, 8>), dim3(256), dim3(512), 0, s, c);
+    DMVAE_LAUNCH((chain_probe_kernel<128, 64, 3, 8>), dim3(256), dim3(512), 0, s, c);
     return check_launch("chain_probe");
 }
 

@@ -49,9 +49,13 @@ namespace dmvae {
 #ifndef DMVAE_ABLATE
 #define DMVAE_ABLATE 0
 #endif
-#if DMVAE_ABLATE == 6      // tools/anatomy256.py: per workgroup {entry, K loop done, epilogue done, HW_ID << 32 | XCC_ID} (100 MHz ticks)
-__device__ unsigned long long g_anat256[4096 * 4];
-#define ANAT256(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_anat256[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#if DMVAE_ABLATE == 6      // tools/anatomy256.py, tools/clock256.py: per workgroup {entry, K loop done, epilogue done (100 MHz ticks, s_memrealtime),
+                           // HW_ID << 32 | XCC_ID, entry, K loop done (shader cycles, s_memtime), 0, 0}: the clock the chip holds in the K loop is
+                           // (slot 5 - slot 4) / (slot 1 - slot 0) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).  The stamps go to this
+                           // table only; no output is computed from them; the product build executes none of them.
+__device__ unsigned long long g_anat256[4096 * 8];
+#define ANAT256(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) { g_anat256[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+                        if ((i) < 2) g_anat256[blockIdx.x * 8 + 4 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define ANAT256(i) do { } while (0)
 #endif
@@ -345,7 +349,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& a, const dmvae_adam
     __syncthreads();
     ANAT256(2);
     if (threadIdx.x == 0 && blockIdx.x < 4096)
-        g_anat256[blockIdx.x * 4 + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);
+        g_anat256[blockIdx.x * 8 + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);
 #endif
 }
 
@@ -456,7 +460,7 @@ static int launch256(hipStream_t s, const GemmArgs& a0, const dmvae_adam_ctx* ct
             cb.n = 1; cb.rows = a.K; cb.rows_per_slab = rps; cb.xb[0] = 0; cb.xb[1] = (a.N + 511) / 512;
             cb.in[0] = reinterpret_cast<const bf16_t*>(a.B); cb.ld[0] = a.ldb; cb.N[0] = a.N; cb.part[0] = ws;
             ProfScope ps(s, "colsum_slabs", (double)a.K * a.N, 2.0 * a.K * a.N + 4.0 * nslab * a.N);
-            hipLaunchKernelGGL(colsum_slabs_kernel, dim3(cb.xb[1], nslab), dim3(256), 0, s, cb);
+            DMVAE_LAUNCH(colsum_slabs_kernel, dim3(cb.xb[1], nslab), dim3(256), 0, s, cb);
         }
         bs.part = ws; bs.nslab = nslab; bs.n = a.N; bs.out = reinterpret_cast<float*>(a.epi.out2);
         extra = std::min(8, (a.N / 4 + 511) / 512);
@@ -470,7 +474,7 @@ static int launch256(hipStream_t s, const GemmArgs& a0, const dmvae_adam_ctx* ct
     if (EPI == DMVAE_EPI_ADAM) bytes += ((double)a.M * a.N + (double)bs.n) * (24.0 + (c.param_bf16 ? 2.0 : 0.0) + (c.store_grad ? 4.0 : 0.0));
     else bytes += ((EPI == DMVAE_EPI_STORE_F32) ? 4.0 : 2.0) * a.M * a.N;
     ProfScope ps(s, nm.c_str(), 2.0 * a.M * a.N * (double)a.K, bytes);
-    hipLaunchKernelGGL((gemm_bf16_256_kernel<LAYOUT, EPI>), dim3(tiles + extra), dim3(512), 0, s, a, c, tiles, bs);
+    DMVAE_LAUNCH((gemm_bf16_256_kernel<LAYOUT, EPI>), dim3(tiles + extra), dim3(512), 0, s, a, c, tiles, bs);
     return check_launch("gemm_bf16_256");
 }
 
@@ -508,7 +512,7 @@ static int launch256_dw_multi(hipStream_t s, const GemmArgs* probs, int n, const
     for (int i = n; i <= MULTI_MAX; ++i) { m.start[i] = total; m.extra[i] = extra; }
     static const std::string nm = std::string("gemm_bf16_256_dw_multi_kernel<") + std::to_string(EPI) + ">";
     ProfScope ps(s, nm.c_str(), flops, bytes);
-    hipLaunchKernelGGL((gemm_bf16_256_dw_multi_kernel<EPI>), dim3(total + extra), dim3(512), 0, s, m);
+    DMVAE_LAUNCH((gemm_bf16_256_dw_multi_kernel<EPI>), dim3(total + extra), dim3(512), 0, s, m);
     return check_launch("gemm_bf16_256_dw_multi");
 }
 bool gemm_bf16_256_rides() { return g_policy256 >= 1 && g_stagger >= 0; }
@@ -534,7 +538,7 @@ static int colsum_slabs_batch(hipStream_t s, GemmArgs* const* probs, int n) {
         }
         cb.n = cnt;
         ProfScope ps(s, "colsum_slabs", work, bytes);
-        hipLaunchKernelGGL(colsum_slabs_kernel, dim3(cb.xb[cnt], nslab), dim3(256), 0, s, cb);
+        DMVAE_LAUNCH(colsum_slabs_kernel, dim3(cb.xb[cnt], nslab), dim3(256), 0, s, cb);
         const int rc = check_launch("colsum_slabs");
         if (rc) return rc;
         lo += cnt;

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
 template <int LAYOUT, int EPI>
 static int launch(hipStream_t s, const GemmArgs& a, int split) {
     dim3 grid((a.M / FBM) * (a.N / FBN), split);
-    hipLaunchKernelGGL((gemm_f32_kernel<LAYOUT, EPI>), grid, dim3(256), 0, s, a);
+    DMVAE_LAUNCH((gemm_f32_kernel<LAYOUT, EPI>), grid, dim3(256), 0, s, a);
     return check_launch("gemm_f32");
 }
 

@@ -142,7 +142,7 @@ __device__ __forceinline__ void adam_quad(const dmvae_adam_ctx& c, int64_t off, 
     float* pp = &p.x; float* mp = &m.x; float* vp = &v.x;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (c.param_bf16) adam_elem<true>(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);       // (wave-uniform: the arithmetic follows the mode, see adam_elem)
+        if (c.param_bf16 && !c.ieee) adam_elem<true>(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);       // (wave-uniform: the arithmetic follows the mode, see adam_elem)
         else adam_elem<false>(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);
     }
     *reinterpret_cast<float4*>(c.param + off) = p;
@@ -181,7 +181,7 @@ __device__ __forceinline__ void adam_quads(const dmvae_adam_ctx& c, const unsign
         float* pp = &p[b].x; float* mp = &m[b].x; float* vp = &v[b].x;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (c.param_bf16) adam_elem<true>(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);       // (wave-uniform: the arithmetic follows the mode, see adam_elem)
+            if (c.param_bf16 && !c.ieee) adam_elem<true>(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);       // (wave-uniform: the arithmetic follows the mode, see adam_elem)
             else adam_elem<false>(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);
         }
         *reinterpret_cast<float4*>(c.param + off[b]) = p[b];
@@ -227,7 +227,7 @@ __device__ __forceinline__ void adam_pipelined(const dmvae_adam_ctx& c, OFF&& of
             float* pp = &p[buf][b].x; float* mp = &m[buf][b].x; float* vp = &v[buf][b].x;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (c.param_bf16) adam_elem<true>(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);       // (wave-uniform: the arithmetic follows the mode, see adam_elem)
+                if (c.param_bf16 && !c.ieee) adam_elem<true>(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);       // (wave-uniform: the arithmetic follows the mode, see adam_elem)
                 else adam_elem<false>(pp[j], mp[j], vp[j], g[j], c.grad_scale, c.beta1, c.beta2, c.epsilon, lr_t);
             }
             *reinterpret_cast<float4*>(c.param + o) = p[buf][b];

@@ -9,6 +9,7 @@ struct AdamArgs {
     float* p; float* g; float* m; float* v; bf16_t* pb;
     float lr, b1, b2, eps, gscale;
     int zero_grad;
+    int ieee;               // bf16 mode with the IEEE square root and division (dmvae_config.adam_ieee)
     uint64_t t_host;
     const dmvae_state* st;
 };

@@ -496,7 +496,7 @@ static void latent_launch_t(hipStream_t s, const LatentLaunch& L, int nblk, size
         static bool set = false;
         if (!set) { (void)hipFuncSetAttribute((const void*)latent_fwd_kernel<MODE, DSL>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set = true; }
     }
-    hipLaunchKernelGGL((latent_fwd_kernel<MODE, DSL>), dim3(nblk), dim3(256), lb, s, L);
+    DMVAE_LAUNCH((latent_fwd_kernel<MODE, DSL>), dim3(nblk), dim3(256), lb, s, L);
 }
 
 int latent_launch(hipStream_t s, const dmvae_latent_args* a) {

@@ -318,7 +318,7 @@ int latent_mfma_launch(hipStream_t s, const dmvae_latent_args* a, float* ws, int
     const double BD = (double)a->B * a->D, BK = (double)a->B * a->K;
     {   // the prior-table operands ride as Kp extra workgroups of the row kernel (one launch less)
         ProfScope ps(s, "latent_pre", 0.0, 4.0 * (BD * (2.0 + (a->eps ? 1.0 : 0.0) + 2.0 + 2.0 + 1.0) + BK * 3.0) + 16.0 * a->K * a->D);
-        hipLaunchKernelGGL(latent_pre_kernel, dim3(nrb + w.Kp), dim3(256), 0, s, L, nrb);
+        DMVAE_LAUNCH(latent_pre_kernel, dim3(nrb + w.Kp), dim3(256), 0, s, L, nrb);
     }
     int rc = check_launch("latent_pre");
     if (rc) return rc;
@@ -332,7 +332,7 @@ int latent_mfma_launch(hipStream_t s, const dmvae_latent_args* a, float* ws, int
     {
         const int extra = (int)std::min<int64_t>(256, ((int64_t)a->K * a->D + 255) / 256);
         ProfScope ps(s, "latent_post", 0.0, 4.0 * (BD * (2.0 + 1.0 + 1.0 + 2.0) + BK * 3.0) + 4.0 * w.nsplit * w.Kp * w.XW);
-        hipLaunchKernelGGL(latent_post_kernel, dim3(nrb + extra), dim3(256), 0, s, L, nrb);
+        DMVAE_LAUNCH(latent_post_kernel, dim3(nrb + extra), dim3(256), 0, s, L, nrb);
     }
     return check_launch("latent_post");
 }

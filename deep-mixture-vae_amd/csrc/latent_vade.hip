@@ -186,7 +186,7 @@ int latent_vade_launch(hipStream_t s, const dmvae_latent_args* a) {
     }
     const int nblk = a->B_pad / 16;
     ProfScope ps(s, "latent_vade", 14.0 * a->B * (double)a->K * a->D, 4.0 * ((double)a->B * (7.0 * a->D + a->K) + 2.0 * a->K * a->D * (nblk + 1)));
-    hipLaunchKernelGGL(latent_vade_kernel, dim3(nblk), dim3(256), lb, s, *a);
+    DMVAE_LAUNCH(latent_vade_kernel, dim3(nblk), dim3(256), lb, s, *a);
     return check_launch("latent_vade");
 }
 

@@ -154,7 +154,7 @@ int mid_bwd_launch(hipStream_t s, const MidBwdArgs& a0) {
     const double flops = 2.0 * a.Bp * ((double)a.Dp * a.N0 + (double)a.Hp * (2 * a.Dp + a.Kp));
     const double bytes = 2.0 * a.Bp * ((double)a.N0 + 4.0 * a.Hp + 2.0 * a.Dp + a.Kp) + 12.0 * a.Bp * a.Dp;
     ProfScope ps(s, "mid_bwd", flops, bytes);
-    hipLaunchKernelGGL(mid_bwd_kernel, dim3(a.nrow_blocks + a.fin.nblocks), dim3(256), lds, s, a);
+    DMVAE_LAUNCH(mid_bwd_kernel, dim3(a.nrow_blocks + a.fin.nblocks), dim3(256), lds, s, a);
     return check_launch("mid_bwd");
 }
 

@@ -16,7 +16,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DMVAE_HIP_LIB: another build of the SAME library (e.g. a measurement variant from tools/ablate.sh)
 LIB_PATH = os.environ.get("DMVAE_HIP_LIB") or os.path.join(_HERE, "libdmvae_hip.so")
 
+ABI_VERSION = 2          # DMVAE_ABI_VERSION of include/dmvae_hip.h
 F32, BF16 = 0, 1
+ADAM_ZERO_GRAD, ADAM_IEEE = 1, 2
 GEMM_FWD, GEMM_DX, GEMM_DW = 0, 1, 2
 (EPI_BIAS_RELU, EPI_BIAS_F32, EPI_BIAS_RECON, EPI_RELU_MASK, EPI_LATENT,
  EPI_STORE_F32, EPI_ATOMIC_F32, EPI_BIAS_SIGMOID, EPI_ADAM) = range(9)
@@ -62,7 +64,7 @@ class AdamCtx(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
                 ("param_bf16", C.c_void_p), ("state", C.c_void_p),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("epsilon", C.c_float), ("grad_scale", C.c_float),
-                ("store_grad", C.c_int32), ("reserved", C.c_int32), ("seg_off", C.c_int64), ("seg_n", C.c_int64)]
+                ("store_grad", C.c_int32), ("ieee", C.c_int32), ("seg_off", C.c_int64), ("seg_n", C.c_int64)]
 
 
 class LatentArgs(C.Structure):
@@ -107,7 +109,7 @@ class Config(C.Structure):
         ("input_type", C.c_int32), ("dtype", C.c_int32), ("max_batch", C.c_int32), ("mode", C.c_int32),
         ("temperature", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
         ("seed", C.c_uint64), ("deterministic", C.c_int32), ("trunk", C.c_int32),
-        ("model", C.c_int32), ("reserved", C.c_int32),
+        ("model", C.c_int32), ("adam_ieee", C.c_int32),
     ]
 
 
@@ -128,7 +130,7 @@ class Buffers(C.Structure):
 
 class ProfRow(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double),
-                ("flops", C.c_double), ("bytes", C.c_double)]
+                ("flops", C.c_double), ("bytes", C.c_double), ("kernel_ms", C.c_double), ("kernel_launches", C.c_int64)]
 
 
 def _load():
@@ -196,6 +198,10 @@ def _load():
     lib.dmvae_last_error.restype = C.c_char_p
     lib.dmvae_latent_ws_bytes.restype = C.c_int64
     lib.dmvae_plan_destroy.restype = None
+    got = lib.dmvae_abi_version()
+    if got != ABI_VERSION:       # the public structs grew between versions: a mismatched pair would read past them
+        raise ImportError("%s reports ABI version %d, this binding is written against %d (include/dmvae_hip.h): rebuild it with "
+                          "`python deep-mixture-vae_amd/build.py`" % (LIB_PATH, got, ABI_VERSION))
     return lib
 
 

@@ -107,7 +107,7 @@ class StepEngine:
     def __init__(self, input_dim, latent_dim, n_classes, enc_layers=(500, 500), head_dim=2000,
                  dec_layers=(2000, 500, 500), input_type="binary", dtype="bf16", max_batch=100,
                  mode="exact", temperature=1.0, seed=0, deterministic=False, session=None,
-                 beta1=0.9, beta2=0.999, adam_eps=1e-8, cnn=False, model="dmvae"):
+                 beta1=0.9, beta2=0.999, adam_eps=1e-8, cnn=False, model="dmvae", adam_ieee=False):
         self.cnn = bool(cnn)
         self.model = model
         if model not in ("dmvae", "vade"):
@@ -142,6 +142,10 @@ class StepEngine:
         cfg.deterministic = 1 if deterministic else 0
         cfg.trunk = _lib.TRUNK_CNN if self.cnn else _lib.TRUNK_MLP
         cfg.model = _lib.MODEL_VADE if model == "vade" else _lib.MODEL_DMVAE
+        # bf16 plans: TF-Adam's quotient with the IEEE square root and division (the fp32 mode's arithmetic) instead of the
+        # hardware v_sqrt_f32 / v_rcp_f32 (1 ulp each, the default)
+        self.adam_ieee = bool(adam_ieee)
+        cfg.adam_ieee = 1 if adam_ieee else 0
         self._cfg = cfg
         h = C.c_void_p()
         check(lib.dmvae_plan_create(C.byref(cfg), C.byref(h)), "dmvae_plan_create")
@@ -633,5 +637,6 @@ def prof_collect(max_rows=64):
     for i in range(n):
         r = rows[i]
         out.append(dict(name=r.name.decode(), launches=int(r.launches), total_ms=float(r.total_ms),
-                        flops=float(r.flops), bytes=float(r.bytes)))
+                        flops=float(r.flops), bytes=float(r.bytes), kernel_ms=float(r.kernel_ms),
+                        kernel_launches=int(r.kernel_launches)))
     return out

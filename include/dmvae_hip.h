@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define DMVAE_ABI_VERSION 1
+/* 2: dmvae_buffers.arena_elems, dmvae_config.model, dmvae_latent_args.mfma_ws(_bytes), dmvae_config.adam_ieee and
+ *    dmvae_prof_row.kernel_ms were added after version 1; a client compiled against an older header passes shorter
+ *    structs, so every binding checks dmvae_abi_version() == DMVAE_ABI_VERSION when it loads the library. */
+#define DMVAE_ABI_VERSION 2
 
 enum { DMVAE_F32 = 0, DMVAE_BF16 = 1 };
 
@@ -129,7 +132,8 @@ typedef struct dmvae_adam_ctx {
     const void* state;         /* dmvae_state: lr and adam_t                                  */
     float beta1, beta2, epsilon, grad_scale;
     int32_t store_grad;        /* also write the gradients to `grad`                          */
-    int32_t reserved;
+    int32_t ieee;              /* bf16 mode: 1 = IEEE square root and division in the update quotient (as fp32 mode),
+                                * 0 = the hardware v_sqrt_f32 / v_rcp_f32 (1 ulp each; dmvae_adam_tf below)      */
     int64_t seg_off, seg_n;
 } dmvae_adam_ctx;
 int dmvae_gemm_grouped_dw_adam(void* stream, const dmvae_gemm_problem* probs, int n, const dmvae_adam_ctx* ctx);
@@ -214,16 +218,18 @@ int dmvae_loss_finalize(void* stream, const float* recon_partials, int n_recon,
 /* ---- TF-1.x Adam on a flat arena (tf.train.AdamOptimizer, base_models.py:95-110)
  * lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t*m/(sqrt(v)+eps).  t = state->adam_t+1
  * (or t_host when state is NULL).  grad is multiplied by grad_scale first (1/world).
- * Optionally refreshes a bf16 shadow of the parameters and zeroes grad.
+ * Optionally refreshes a bf16 shadow of the parameters and zeroes grad (flags & DMVAE_ADAM_ZERO_GRAD).
  * Arithmetic follows the mode: param_bf16 == NULL (fp32 parity mode) -> IEEE sqrt and division; param_bf16 != NULL (bf16
  * throughput mode, where the forward pass reads the 8-bit-mantissa shadow) -> the quotient lr_t*m / (sqrt(v)+eps) with
  * the hardware square root and reciprocal (1 ulp each), exactly as the fused dW + Adam epilogues of that mode compute it
- * (DMVAE_EPI_ADAM: bit-identical to this kernel on the same inputs).
+ * (DMVAE_EPI_ADAM: bit-identical to this kernel on the same inputs); flags & DMVAE_ADAM_IEEE keeps IEEE there too.
  * dmvae_adam_finish bumps state->adam_t (separate 1-thread kernel so that all
  * chunks of one update see the same t). */
+#define DMVAE_ADAM_ZERO_GRAD 1
+#define DMVAE_ADAM_IEEE 2
 int dmvae_adam_tf(void* stream, int64_t n, float* param, float* grad, float* m, float* v,
                   void* param_bf16, float lr, float beta1, float beta2, float epsilon,
-                  float grad_scale, int zero_grad, uint64_t t_host, const void* state);
+                  float grad_scale, int flags, uint64_t t_host, const void* state);
 int dmvae_adam_finish(void* stream, void* state);
 
 /* ---- batch assembly (Dataset.get_batches, includes/utils.py:449-463) -----
@@ -279,7 +285,9 @@ typedef struct dmvae_config {
     int32_t deterministic;                           /* 1: no float atomics anywhere             */
     int32_t trunk;                                   /* DMVAE_TRUNK_MLP (default) or DMVAE_TRUNK_CNN */
     int32_t model;                                   /* DMVAE_MODEL_DMVAE (default) or DMVAE_MODEL_VADE */
-    int32_t reserved;
+    int32_t adam_ieee;                               /* bf16 plans: 1 = TF-Adam with the IEEE square root and division (exactly the
+                                                      * fp32 mode's arithmetic on the fp32 master weights); 0 (default) = hardware
+                                                      * sqrt / reciprocal, 1 ulp each (-0.06 ms at cfg5)                */
 } dmvae_config;
 
 typedef struct dmvae_tensor_info {
@@ -367,57 +375,8 @@ int dmvae_plan_decode(dmvae_plan* p, void* stream, const float* Z, int64_t ldz, 
  * returns the device pointer, leading dimension (elements) and dtype. */
 int dmvae_plan_view(const dmvae_plan* p, const char* name, void** ptr, int64_t* ld, int32_t* dtype);
 
-/* ---- per-kernel timing with HIP events (bench.py roofline leg) ----------
- * enable(1): every launch made through this library is bracketed by a
- * hipEvent pair on its stream.  collect() synchronises those events and
- * returns, per kernel family, launches / total ms / algorithmic flops / bytes. */
-typedef struct dmvae_prof_row {
-    char name[48];
-    int64_t launches;
-    double total_ms;
-    double flops;   /* algorithmic */
-    double bytes;   /* algorithmic */
-} dmvae_prof_row;
-int dmvae_prof_enable(int on);
-/* keeps `stream` busy for ~microseconds (<= 20 ms) so the host can run ahead of the GPU and the
- * event brackets of the following launches contain no host launch latency */
-int dmvae_debug_spin(void* stream, int microseconds);
-int dmvae_prof_collect(dmvae_prof_row* rows, int max_rows);   /* returns number of rows */
-/* measurement builds only (tools/ablate.sh 6): device pointer of the per-workgroup stamp table of the
- * grouped GEMM kernel, 2048 x {start, end (100 MHz ticks), HW_ID<<32 | XCC_ID, layout<<32 | tile kind};
- * the product library never writes it */
-int dmvae_debug_stamps(void** device_ptr);
-/* DMVAE_ABLATE=6 builds: per-workgroup phase stamps of the last small-tile bf16 GEMM launch, 2048 x 8 uint64 (100 MHz ticks):
- * {entry, first K tile landed, K loop done, epilogue issued, stores acknowledged, HW_ID << 32 | XCC_ID} (tools/anatomy.py) */
-int dmvae_debug_anatomy(void** device_ptr);
-/* likewise for the last 256x256 macro-tile launch: 4096 x 4 uint64 {entry, K loop done, epilogue done, HW_ID << 32 | XCC_ID} (tools/anatomy256.py) */
-int dmvae_debug_anatomy256(void** device_ptr);
-/* probe (tools/chain_probe.py): nlayer (1..8) square bias + ReLU layers [M x N] x [N x N] (bf16, M % 1024 == 0, N % 64 == 0)
- * as ONE launch in which the workgroups of a physical XCD own one eighth of the rows through every layer; layer l reads
- * act[l % 2] and writes act[(l + 1) % 2].  variant 0: L1 invalidate between layers, 1: agent-scope fences.  sync: 2112 B of
- * device scratch (zeroed by the call); *err (device int, zeroed by the caller) != 0 when a bounded wait gave up. */
-int dmvae_debug_chain(void* stream, int variant, int nlayer, int M, int N, void* act0, void* act1,
-                      const void* const* W, const float* const* bias, void* sync, int* err);
-
-/* tuning aid: force the bf16 GEMM tile (64|128 x 64|128); (0,0) restores the heuristic */
-int dmvae_debug_set_tile(int bm, int bn);
-/* tuning aid: knob 0 = supertile height (tile rows) of the L2-friendly tile order,
- *             knob 1 = 8-wave workgroups for the 128-row tiles (0|1),
- *             knob 2 = per-problem tile shapes in the grouped dW grid (0 = all 64x64, 1 = planned, 2 = largest),
- *             knob 3 = ring depth policy (-1 deep ring when <= 1 workgroup per CU, 0 never, 1 always),
- *             knob 4 = XCD runs of a grouped grid cut per tile-shape class (1) or per problem (0),
- *             knob 5 = conv-mode tiles: >= 1 short-K tiles as 4-wave / 2-slot workgroups (three per CU),
- *                      2 also 3-slot rings for the 64x64 weight-gradient tiles,
- *             knob 6 = 256x256 macro-tile kernel (csrc/gemm_bf16_256.hip): 0 never, 1 when its grid covers the chip
- *                      (default), 2 whenever M and N divide by 256,
- *             knob 7 = problems with K <= 128 as 64x64 tiles on a 2-slot ring (32 KiB: four to five workgroups per CU) (0|1;
- *                      default 0: measured slower on the whole step),
- *             knob 8 = merged weight-gradient grid of the 256x256 kernel: first-tile delay, units of 3.4 us spread over the
- *                      256 CUs (default 0 = none, measured best; -1 = one launch per problem),
- *             knob 9 = the narrow middle of the backward pass (dZ GEMM + latent epilogue + both head dX GEMMs) as one kernel over
- *                      16-row blocks, csrc/mid_bwd.hip (0|1) */
-int dmvae_debug_set_knob(int which, int value);
-
+/* Measurement and tuning entry points (per-kernel timing for bench.py's roofline leg, probes, tile knobs) are
+ * declared in dmvae_hip_debug.h: exported by the same library, not part of the drop-in boundary. */
 int dmvae_abi_version(void);
 const char* dmvae_last_error(void);
 

@@ -1,0 +1,76 @@
+/*
+ * dmvae_hip_debug.h -- measurement and tuning entry points of libdmvae_hip.so.
+ *
+ * NOT part of the drop-in boundary (include/dmvae_hip.h): nothing here replaces a line of the reference.
+ * bench.py's roofline leg uses dmvae_prof_* / dmvae_debug_spin; tools/ uses the probes and knobs.
+ */
+#ifndef DMVAE_HIP_DEBUG_H
+#define DMVAE_HIP_DEBUG_H
+
+#include "dmvae_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- per-kernel timing with HIP events (bench.py roofline leg) ----------
+ * enable(1): every launch made through this library is bracketed by a
+ * hipEvent pair on its stream AND issued through hipExtLaunchKernelGGL with an
+ * event pair bound to the dispatch itself.  collect() synchronises those events and
+ * returns, per kernel family, launches / bracket ms / kernel ms / algorithmic flops / bytes.
+ * Eager launches only (not under stream capture). */
+typedef struct dmvae_prof_row {
+    char name[48];
+    int64_t launches;          /* profiled scopes (one per library call that launches this kernel family)       */
+    double total_ms;           /* event BRACKETS around them: kernel + its dispatch / event markers              */
+    double flops;   /* algorithmic */
+    double bytes;   /* algorithmic */
+    double kernel_ms;          /* the kernels' own begin -> end (the pair hipExtLaunchKernelGGL binds to a       */
+    int64_t kernel_launches;   /* dispatch = what rocprofv3 --kernel-trace reports), and how many dispatches;    */
+                               /* 0 when the runtime returned no dispatch timestamps                              */
+} dmvae_prof_row;
+int dmvae_prof_enable(int on);
+/* keeps `stream` busy for ~microseconds (<= 20 ms) so the host can run ahead of the GPU and the
+ * event brackets of the following launches contain no host launch latency */
+int dmvae_debug_spin(void* stream, int microseconds);
+int dmvae_prof_collect(dmvae_prof_row* rows, int max_rows);   /* returns number of rows */
+/* measurement builds only (tools/ablate.sh 6): device pointer of the per-workgroup stamp table of the
+ * grouped GEMM kernel, 2048 x {start, end (100 MHz ticks), HW_ID<<32 | XCC_ID, layout<<32 | tile kind};
+ * the product library never writes it */
+int dmvae_debug_stamps(void** device_ptr);
+/* DMVAE_ABLATE=6 builds: per-workgroup phase stamps of the last small-tile bf16 GEMM launch, 2048 x 8 uint64 (100 MHz ticks):
+ * {entry, first K tile landed, K loop done, epilogue issued, stores acknowledged, HW_ID << 32 | XCC_ID} (tools/anatomy.py) */
+int dmvae_debug_anatomy(void** device_ptr);
+/* likewise for the last 256x256 macro-tile launch: 4096 x 8 uint64 {entry, K loop done, epilogue done (100 MHz ticks), HW_ID << 32 | XCC_ID,
+ * entry, K loop done (shader cycles, s_memtime), 0, 0} (tools/anatomy256.py; tools/clock256.py: the clock held inside the K loop) */
+int dmvae_debug_anatomy256(void** device_ptr);
+/* probe (tools/chain_probe.py): nlayer (1..8) square bias + ReLU layers [M x N] x [N x N] (bf16, M % 1024 == 0, N % 64 == 0)
+ * as ONE launch in which the workgroups of a physical XCD own one eighth of the rows through every layer; layer l reads
+ * act[l % 2] and writes act[(l + 1) % 2].  variant 0: L1 invalidate between layers, 1: agent-scope fences.  sync: 2112 B of
+ * device scratch (zeroed by the call); *err (device int, zeroed by the caller) != 0 when a bounded wait gave up. */
+int dmvae_debug_chain(void* stream, int variant, int nlayer, int M, int N, void* act0, void* act1,
+                      const void* const* W, const float* const* bias, void* sync, int* err);
+
+/* tuning aid: force the bf16 GEMM tile (64|128 x 64|128); (0,0) restores the heuristic */
+int dmvae_debug_set_tile(int bm, int bn);
+/* tuning aid: knob 0 = supertile height (tile rows) of the L2-friendly tile order,
+ *             knob 1 = 8-wave workgroups for the 128-row tiles (0|1),
+ *             knob 2 = per-problem tile shapes in the grouped dW grid (0 = all 64x64, 1 = planned, 2 = largest),
+ *             knob 3 = ring depth policy (-1 deep ring when <= 1 workgroup per CU, 0 never, 1 always),
+ *             knob 4 = XCD runs of a grouped grid cut per tile-shape class (1) or per problem (0),
+ *             knob 5 = conv-mode tiles: >= 1 short-K tiles as 4-wave / 2-slot workgroups (three per CU),
+ *                      2 also 3-slot rings for the 64x64 weight-gradient tiles,
+ *             knob 6 = 256x256 macro-tile kernel (csrc/gemm_bf16_256.hip): 0 never, 1 when its grid covers the chip
+ *                      (default), 2 whenever M and N divide by 256,
+ *             knob 7 = problems with K <= 128 as 64x64 tiles on a 2-slot ring (32 KiB: four to five workgroups per CU) (0|1;
+ *                      default 0: measured slower on the whole step),
+ *             knob 8 = merged weight-gradient grid of the 256x256 kernel: first-tile delay, units of 3.4 us spread over the
+ *                      256 CUs (default 0 = none, measured best; -1 = one launch per problem),
+ *             knob 9 = the narrow middle of the backward pass (dZ GEMM + latent epilogue + both head dX GEMMs) as one kernel over
+ *                      16-row blocks, csrc/mid_bwd.hip (0|1) */
+int dmvae_debug_set_knob(int which, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMVAE_HIP_DEBUG_H */

@@ -491,21 +491,28 @@ def test_colsum(hip):
         np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-4)
 
 
-@pytest.mark.parametrize("shadow", [True, False])      # bf16 mode (hardware sqrt / reciprocal, 1 ulp each) | fp32 parity mode (IEEE)
-def test_adam_tf_matches_oracle_over_steps(hip, shadow):
+# bf16 mode (hardware sqrt / reciprocal, 1 ulp each) | bf16 mode with DMVAE_ADAM_IEEE (dmvae_config.adam_ieee) | fp32 parity mode (IEEE)
+@pytest.mark.parametrize("shadow,ieee", [(True, False), (True, True), (False, False)])
+def test_adam_tf_matches_oracle_over_steps(hip, shadow, ieee):
     L = hip
+    flags = L.ADAM_ZERO_GRAD | (L.ADAM_IEEE if ieee else 0)
     rng = np.random.RandomState(4)
     n = 4096 + 64
     p = {"a": rng.randn(n).astype(np.float32).astype(np.float64)}
     m, v = O.adam_tf_init(p)
     pd, md, vd = dev(p["a"]), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
     pb = torch.zeros(n, dtype=torch.bfloat16, device="cuda") if shadow else None
+    p32, m32, v32 = pd.clone(), md.clone(), vd.clone()          # the fp32 mode beside it: IEEE in bf16 mode must give ITS bits
     for t in range(1, 6):
         g = (rng.randn(n) * 10 ** rng.uniform(-4, 1)).astype(np.float32).astype(np.float64)
         gd = dev(g * 2.0)    # grad_scale 0.5 undoes the factor 2 (the 1/world path)
         O.adam_tf(p, {"a": g}, m, v, t, lr=0.002)
         L.check(L.lib.dmvae_adam_tf(stream(), n, L.ptr(pd), L.ptr(gd), L.ptr(md), L.ptr(vd), L.ptr(pb) if shadow else None, 0.002, 0.9, 0.999,
-                                    1e-8, 0.5, 1, t, None))
+                                    1e-8, 0.5, flags, t, None))
+        if ieee:
+            g32 = dev(g * 2.0)
+            L.check(L.lib.dmvae_adam_tf(stream(), n, L.ptr(p32), L.ptr(g32), L.ptr(m32), L.ptr(v32), None, 0.002, 0.9, 0.999, 1e-8, 0.5, 0, t, None))
+            assert torch.equal(pd, p32) and torch.equal(md, m32) and torch.equal(vd, v32)
         torch.cuda.synchronize()
         np.testing.assert_allclose(pd.cpu().numpy(), p["a"], rtol=3e-6, atol=3e-7)
         np.testing.assert_allclose(md.cpu().numpy(), m["a"], rtol=1e-5, atol=2e-7)

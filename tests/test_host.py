@@ -15,14 +15,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_loads_and_exports_every_declared_symbol():
     from dmvae_hip import _lib
-    hdr = open(os.path.join(ROOT, "include", "dmvae_hip.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(dmvae_[a-z0-9_]+)\s*\(", hdr))
+    declared = set()
+    for h in ("dmvae_hip.h", "dmvae_hip_debug.h"):      # the drop-in boundary, and the measurement / tuning entries
+        hdr = open(os.path.join(ROOT, "include", h)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        names = set(re.findall(r"\b(dmvae_[a-z0-9_]+)\s*\(", hdr))
+        assert all(("debug" in n or "prof" in n) == (h == "dmvae_hip_debug.h") for n in names), (h, names)
+        declared |= names
     assert len(declared) >= 30
     for name in sorted(declared):
         assert hasattr(_lib.lib, name), "libdmvae_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert _lib.lib.dmvae_abi_version() == 1
+    m = re.search(r"#define DMVAE_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "dmvae_hip.h")).read())
+    assert _lib.lib.dmvae_abi_version() == int(m.group(1)) == _lib.ABI_VERSION == 2
 
 
 def test_ctypes_structs_match_header_layout():
@@ -33,7 +38,7 @@ def test_ctypes_structs_match_header_layout():
     assert C.sizeof(_lib.Epilogue) == 24 + 12 * 8
     assert C.sizeof(_lib.Buffers) == 8 * 8
     assert C.sizeof(_lib.TensorInfo) == 32 + 8 + 4 + 4 + 8
-    assert C.sizeof(_lib.ProfRow) == 48 + 8 + 8 + 8 + 8
+    assert C.sizeof(_lib.ProfRow) == 48 + 8 + 8 + 8 + 8 + 8 + 8
     assert C.sizeof(_lib.Config) == 4 * 3 + 4 + 32 + 4 + 4 + 32 + 4 * 4 + 4 * 4 + 8 + 4 + 4 + 4 + 4
 
 

@@ -18,9 +18,9 @@ e.init_parameters(0); e.write_state(lr=1e-4); e.reset_epoch(2)
 for _ in range(3): e.train_step(data, perm, use_state_cursor=True)
 torch.cuda.synchronize()
 p = C.c_void_p(); L.check(L.lib.dmvae_debug_anatomy256(C.byref(p)))
-buf = torch.empty(4096 * 4, dtype=torch.int64, device="cuda"); torch.cuda.synchronize()
-C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(buf.data_ptr()), p, C.c_size_t(4096 * 32), 3)
-s = buf.cpu().numpy().reshape(4096, 4)
+buf = torch.empty(4096 * 8, dtype=torch.int64, device="cuda"); torch.cuda.synchronize()
+C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(buf.data_ptr()), p, C.c_size_t(4096 * 64), 3)
+s = buf.cpu().numpy().reshape(4096, 8)
 s = s[s[:, 2] != 0]                      # the LAST macro-tile launch of the step = the merged dW + Adam grid (its bias workgroups write nothing)
 t0 = s[:, 0].min()
 ent, kend, eend = (s[:, 0] - t0) / 100.0, (s[:, 1] - t0) / 100.0, (s[:, 2] - t0) / 100.0
