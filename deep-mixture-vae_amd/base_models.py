@@ -104,6 +104,26 @@ class VAE:
             break
 
 
+def _cnn_encoder_network(out_dim):
+    """the convolutional encoder as the reference specifies it (base_models.py:179-205 with ("fc", 2048 -> 500) for DMVAE,
+    :459-488 with ("fc", 2048 -> 128) for VaDE): the DeepNetwork spec list drives the plan's CNN trunk -- the plan implements
+    exactly this stack, any other list is refused here rather than silently ignored"""
+    from dmvae_hip.runtime import CONV_STACK, CONV_FLAT
+    enc_spec = [("cn", {"n_kernels": 32, "prev_n_kernels": 1, "kernel": (3, 3)}),
+                ("cn", {"n_kernels": 32, "prev_n_kernels": 32, "kernel": (3, 3)}), ("mp", {"k": 2}),
+                ("cn", {"n_kernels": 64, "prev_n_kernels": 32, "kernel": (3, 3)}),
+                ("cn", {"n_kernels": 64, "prev_n_kernels": 64, "kernel": (3, 3)}), ("mp", {"k": 2}),
+                ("cn", {"n_kernels": 128, "prev_n_kernels": 64, "kernel": (3, 3)}),
+                ("cn", {"n_kernels": 128, "prev_n_kernels": 128, "kernel": (3, 3)}), ("mp", {"k": 2}),
+                ("fc", {"input_dim": 2048, "output_dim": out_dim})]
+    net = DeepNetwork("layers", enc_spec, activation="relu", initializer="xavier")
+    stack, side = net.conv_stack(28)
+    if stack != tuple((ci, co, hw, pool) for _, ci, co, hw, pool in CONV_STACK) or side * side * stack[-1][1] != CONV_FLAT:
+        raise NotImplementedError("the plan's CNN trunk is the stack of base_models.py:181-202; got %r" % (stack,))
+    assert net.widths() == (out_dim,)
+    return net
+
+
 class DeepMixtureVAE(VAE):
     def __init__(self, name, input_type, input_dim, latent_dim, n_classes, activation=None, initializer=None,
                  cnn=False, *, batch_size=100, dtype="bf16", enc_layers=(500, 500), head_dim=2000,
@@ -147,21 +167,7 @@ class DeepMixtureVAE(VAE):
         self.decoder_network = DeepNetwork("layers", spec, activation="relu", initializer="xavier")
         assert self.decoder_network.widths() == self.dec_layers
         if self.cnn:
-            # the encoder as the reference specifies it (base_models.py:179-205): the DeepNetwork spec list drives the plan's
-            # CNN trunk -- the plan implements exactly this stack, any other list is refused here rather than silently ignored
-            from dmvae_hip.runtime import CONV_STACK, CONV_FLAT
-            enc_spec = [("cn", {"n_kernels": 32, "prev_n_kernels": 1, "kernel": (3, 3)}),
-                        ("cn", {"n_kernels": 32, "prev_n_kernels": 32, "kernel": (3, 3)}), ("mp", {"k": 2}),
-                        ("cn", {"n_kernels": 64, "prev_n_kernels": 32, "kernel": (3, 3)}),
-                        ("cn", {"n_kernels": 64, "prev_n_kernels": 64, "kernel": (3, 3)}), ("mp", {"k": 2}),
-                        ("cn", {"n_kernels": 128, "prev_n_kernels": 64, "kernel": (3, 3)}),
-                        ("cn", {"n_kernels": 128, "prev_n_kernels": 128, "kernel": (3, 3)}), ("mp", {"k": 2}),
-                        ("fc", {"input_dim": 2048, "output_dim": self.enc_layers[0]})]
-            self.encoder_network = DeepNetwork("layers", enc_spec, activation="relu", initializer="xavier")
-            stack, side = self.encoder_network.conv_stack(28)
-            if stack != tuple((ci, co, hw, pool) for _, ci, co, hw, pool in CONV_STACK) or side * side * stack[-1][1] != CONV_FLAT:
-                raise NotImplementedError("the plan's CNN trunk is the stack of base_models.py:181-202; got %r" % (stack,))
-            assert self.encoder_network.widths() == self.enc_layers
+            self.encoder_network = _cnn_encoder_network(self.enc_layers[0])
         self._engine = StepEngine(self.input_dim, self.latent_dim, self.n_classes, enc_layers=self.enc_layers,
                                   head_dim=self.head_dim, dec_layers=self.dec_layers, input_type=self.input_type,
                                   dtype=self.dtype, max_batch=self.batch_size, mode="relaxed" if self.gumbel else "exact",
@@ -459,16 +465,17 @@ class VaDE(DeepMixtureVAE):
     the categorical KL, decoder D -> 500 -> 500 -> 2000 -> input (:530-547).  The per-batch step is the DMVAE step plan
     with dmvae_config.model = DMVAE_MODEL_VADE: no head hidden layers / logits, latent stage = dmvae_latent_fwd mode 2
     (csrc/latent_vade.hip), whose gradients include the path through the responsibilities into Z and the prior tables.
-    cnn=True (the reference's convolutional variant, :456-488, ends in fc 2048 -> 128) is not built."""
+    cnn=True (:456-488): the batch as 28x28x1 images through the same six-convolution / three-pool stack as DMVAE's
+    checked-in encoder, ending in ("fc", 2048 -> 128), with mean / log_var straight off those 128 units
+    (dmvae_config.trunk = DMVAE_TRUNK_CNN, enc = (128,))."""
 
     def __init__(self, name, input_type, input_dim, latent_dim, n_classes, activation=None, initializer=None, cnn=False, *,
                  batch_size=100, dtype="bf16", enc_layers=(2000, 500, 500), dec_layers=(500, 500, 2000), noise="device", seed=0,
                  deterministic=True, session=None):
-        if cnn:
-            raise NotImplementedError("VaDE(cnn=True): the convolutional VaDE encoder (base_models.py:456-488) is not built; "
-                                      "the CNN trunk exists for DeepMixtureVAE (cnn=True)")
+        if cnn and tuple(enc_layers) == (2000, 500, 500):
+            enc_layers = (128,)            # base_models.py:486: ("fc", {"input_dim": 2048, "output_dim": 128})
         DeepMixtureVAE.__init__(self, name, input_type, input_dim, latent_dim, n_classes, activation=activation, initializer=initializer,
-                                cnn=False, batch_size=batch_size, dtype=dtype, enc_layers=enc_layers, head_dim=64, dec_layers=dec_layers,
+                                cnn=cnn, batch_size=batch_size, dtype=dtype, enc_layers=enc_layers, head_dim=64, dec_layers=dec_layers,
                                 gumbel=False, temperature=1.0, noise=noise, seed=seed, deterministic=deterministic, session=session)
 
     def build_graph(self):
@@ -483,12 +490,13 @@ class VaDE(DeepMixtureVAE):
         for w in self.dec_layers:
             dec_spec.append(("fc", {"input_dim": prev, "output_dim": w}))
             prev = w
-        self.encoder_network = DeepNetwork("layers", enc_spec, activation="relu", initializer="xavier")
+        self.encoder_network = (_cnn_encoder_network(self.enc_layers[0]) if self.cnn else
+                                DeepNetwork("layers", enc_spec, activation="relu", initializer="xavier"))
         self.decoder_network = DeepNetwork("layers", dec_spec, activation="relu", initializer="xavier")
         self._engine = StepEngine(self.input_dim, self.latent_dim, self.n_classes, enc_layers=self.enc_layers, head_dim=64,
                                   dec_layers=self.dec_layers, input_type=self.input_type, dtype=self.dtype, max_batch=self.batch_size,
                                   mode="exact", seed=self.seed + 7919 * sess.rank, deterministic=self.deterministic, session=sess,
-                                  model="vade")
+                                  model="vade", cnn=self.cnn)
         self._engine.init_parameters(self.seed)
         self.X, self.epsilon = "X", "epsilon"
         self.mean, self.log_var, self.cluster_probs, self.Z = "mean", "log_var", "cluster_probs", "Z"

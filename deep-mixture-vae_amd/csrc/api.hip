@@ -200,8 +200,8 @@ static void add_tensor(dmvae_plan* p, const std::string& name, int64_t off, int 
 extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
     DMVAE_REQUIRE(c && out, "dmvae_plan_create: null argument");
     DMVAE_REQUIRE(c->input_dim > 0 && c->latent_dim > 0 && c->n_classes > 0 && (c->head_dim > 0 || c->model == DMVAE_MODEL_VADE), "dmvae_plan_create: bad dims");
-    DMVAE_REQUIRE(c->model == DMVAE_MODEL_DMVAE || (c->model == DMVAE_MODEL_VADE && c->trunk == DMVAE_TRUNK_MLP && c->mode == 0),
-                  "dmvae_plan_create: model %d (0 DMVAE, 1 VaDE; VaDE runs the MLP branch with the exact KL)", c->model);
+    DMVAE_REQUIRE(c->model == DMVAE_MODEL_DMVAE || (c->model == DMVAE_MODEL_VADE && c->mode == 0),
+                  "dmvae_plan_create: model %d (0 DMVAE, 1 VaDE; VaDE runs the exact KL)", c->model);
     DMVAE_REQUIRE(c->n_enc >= 1 && c->n_enc <= DMVAE_MAX_LAYERS && c->n_dec >= 1 && c->n_dec <= DMVAE_MAX_LAYERS, "dmvae_plan_create: 1..%d layers", DMVAE_MAX_LAYERS);
     DMVAE_REQUIRE(c->dtype == DMVAE_F32 || c->dtype == DMVAE_BF16, "dmvae_plan_create: bad dtype");
     DMVAE_REQUIRE(c->max_batch > 0, "dmvae_plan_create: max_batch must be > 0");

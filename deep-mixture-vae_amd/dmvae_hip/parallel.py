@@ -148,33 +148,49 @@ class ShardedExchange(GradExchange):
     def bucket_bounds(self, bounds, n_alloc):
         """bounds = [(lo, hi)] in completion order (StepEngine.grad_buckets: last part of the arena first).  The
         interior boundaries are rounded UP to the alignment: a bucket then only grows into the part of the arena
-        that was complete EARLIER, so it is still final when its segment ends."""
+        that was complete EARLIER, so it is still final when its segment ends.  ONE ENTRY PER SEGMENT, in the
+        order given: a bucket that rounding has emptied (fewer than 64 * world elements: tiny models, huge worlds)
+        is None -- its elements have moved into the bucket of a LATER segment -- and the caller skips it; dropping
+        it would shift every later bucket onto an earlier segment, whose gradients are not written yet."""
         cuts = sorted({lo for lo, _ in bounds} | {hi for _, hi in bounds})
         rounded = [0] + [min(self.padded(c), n_alloc) for c in cuts[1:-1]] + [n_alloc]
         out = []
         for lo, hi in bounds:
             i = cuts.index(lo)
-            out.append((rounded[i], rounded[i + 1]))
-        return [b for b in out if b[1] > b[0]]
+            out.append((rounded[i], rounded[i + 1]) if rounded[i + 1] > rounded[i] else None)
+        return out
 
     def owned(self, lo, hi):
         chunk = (hi - lo) // self.world
         assert chunk * self.world == hi - lo and chunk % 4 == 0, (lo, hi, self.world)
         return lo + self.rank * chunk, lo + (self.rank + 1) * chunk
 
+    # Both collectives run IN PLACE in the one layout NCCL / RCCL define for it: reduce-scatter with
+    # recvbuff == sendbuff + rank * recvcount, all-gather with sendbuff == recvbuff + rank * sendcount (the library then
+    # skips its local copy).  _in_place asserts exactly that aliasing, so no other overlap of input and output can be
+    # passed by accident.  Covered by: gloo at world 2 / 4 / 8 (CPU; gloo copies), two processes on the real kernels, a
+    # one-rank RCCL communicator (identity).  NOT yet covered: a multi-rank RCCL run (gpurun gives one GPU) -- the
+    # bench line says so (`multi_rank_rccl_verified: false`); DMVAE_DP_MODE=allreduce is the conventional fallback.
+    def _in_place(self, flat, lo, hi):
+        slo, shi = self.owned(lo, hi)
+        whole, mine = flat[lo:hi], flat[slo:shi]
+        assert flat.is_contiguous() and mine.numel() * self.world == whole.numel()
+        assert mine.data_ptr() == whole.data_ptr() + self.rank * mine.numel() * flat.element_size()
+        return whole, mine
+
     def reduce_scatter(self, flat, lo, hi, async_op=False):
         """sum over ranks of flat[lo:hi]; this rank's slice of the result lands IN PLACE at owned(lo, hi)"""
-        slo, shi = self.owned(lo, hi)
+        whole, mine = self._in_place(flat, lo, hi)
         if not self.enabled:
             return None
-        return dist.reduce_scatter_tensor(flat[slo:shi], flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        return dist.reduce_scatter_tensor(mine, whole, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def all_gather(self, flat, lo, hi, async_op=False):
         """every rank's owned slice of flat[lo:hi] to every rank, in place"""
-        slo, shi = self.owned(lo, hi)
+        whole, mine = self._in_place(flat, lo, hi)
         if not self.enabled:
             return None
-        return dist.all_gather_into_tensor(flat[lo:hi], flat[slo:shi], group=self.group, async_op=async_op)
+        return dist.all_gather_into_tensor(whole, mine, group=self.group, async_op=async_op)
 
 
 def make_exchange(param_bytes=0, group=None):

@@ -61,10 +61,11 @@ CONV_STACK = (("conv0", 1, 32, 28, False), ("conv1", 32, 32, 28, True), ("conv2"
 CONV_FLAT = 4 * 4 * 128
 
 
-def vade_layer_table(input_dim, latent_dim, enc_layers, dec_layers):
+def vade_layer_table(input_dim, latent_dim, enc_layers, dec_layers, cnn=False):
     """VaDE (base_models.py:490-547): FullyConnected encoder / decoder layers (xavier bias), tf.layers.dense mean /
-    log_var straight off the trunk and output layer (zero bias)."""
-    t, prev = [], input_dim
+    log_var straight off the trunk and output layer (zero bias).  cnn (:456-488): the encoder's dense part is the one
+    ("fc", 2048 -> 128) layer behind the conv stack."""
+    t, prev = [], (CONV_FLAT if cnn else input_dim)
     for i, h in enumerate(enc_layers):
         t.append(("enc%d" % i, prev, h, "xavier"))
         prev = h
@@ -235,7 +236,7 @@ class StepEngine:
                 p["W_" + name] = rng.uniform(-lim, lim, size=(9 * ci, co))
                 lb = math.sqrt(6.0 / (co + co))
                 p["b_" + name] = rng.uniform(-lb, lb, size=(co,))
-        table = (vade_layer_table(self.input_dim, self.latent_dim, self.enc_layers, self.dec_layers) if self.model == "vade" else
+        table = (vade_layer_table(self.input_dim, self.latent_dim, self.enc_layers, self.dec_layers, self.cnn) if self.model == "vade" else
                  layer_table(self.input_dim, self.latent_dim, self.n_classes, self.enc_layers, self.head_dim, self.dec_layers, self.cnn))
         for name, fi, fo, bk in table:
             lim = math.sqrt(6.0 / (fi + fo))
@@ -375,11 +376,13 @@ class StepEngine:
                 buckets = grad_sync.bucket_bounds(self.grad_buckets(), n)
                 # the plan's segments complete the UNROUNDED buckets in this order; rounding up keeps that true
                 handles = []
+                assert len(buckets) == 3          # one per segment; None = emptied by the rounding (its elements ride in a later bucket)
                 for stage in range(3):
                     self.forward_backward_stage(stage, n_valid, eps, gumbel, inv_B)
-                    if stage < len(buckets):
+                    if buckets[stage] is not None:
                         lo, hi = buckets[stage]
                         handles.append(grad_sync.reduce_scatter(self.grad, lo, hi, async_op=True))
+                buckets = [b for b in buckets if b is not None]
                 gathers = []
                 for h, (lo, hi) in zip(handles, buckets):
                     grad_sync.wait(h)
@@ -466,6 +469,9 @@ class StepEngine:
         forward pass, under the names the parameters use (enc<i>, zh, ch, dec<i>)."""
         out = {}
         if self.model == "vade":
+            if self.cnn:
+                for name, _, _, _, _ in CONV_STACK:
+                    out[name] = self.view(name, rows)
             for i, w in enumerate(self.enc_layers):
                 out["enc%d" % i] = self.view("enc%d" % i, rows, w)
             for i, w in enumerate(self.dec_layers):

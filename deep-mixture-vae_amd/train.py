@@ -155,9 +155,12 @@ def main(argv):
             model.load_state_dict({k: f[k] for k in f.files})
         if rank == 0:
             print("Restored", ckpt_path)
-    except FileNotFoundError:
+    except (OSError, ValueError, KeyError, RuntimeError) as e:
+        # no checkpoint, one written by another revision (e.g. a torch.save zip at this path), a truncated archive,
+        # other shapes / names: say why and carry on from the initial parameters, as the reference does
+        # (bare except around saver.restore, train.py:251-258) and as DeepMixtureVAE._restore does
         if rank == 0:
-            print("Could not load trained model")
+            print("Could not load trained model" + ("" if isinstance(e, FileNotFoundError) else " (%s: %s)" % (type(e).__name__, e)))
     if world > 1:   # every rank starts from rank 0's parameters
         import torch.distributed as dist
         dist.broadcast(model.engine.param, src=0)

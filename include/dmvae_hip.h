@@ -266,7 +266,8 @@ int dmvae_cast_bf16_to_f32(void* stream, const void* in, float* out, int64_t n);
  * VaDE: base_models.py:435-562 -- n_enc FullyConnected trunk layers, mean / log_var linear straight off the trunk (no
  * head hidden layers, no logits: head_dim is ignored), q(c|x) := p(c|z) = get_cluster_probs(Z) (priors.py:91-102) as the
  * mixture weights AND the categorical probabilities; the latent stage is dmvae_latent_fwd mode 2.  Tensor table: W_enc<i>,
- * b_enc<i>, W_mean, b_mean, W_logvar, b_logvar, W_dec<i>, b_dec<i>, W_out, b_out, prior_means, prior_log_vars. */
+ * b_enc<i>, W_mean, b_mean, W_logvar, b_logvar, W_dec<i>, b_dec<i>, W_out, b_out, prior_means, prior_log_vars.
+ * With DMVAE_TRUNK_CNN (base_models.py:456-488): the same conv / pool stack in front, enc[0] = 128 (fc 2048 -> 128). */
 #define DMVAE_MODEL_DMVAE 0
 #define DMVAE_MODEL_VADE 1
 

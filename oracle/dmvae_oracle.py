@@ -494,16 +494,21 @@ class VadeConfig:
     ("fc", ...) specs = FullyConnected layers, whose (1, out) bias is xavier-initialised like the weight
     (includes/layers.py:24-28); the mean / log_var / output layers are tf.layers.dense (zero bias)."""
 
+    CONV_STACK, CONV_FLAT = Config.CONV_STACK, Config.CONV_FLAT
+
     def __init__(self, input_dim=784, latent_dim=10, n_classes=10, enc_layers=(2000, 500, 500), dec_layers=(500, 500, 2000),
-                 input_type="binary"):
+                 input_type="binary", cnn=False):
         self.input_dim, self.latent_dim, self.n_classes = int(input_dim), int(latent_dim), int(n_classes)
-        self.enc_layers = tuple(int(v) for v in enc_layers)
+        # cnn (base_models.py:456-488): the SAME conv / pool stack as DMVAE's (:181-201) ending in ("fc", 2048 -> 128)
+        self.cnn = bool(cnn)
+        self.enc_layers = tuple(int(v) for v in ((128,) if (cnn and tuple(enc_layers) == (2000, 500, 500)) else enc_layers))
         self.dec_layers = tuple(int(v) for v in dec_layers)
         self.input_type = input_type
-        self.cnn = False
+        if self.cnn:
+            assert self.input_dim == 784 and len(self.enc_layers) == 1, "cnn trunk: 784 inputs, one fc layer"
 
     def layer_table(self):
-        t, prev = [], self.input_dim
+        t, prev = [], (self.CONV_FLAT if self.cnn else self.input_dim)
         for i, h in enumerate(self.enc_layers):
             t.append(("enc%d" % i, prev, h, "xavier"))
             prev = h
@@ -517,10 +522,11 @@ class VadeConfig:
         return t
 
     def conv_table(self):
-        return ()
+        return self.CONV_STACK if self.cnn else ()
 
     def n_params(self):
-        return sum(fi * fo + fo for _, fi, fo, _ in self.layer_table()) + 2 * self.n_classes * self.latent_dim
+        return (sum(9 * ci * co + co for _, ci, co, _, _ in self.conv_table()) +
+                sum(fi * fo + fo for _, fi, fo, _ in self.layer_table()) + 2 * self.n_classes * self.latent_dim)
 
 
 def vade_forward(p, cfg, X, epsilon, kl_ratio=1.0):
@@ -528,7 +534,7 @@ def vade_forward(p, cfg, X, epsilon, kl_ratio=1.0):
     (priors.py:91-102) are the mixture weights of the exact KL (priors.py:131-145, cluster_sample False) AND the
     probabilities of the categorical KL (priors.py:183-201, "probs" branch)."""
     a = {"x": X, "eps": epsilon}
-    h = X
+    h = cnn_trunk(p, cfg, X, a) if cfg.cnn else X           # cnn: X_flat = reshape(X, (-1, 28, 28, 1)), base_models.py:455,482
     for i in range(len(cfg.enc_layers)):
         h = _dense(h, p["W_enc%d" % i], p["b_enc%d" % i], True)
         a["enc%d" % i] = h
@@ -601,11 +607,13 @@ def vade_backward(p, cfg, a, masks=None):
     dh = dmean @ p["W_mean"].T + dlogvar @ p["W_logvar"].T
     for i in reversed(range(ne)):
         dy = dh * (a["enc%d" % i] > 0)
-        xin = a["enc%d" % (i - 1)] if i > 0 else X
+        xin = a["enc%d" % (i - 1)] if i > 0 else (a["flat"] if cfg.cnn else X)
         g["W_enc%d" % i] = xin.T @ dy
         g["b_enc%d" % i] = dy.sum(0)
-        if i > 0:
+        if i > 0 or cfg.cnn:
             dh = dy @ p["W_enc%d" % i].T
+    if cfg.cnn:
+        cnn_trunk_backward(p, cfg, a, dh, g)
     return g
 
 

@@ -181,7 +181,6 @@ def test_full_size_step_properties_with_the_fused_middle_backward(name):
         assert grads[0][1] == grads[1][1]                              # the forward pass is untouched
         d = (grads[0][0] - grads[1][0]).norm().item() / grads[0][0].norm().item()
         assert d <= 2e-2, d                                             # a different summation order over bf16 operands
-        assert d > 0 or True
         _lib.check(_lib.lib.dmvae_debug_set_knob(9, 1))
         _full_size_step_properties(name)
     finally:

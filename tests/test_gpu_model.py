@@ -243,8 +243,9 @@ def test_unsupported_surfaces_fail_loudly():
     import base_models
     with pytest.raises(ValueError):                    # the CNN trunk reshapes to 28x28x1 (base_models.py:176)
         base_models.DeepMixtureVAE("m", "binary", 100, 10, 10, cnn=True)
-    with pytest.raises(NotImplementedError):           # VaDE's convolutional encoder variant (base_models.py:456-488) is not built
-        base_models.VaDE("v", "binary", 784, 10, 10, cnn=True)
+    with pytest.raises(ValueError):                    # VaDE's convolutional encoder (base_models.py:455) likewise
+        base_models.VaDE("v", "binary", 100, 10, 10, cnn=True)
+    assert base_models.VaDE("v", "binary", 784, 10, 10, cnn=True).enc_layers == (128,)       # :486 ("fc", 2048 -> 128); built in tests/test_gpu_vade.py
 
 
 def test_cnn_model_trains_through_the_reference_surface():
@@ -282,3 +283,14 @@ def test_train_cli_one_epoch(tmp_path, monkeypatch):
     assert np.isfinite(loss) and 50 < loss < 560
     assert os.path.exists(tmp_path / "saved-models" / "mnist" / "dmvae" / "model" / "parameters.ckpt")
     assert "Max Accuracy" in open(tmp_path / "dmvae_logs.txt").read()
+    # a checkpoint this revision cannot read (another format at the same path, a truncated archive, other shapes)
+    # must not abort start-up: the reason is printed and training starts from the initial parameters, as in the reference
+    ck = tmp_path / "saved-models" / "mnist" / "dmvae" / "model" / "parameters.ckpt"
+    blob = open(ck, "rb").read()
+    for bad in (blob[: len(blob) // 3], b"PK\x03\x04 not an npz", b""):
+        open(ck, "wb").write(bad)
+        loss = train.main(train.parser.parse_args(["--n_epochs", "1", "--batch_size", "256", "--latent_dim", "10", "--seed", "1"]))
+        assert np.isfinite(loss)
+    np.savez(open(ck, "wb"), W_enc0=np.zeros((3, 3), np.float32))          # readable archive, wrong shapes
+    loss = train.main(train.parser.parse_args(["--n_epochs", "1", "--batch_size", "256", "--latent_dim", "10", "--seed", "1"]))
+    assert np.isfinite(loss)

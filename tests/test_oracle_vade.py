@@ -11,6 +11,17 @@ import dmvae_oracle as O
 def torch_vade_loss(tp, cfg, X, eps, r):
     Xt, et = torch.tensor(X), torch.tensor(eps)
     h = Xt
+    if cfg.cnn:                          # base_models.py:455-488 with torch's own conv2d / max_pool2d
+        F = torch.nn.functional
+        h = Xt.reshape(-1, 1, 28, 28)
+        for name, ci, co, hw, pool in cfg.conv_table():
+            W = tp["W_" + name].reshape(3, 3, ci, co).permute(3, 2, 0, 1)      # HWIO -> OIHW
+            h = torch.relu(F.conv2d(h, W, tp["b_" + name], padding=1))
+            if pool:
+                if h.shape[-1] % 2:                                          # SAME: pad bottom / right
+                    h = F.pad(h, (0, 1, 0, 1), value=float("-inf"))
+                h = F.max_pool2d(h, 2)
+        h = h.permute(0, 2, 3, 1).reshape(Xt.shape[0], -1)                    # flatten (h, w, c)
     for i in range(len(cfg.enc_layers)):
         h = torch.relu(h @ tp["W_enc%d" % i] + tp["b_enc%d" % i])
     mean, lv = h @ tp["W_mean"] + tp["b_mean"], h @ tp["W_logvar"] + tp["b_logvar"]
@@ -78,3 +89,27 @@ def test_vade_adam_step_moves_every_tensor():
     for k in p:                                       # every VaDE trainable has a gradient (no dead Y head as in DMVAE)
         assert np.abs(p[k] - before[k]).max() > 0, k
     assert cfg.n_params() == sum(x.size for x in p.values())
+
+
+def test_vade_cnn_backward_matches_autograd():
+    """VaDE(cnn=True), base_models.py:456-488: the conv / pool stack ending in ("fc", 2048 -> 128), mean / log_var straight off
+    it; the oracle's forward and hand-derived backward (through the conv trunk) against torch conv2d / max_pool2d + autograd."""
+    cfg = O.VadeConfig(784, 5, 4, dec_layers=(12, 10), cnn=True)
+    assert cfg.enc_layers == (128,) and [t[:3] for t in cfg.layer_table()[:3]] == [("enc0", 2048, 128), ("mean", 128, 5), ("logvar", 128, 5)]
+    p = O.init_params(cfg, 2)
+    assert cfg.n_params() == sum(v.size for v in p.values())
+    assert np.abs(p["b_enc0"]).max() > 0 and not p["b_mean"].any()         # FullyConnected bias xavier, tf.layers.dense bias zero
+    rng = np.random.RandomState(4)
+    p["prior_log_vars"] = rng.randn(4, 5) * 0.3
+    B = 3
+    X, eps = O.synthetic_images(B, 784, seed=5).astype(np.float64), rng.randn(B, 5)
+    a = O.vade_forward(p, cfg, X, eps, 0.9)
+    g = O.vade_backward(p, cfg, a)
+    assert a["flat"].shape == (B, 2048) and a["enc0"].shape == (B, 128)
+    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    loss, rec, klz, klc = torch_vade_loss(tp, cfg, X, eps, 0.9)
+    loss.backward()
+    assert a["loss"] == pytest.approx(loss.item(), rel=1e-12)
+    assert set(g) == set(p)
+    for k in g:
+        np.testing.assert_allclose(g[k], tp[k].grad.numpy(), rtol=1e-8, atol=1e-12, err_msg=k)
