@@ -254,6 +254,9 @@ def main():
 
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    for kv in os.environ.get("DMVAE_KNOBS", "").split(","):      # measurement only: "knob=value,..." (include/dmvae_hip_debug.h)
+        if kv:
+            dmvae_hip._lib.check(dmvae_hip.lib.dmvae_debug_set_knob(int(kv.split("=")[0]), int(kv.split("=")[1])))
     if args.global_batch:      # strong scaling: one global batch cut over the ranks
         if args.global_batch % world:
             raise SystemExit("bench.py: --global-batch %d is not a multiple of %d ranks" % (args.global_batch, world))

@@ -22,6 +22,7 @@ noise ("device" Philox | "host" NumPy stream of the reference), seed.
 """
 import math
 import os
+import zipfile
 
 import numpy as np
 
@@ -337,7 +338,7 @@ class DeepMixtureVAE(VAE):
             with np.load(path, allow_pickle=False) as f:
                 self.load_state_dict({k: f[k] for k in f.files})
             return True
-        except (OSError, ValueError, KeyError, RuntimeError) as e:
+        except (OSError, ValueError, KeyError, RuntimeError, EOFError, zipfile.BadZipFile) as e:
             print("Could not read %s: %s" % (path, e))
             return False
 

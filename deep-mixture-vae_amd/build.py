@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "dmvae_hip", "libdmvae_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_bf16_256.hip", "gemm_f32.hip", "latent.hip", "latent_mfma.hip", "latent_vade.hip", "mid_bwd.hip", "elementwise.hip", "conv.hip", "api.hip"]
+SOURCES = ["gemm_bf16.hip", "gemm_bf16_256.hip", "gemm_f32.hip", "latent.hip", "latent_mfma.hip", "latent_vade.hip", "elementwise.hip", "conv.hip", "api.hip"]
 # -amdgpu-mfma-vgpr-form: accumulators stay in VGPRs.  Left to its default, hipcc (ROCm 7.2) puts the
 # 4-wave GEMM tiles' accumulators in AGPRs and then shuffles them through v_accvgpr_read/write/mov on
 # every K step (256 such moves against 80 MFMAs in the 128x128 dW loop); no kernel here needs > 256 VGPRs.
@@ -25,7 +25,7 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers.append(os.path.join(HERE, "..", "include", "dmvae_hip.h"))
+    headers += [os.path.join(HERE, "..", "include", h) for h in ("dmvae_hip.h", "dmvae_hip_debug.h")]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
@@ -64,7 +64,7 @@ def build_host_asan(verbose=False):
     objdir = os.path.join(HERE, "build", "asan")
     os.makedirs(objdir, exist_ok=True)
     out = os.path.join(objdir, "libdmvae_hip_asan.so")
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "dmvae_hip.h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", h) for h in ("dmvae_hip.h", "dmvae_hip_debug.h")]
     flags = ["--offload-arch=gfx950", "--cuda-host-only", "-O1", "-g", "-fPIC", "-std=c++17", "-fsanitize=address,undefined",
              "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"]
     objs, jobs = [], []

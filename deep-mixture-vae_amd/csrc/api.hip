@@ -117,9 +117,9 @@ static int gemm_partials(int, int M, int N) { return (M / 64) * (N / 64); }
 
 using namespace dmvae;
 
-// tuning knob (dmvae_debug_set_knob 9): the narrow middle of the backward pass (dZ GEMM + latent epilogue + both head dX GEMMs)
-// as one 16-row-block kernel (mid_bwd.hip) instead of three tile-GEMM launches
-static int g_mid_bwd = 0;
+// tuning knob (dmvae_debug_set_knob 10): K slices of the dense weight-gradient group (0 = the plan's rule, 1 = none, 2 / 4 = forced where
+// the plan has the slabs); see dmvae_plan::dw_slices_max
+static int g_dw_slices = 0;
 
 // ====================================================================== plan
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -171,16 +171,23 @@ struct dmvae_plan {
     dmvae_buffers buf;
     bool bound;
     std::vector<GemmArgs> dw_queue;   // dW problems queued (bf16: flushed as grouped launches)
-    hipStream_t side = nullptr;       // side stream the dW groups run on, concurrently with the dX chain
-    hipEvent_t ev_fork[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join = nullptr;   // [3] = step_finalize fork
-    bool side_busy = false;
+    // Large batches (Bp >= 8192, MNIST-shaped layers): the dW group's tile count is fixed by the parameter shapes while its K = the
+    // batch grows -- few, very long workgroups (cfg3: 256 K tiles each) that fill the CUs' slots unevenly and re-fetch their operand
+    // panels (1.75x at cfg3, profiles/r03_cfg3_pmc_traffic.txt).  Then every problem is cut into dw_slices K slices, each a set of
+    // ordinary workgroups of the SAME grouped launch storing its partial product (and bias partial) into its own slab -- a full image
+    // of the gradient arena per slice, [dw_slices_max][param_elems] floats at o_dwslab -- and the slabs are added in ascending order
+    // by the Adam kernel (adam_slabs: fused step) or by slab_reduce into the gradient arena (backward alone).  No float atomics.
+    int dw_slices_max = 1;            // 1: the plan has no slabs
+    int64_t o_dwslab = 0;
+    int dw_slices_now = 1;            // slices of the pass being enqueued
     bool fused_update = false;        // set for the duration of dmvae_plan_train_step on a bf16 plan
     bool staged = false;              // dmvae_plan_forward_backward_stage: every segment launches its own dW group
-    GatherSrc xsrc{};                 // dmvae_plan_load_batch_deferred: the batch gather waits for the first dense layer's launch
-    bool xsrc_pending = false;
-    bool split_odd_dw = false;        // DMVAE_DW_SPLIT=1: 128-aligned part + remainder strip as two dW problems (see grad_dense)
-    bool overlap_dw = true;
-    bool finalize_rides = true;       // DMVAE_FINALIZE_INLINE=1: step_finalize as its own launch (A/B)
+    // dmvae_plan_load_batch_step: the batch was assembled for a step that follows at once -- no f32 copy of it exists; the output
+    // layer's reconstruction epilogue reads its targets from the dataset through the same permutation (bf16 plans whose output
+    // layer runs on the small-tile kernel, input_dim a multiple of 4)
+    struct { const float* data; int64_t n_rows; const int32_t* perm; int64_t first; int n_valid; const void* st; } tsrc{};
+    bool tsrc_valid = false;          // cleared by dmvae_plan_load_batch (which writes the f32 copy)
+    bool tgt_gather = false;          // the plan is eligible
     bool vade = false;                // cfg.model == DMVAE_MODEL_VADE: no head hidden layers, no logits; latent mode 2
     // bias gradients of the macro-tile path: the GEMM that PRODUCES a dY (256x256 kernel, ReLU-gate / recon epilogue) leaves
     // its column sums per 256-row tile, [Bp/256][width] floats per dY tensor; the dW problem of that layer picks them up
@@ -365,6 +372,22 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
     maxN = std::max(maxN, 2 * KD);
     p->cs_elems = (int64_t)64 * maxN;
     p->o_cs = take(p->cs_elems * 4);
+    {   // K slices of the dW group (see dw_slices_max): bf16, dense trunk, a batch of >= 8192 rows, no layer on the macro tile
+        bool macro = false;
+        auto chk = [&](const PLayer& L) { macro = macro || gemm_bf16_256_ok(DMVAE_GEMM_DW, DMVAE_EPI_ADAM, L.in_pad, L.out_pad, (int)Bp, false); };
+        for (auto& L : p->enc) chk(L);
+        for (auto& L : p->dec) chk(L);
+        if (!p->vade) { chk(p->zc); chk(p->lg); }
+        chk(p->mv); chk(p->out);
+        if (c->dtype == DMVAE_BF16 && p->conv.empty() && Bp >= 8192 && Bp % (4 * 64) == 0 && !macro) {
+            p->dw_slices_max = 4;
+            p->o_dwslab = take((int64_t)p->dw_slices_max * p->param_elems * 4);
+        }
+    }
+    // the step path may leave the batch's f32 copy out (dmvae_plan_load_batch_step): bf16, 16-byte aligned dataset rows, and an
+    // output layer that the small-tile kernel runs (the macro tile fetches its targets in row batches from the copy)
+    p->tgt_gather = c->dtype == DMVAE_BF16 && c->input_dim % 4 == 0 &&
+                    !gemm_bf16_256_ok(DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_RECON, p->Bp, p->Ip, p->dec.back().out_pad, false);
     p->work_bytes = w;
     *out = p;
     return 0;
@@ -372,9 +395,6 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
 
 extern "C" void dmvae_plan_destroy(dmvae_plan* p) {
     if (!p) return;
-    for (auto& e : p->ev_fork) if (e) (void)hipEventDestroy(e);
-    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
-    if (p->side) (void)hipStreamDestroy(p->side);
     delete p;
 }
 
@@ -402,15 +422,6 @@ extern "C" int dmvae_plan_bind(dmvae_plan* p, const dmvae_buffers* b) {
     DMVAE_REQUIRE(p->buf.arena_elems >= p->param_elems && p->buf.arena_elems % 4 == 0, "dmvae_plan_bind: arena_elems %lld < the plan's %lld parameters (or not a multiple of 4)",
                   (long long)p->buf.arena_elems, (long long)p->param_elems);
     p->bound = true;
-    if (!p->side) {   // setup-time resources (never created while enqueueing)
-        hipError_t e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
-        for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ev_fork[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming);
-        if (e != hipSuccess) { set_error("dmvae_plan_bind: side stream / events: %s", hipGetErrorString(e)); return (int)e; }
-    }
-    p->overlap_dw = getenv("DMVAE_DW_OVERLAP") != nullptr;
-    p->split_odd_dw = getenv("DMVAE_DW_SPLIT") != nullptr;
-    p->finalize_rides = getenv("DMVAE_FINALIZE_INLINE") == nullptr;
     return 0;
 }
 
@@ -430,34 +441,26 @@ extern "C" int dmvae_plan_load_batch(dmvae_plan* p, void* stream, const float* d
     DMVAE_REQUIRE(n_valid >= 0 && n_valid <= p->cfg.max_batch, "dmvae_plan_load_batch: n_valid=%d exceeds max_batch=%d", n_valid, p->cfg.max_batch);
     hipStream_t s = (hipStream_t)stream;
     void* xa = p->cfg.dtype == DMVAE_BF16 ? (void*)WS(p, p->o_x) : nullptr;
+    p->tsrc_valid = false;
     return gather_launch(s, p->cfg.dtype, data, n_rows, p->cfg.input_dim, perm, first, p->cfg.max_batch, n_valid, p->Bp, xa, p->Ip,
                          reinterpret_cast<float*>(WS(p, p->o_xf)), p->Ip, p->Ip, use_state_cursor ? p->buf.state : nullptr);
 }
 
-// Does the first dense layer take the batch gather into its own launch (gemm_bf16_gather_kernel)?  bf16, MLP trunk, a layer
-// the small-tile kernel runs (the 256x256 macro tile has no gather mode).
-static bool gather_folds(const dmvae_plan* p) {
-    return p->cfg.dtype == DMVAE_BF16 && p->conv.empty() && !p->enc.empty() && gemm_bf16_gather_ok(p->Bp, p->enc[0].out_pad, p->Ip);
-}
-extern "C" int dmvae_plan_gather_folds(const dmvae_plan* p) { return p && gather_folds(p) ? 1 : 0; }
-
-// As dmvae_plan_load_batch, for a caller that goes straight on to dmvae_plan_encode / _forward_backward / _train_step: `shadow`
-// is a bf16 copy of `data`, [shadow_rows >= n_rows + 1][input_dim padded to 64] with its pad columns and every row >= n_rows zero
-// (dmvae_gather_rows with perm = NULL makes one).  When dmvae_plan_gather_folds(p) the gather is NOT launched here: the first
-// dense layer reads the shadow through perm and the same launch writes the batch's copies; otherwise exactly dmvae_plan_load_batch.
-extern "C" int dmvae_plan_load_batch_deferred(dmvae_plan* p, void* stream, const float* data, const void* shadow, int64_t shadow_rows, int64_t n_rows,
-                                              const int32_t* perm, int64_t first, int n_valid, int use_state_cursor) {
-    DMVAE_REQUIRE(p && p->bound && data, "dmvae_plan_load_batch_deferred: plan not bound / null data");
-    DMVAE_REQUIRE(n_valid >= 0 && n_valid <= p->cfg.max_batch, "dmvae_plan_load_batch_deferred: n_valid=%d exceeds max_batch=%d", n_valid, p->cfg.max_batch);
-    if (!shadow || shadow_rows <= n_rows || !gather_folds(p)) return dmvae_plan_load_batch(p, stream, data, n_rows, perm, first, n_valid, use_state_cursor);
-    GatherSrc& g = p->xsrc;
-    g.shadow = reinterpret_cast<const bf16_t*>(shadow); g.ld_s = p->Ip; g.zero_row = n_rows;
-    g.data = data; g.dim = p->cfg.input_dim; g.n_rows = n_rows; g.perm = perm; g.first = first; g.batch = p->cfg.max_batch;
-    g.n_valid = n_valid; g.B_pad = p->Bp;
-    g.out_act = reinterpret_cast<bf16_t*>(WS(p, p->o_x)); g.ld_act = p->Ip; g.out_f32 = reinterpret_cast<float*>(WS(p, p->o_xf)); g.ld_f32 = p->Ip;
-    g.cols_pad = p->Ip; g.st = use_state_cursor ? p->buf.state : nullptr;
-    p->xsrc_pending = true;
-    return 0;
+// The same for a caller that goes straight on to dmvae_plan_forward_backward / _train_step (one step on this batch, nothing else
+// reads it).  On an eligible plan (tgt_gather) only the bf16 copy of the batch is written: the f32 copy's one reader in a step,
+// the reconstruction epilogue of the output layer, fetches its target rows from `data` through `perm` itself -- the same bytes
+// read, 4 B per input element less written and re-read (cfg2: the gather 9.9 -> 6 us).  The "x" view is then NOT valid.
+// Otherwise exactly dmvae_plan_load_batch.  `data` / `perm` must stay alive and unchanged until the step has run.
+extern "C" int dmvae_plan_load_batch_step(dmvae_plan* p, void* stream, const float* data, int64_t n_rows, const int32_t* perm,
+                                          int64_t first, int n_valid, int use_state_cursor) {
+    DMVAE_REQUIRE(p && p->bound && data, "dmvae_plan_load_batch_step: plan not bound / null data");
+    DMVAE_REQUIRE(n_valid >= 0 && n_valid <= p->cfg.max_batch, "dmvae_plan_load_batch_step: n_valid=%d exceeds max_batch=%d", n_valid, p->cfg.max_batch);
+    if (!p->tgt_gather) return dmvae_plan_load_batch(p, stream, data, n_rows, perm, first, n_valid, use_state_cursor);
+    p->tsrc.data = data; p->tsrc.n_rows = n_rows; p->tsrc.perm = perm; p->tsrc.first = first; p->tsrc.n_valid = n_valid;
+    p->tsrc.st = use_state_cursor ? p->buf.state : nullptr;
+    p->tsrc_valid = true;
+    return gather_launch((hipStream_t)stream, DMVAE_BF16, data, n_rows, p->cfg.input_dim, perm, first, p->cfg.max_batch, n_valid, p->Bp,
+                         WS(p, p->o_x), p->Ip, nullptr, p->Ip, p->Ip, use_state_cursor ? p->buf.state : nullptr);
 }
 
 static int fwd_dense(dmvae_plan* p, hipStream_t s, const void* A, int64_t lda, int Kdim, const PLayer& L, int N, int64_t w_col,
@@ -589,12 +592,6 @@ static int encode_impl(dmvae_plan* p, hipStream_t s) {
     }
     for (size_t i = 0; i < p->enc.size(); ++i) {
         const PLayer& L = p->enc[i];
-        if (i == 0 && p->xsrc_pending) {     // the deferred batch gather rides in this launch (dmvae_plan_load_batch_deferred)
-            p->xsrc_pending = false;
-            GemmArgs a;
-            TRY(fwd_dense(p, s, in, ld, kd, L, L.out_pad, 0, DMVAE_EPI_BIAS_RELU, WS(p, p->o_enc[i]), L.out_pad, &a));
-            TRY(gemm_bf16_gather_launch(s, a, p->xsrc));
-        } else
         TRY(fwd_dense(p, s, in, ld, kd, L, L.out_pad, 0, DMVAE_EPI_BIAS_RELU, WS(p, p->o_enc[i]), L.out_pad));
         in = WS(p, p->o_enc[i]); ld = L.out_pad; kd = L.out_pad;
     }
@@ -658,70 +655,68 @@ static int grad_dense(dmvae_plan* p, hipStream_t s, const void* X, int64_t ldx, 
     dmvae_epilogue e;
     memset(&e, 0, sizeof(e));
     const int split = dw_split(p, Mdim, N);
-    e.kind = p->fused_update ? DMVAE_EPI_ADAM : (split > 1 ? DMVAE_EPI_ATOMIC_F32 : DMVAE_EPI_STORE_F32);
-    e.out = p->buf.grad + w_off; e.ldo = ldw;
-    e.out2 = p->buf.grad + b_off;             // db = column sums of dY, fused (ones-operand MFMA)
+    const int nsl = p->cfg.dtype == DMVAE_BF16 ? p->dw_slices_now : 1;      // K slices into slabs (dw_slices_max)
+    float* gbase = nsl > 1 ? reinterpret_cast<float*>(WS(p, p->o_dwslab)) : p->buf.grad;
+    e.kind = nsl > 1 ? DMVAE_EPI_STORE_F32 : p->fused_update ? DMVAE_EPI_ADAM : (split > 1 ? DMVAE_EPI_ATOMIC_F32 : DMVAE_EPI_STORE_F32);
+    e.out = gbase + w_off; e.ldo = ldw;
+    e.out2 = gbase + b_off;             // db = column sums of dY, fused (ones-operand MFMA)
     if (p->cfg.dtype == DMVAE_BF16) {         // bf16: queued, all dW problems of the step go out as ONE grouped launch
-        // A dimension that is a multiple of 64 but not of 128 (784 -> 832 = 6.5 x 128) would force 64-wide
-        // tiles on the whole matrix (2x the streamed bytes of 128x128).  Optionally (DMVAE_DW_SPLIT=1) cut
-        // such a matrix into its 128-aligned part and the 64-wide remainder strip, two problems of the
-        // same grouped launch.  MEASURED at cfg2: slower, 0.3104 vs 0.3072 ms/step -- 13 % fewer bytes, but
-        // 288 instead of 240 large tiles no longer pair one-to-one with the small ones on the 256 CUs
-        // (see the planner in gemm_bf16.hip); off by default, kept for other shapes.
-        const int m1 = (Mdim % 128 && Mdim > 128 && p->split_odd_dw) ? Mdim / 128 * 128 : Mdim;
-        const int n1 = (N % 128 && N > 128 && p->split_odd_dw) ? N / 128 * 128 : N;
-        const bf16_t* Xb = reinterpret_cast<const bf16_t*>(X);
-        const bf16_t* dYb = reinterpret_cast<const bf16_t*>(dY);
-        for (int mi = 0; mi < (m1 < Mdim ? 2 : 1); ++mi) {
-            for (int ni = 0; ni < (n1 < N ? 2 : 1); ++ni) {
-                const int mo = mi ? m1 : 0, no = ni ? n1 : 0;
-                const int mm = mi ? Mdim - m1 : m1, nn = ni ? N - n1 : n1;
-                dmvae_epilogue es = e;
-                es.out = p->buf.grad + w_off + (int64_t)mo * ldw + no;
-                es.out2 = mi == 0 ? p->buf.grad + b_off + no : nullptr;      // bias gradient once per column range
-                if ((int)p->dw_queue.size() >= DMVAE_MAX_GROUP) TRY(launch_dw_queue(p, s, false));    // deep stacks: a full group goes out early
-                GemmArgs a;
-                TRY(gemm_checked(s, DMVAE_BF16, DMVAE_GEMM_DW, mm, nn, p->Bp, Xb + mo, ldx, dYb + no, ldy, &es, 1, &a));
-                a.ws = reinterpret_cast<float*>(WS(p, p->o_cs)); a.ws_elems = p->cs_elems;     // bias-gradient slab sums of a 256x256-tile problem
-                auto cs = p->csum_of.find(dY);
-                if (cs != p->csum_of.end() && no == 0 && nn == N && cs->second.second == N) {      // ... unless dY's producer left its column sums
-                    a.csum_in = cs->second.first; a.csum_ld = N; a.csum_rows = p->Bp / 256;
-                }
-                p->dw_queue.push_back(a);
-            }
+        if ((int)p->dw_queue.size() >= DMVAE_MAX_GROUP) TRY(launch_dw_queue(p, s, false));    // deep stacks: a full group goes out early
+        GemmArgs a;
+        TRY(gemm_checked(s, DMVAE_BF16, DMVAE_GEMM_DW, Mdim, N, p->Bp, X, ldx, dY, ldy, &e, 1, &a));
+        a.ws = reinterpret_cast<float*>(WS(p, p->o_cs)); a.ws_elems = p->cs_elems;     // bias-gradient slab sums of a 256x256-tile problem
+        if (nsl > 1) { a.k_split = p->Bp / nsl; a.slab_stride = a.slab_stride2 = p->param_elems; }       // slice y -> slab y (gemm_bf16_body)
+        auto cs = p->csum_of.find(dY);
+        if (cs != p->csum_of.end() && cs->second.second == N) {      // ... unless dY's producer left its column sums
+            a.csum_in = cs->second.first; a.csum_ld = N; a.csum_rows = p->Bp / 256;
         }
+        p->dw_queue.push_back(a);
         return 0;
     }
     return gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_DW, Mdim, N, p->Bp, X, ldx, dY, ldy, &e, split);
 }
 
 // Launch the queued weight-gradient problems as ONE grouped grid (with the Adam update in its
-// epilogue under dmvae_plan_train_step).  Three forms:
-//   default   everything queues until the last call (group 2): one launch, on the main stream;
-//   staged    (dmvae_plan_forward_backward_stage, data parallel) every group is launched where it
-//             is flushed, so that its gradient bucket is final when the segment ends;
-//   DMVAE_DW_OVERLAP=1   every group goes to the plan's side stream beside the dX chain (fork /
-//             join by events, capturable).  MEASURED (cfg2, round 1): SLOWER, 0.4235 vs 0.391
-//             ms/step -- the dW grid and the dX chain are bound by the same per-CU intake, and
-//             three small groups fill the chip worse than one large one.  Kept for re-measurement.
+// epilogue under dmvae_plan_train_step).  Whole pass: everything queues until the last call (group 2) -- one launch;
+// staged (dmvae_plan_forward_backward_stage, data parallel): every group is launched where it is flushed, so that its gradient
+// bucket is final when the segment ends.  (The groups on a side stream beside the dX chain were measured twice and removed:
+// 0.4235 vs 0.391 ms in round 1, 0.358 vs 0.292 ms in round 2 -- a fork / join pair in a replayed graph costs 15-20 us.)
 static int flush_dw(dmvae_plan* p, hipStream_t s, int group) {
     if (p->dw_queue.empty()) return 0;
-    if (!p->overlap_dw && !p->staged && group != 2) return 0;
-    hipStream_t target = s;
-    if (p->side && p->overlap_dw && !p->staged) {
-        hipError_t e = hipEventRecord(p->ev_fork[group], s);
-        if (e == hipSuccess) e = hipStreamWaitEvent(p->side, p->ev_fork[group], 0);
-        if (e != hipSuccess) { set_error("dW side stream fork: %s", hipGetErrorString(e)); return (int)e; }
-        target = p->side;
-        p->side_busy = true;
-    }
-    return launch_dw_queue(p, target, group == 2);
+    if (!p->staged && group != 2) return 0;
+    return launch_dw_queue(p, s, group == 2);
 }
 
 // one grouped launch of whatever is queued; with_prior: also the prior tables' Adam (once per fused step)
 static int launch_dw_queue(dmvae_plan* p, hipStream_t target, bool with_prior) {
     if (p->dw_queue.empty()) return 0;
     int rc;
+    if (p->dw_slices_now > 1) {    // K slices into slabs, then their fixed-order sum: inside the Adam kernel (fused step) or into the gradient arena
+        const float* slab = reinterpret_cast<const float*>(WS(p, p->o_dwslab));
+        int64_t lo = p->param_elems, hi = 0;
+        for (auto& a : p->dw_queue) {
+            const int64_t w0 = reinterpret_cast<const float*>(a.epi.out) - slab;
+            lo = std::min(lo, w0);
+            hi = std::max(hi, w0 + (int64_t)a.M * a.epi.ldo);
+            if (a.epi.out2) hi = std::max(hi, (reinterpret_cast<const float*>(a.epi.out2) - slab) + (int64_t)a.N);
+        }
+        rc = gemm_bf16_grouped_dw(target, p->dw_queue.data(), (int)p->dw_queue.size());
+        p->dw_queue.clear();
+        if (rc) return rc;
+        if (p->fused_update) {
+            DMVAE_REQUIRE(with_prior && lo == 0, "dW slabs: the fused step flushes ONE group holding every layer");
+            AdamArgs a;
+            a.n = p->param_elems; a.p = p->buf.param; a.g = p->buf.grad; a.m = p->buf.m; a.v = p->buf.v;
+            a.pb = reinterpret_cast<bf16_t*>(p->buf.param_bf16);
+            a.lr = 0.f; a.b1 = p->cfg.beta1; a.b2 = p->cfg.beta2; a.eps = p->cfg.adam_eps; a.gscale = 1.f;
+            a.zero_grad = 0; a.ieee = p->cfg.adam_ieee;
+            a.t_host = ~0ull;                                   // t = state->adam_t, advanced by this step's step_finalize
+            a.st = reinterpret_cast<const dmvae_state*>(p->buf.state);
+            // [hi, param_elems): the prior tables (gradient complete in the arena, written by step_finalize) and the arena's zero tail
+            return adam_slabs_launch(target, a, slab, p->dw_slices_now, p->param_elems, hi, p->param_elems);
+        }
+        return slab_reduce_launch(target, slab + lo, hi - lo, p->dw_slices_now, p->param_elems, p->buf.grad + lo);
+    }
     if (p->fused_update) {    // dmvae_plan_train_step: the Adam update rides in the epilogue of this launch
         dmvae_adam_ctx c;
         memset(&c, 0, sizeof(c));
@@ -774,6 +769,12 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     const int dt = c.dtype;
     const bool all = stage < 0;
     p->staged = !all;
+    if (all || stage == 0) {      // K slices of this pass's dW groups (dw_slices_max).  MEASURED (tools/knob_step.py <cfg> 10 1 2 4, same box):
+        // cfg3 (16384 rows) 1.0065 / 0.9778 / 0.9855 ms per step for 1 / 2 / 4 slices; cfg4 (8192 rows) 0.6623 / 0.7003 / 0.7126 -- the
+        // slabs' extra 8 B per parameter and the separate Adam pass pay only once a tile's K loop is > 128 K tiles: two slices from 16384 rows
+        const int want = g_dw_slices > 0 ? g_dw_slices : (p->Bp >= 16384 ? 2 : 1);
+        p->dw_slices_now = (p->dw_slices_max > 1 && want > 1 && p->Bp % (want * 64) == 0) ? std::min(want, p->dw_slices_max) : 1;
+    }
     const int nd = (int)p->dec.size(), ne = (int)p->enc.size();
     auto cso = [](const std::vector<int64_t>& v, int i) -> int64_t { return v.empty() ? -1 : v[i]; };      // column-sum partials of a dY (bf16, Bp % 256 == 0)
     // Loss scalars, Adam t / lr_t and the prior-table gradients need only the forward partials.  Whole pass, bf16:
@@ -788,10 +789,7 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     // (wide heads -- the 4096-wide configuration -- take the 256x256 macro-tile kernel one by one instead of the grouped grid)
     const bool heads_big = dt == DMVAE_BF16 && gemm_bf16_256_ok(DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK, p->Bp, p->Hp, 2 * p->Dp, false) &&
                            gemm_bf16_256_ok(DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK, p->Bp, p->Hp, p->Kp, false);
-    // (not with the dW groups on the side stream: the first of them starts ahead of the heads launch and its Adam reads lr_t)
-    const bool fin_rides = all && dt == DMVAE_BF16 && p->finalize_rides && !heads_big && !p->vade && !p->overlap_dw;
-    const bool use_mid = g_mid_bwd && !p->overlap_dw && dt == DMVAE_BF16 && !p->vade && !heads_big && p->conv.empty() &&
-                         mid_bwd_applies(p->Bp, p->Dp, p->Kp, p->Hp, p->dec[0].out_pad);
+    const bool fin_rides = all && dt == DMVAE_BF16 && !heads_big && !p->vade;
   if (all || stage == 0) {
     p->dw_queue.clear();
     p->csum_of.clear();
@@ -828,6 +826,12 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
         e.out = WS(p, p->o_dl); e.ldo = p->Ip; e.bias = p->buf.param + L.b_off;
         e.aux0 = WS(p, p->o_xf); e.ld0 = p->Ip; e.partials = reinterpret_cast<float*>(WS(p, p->o_rpart));
         const int Kd = p->dec[nd - 1].out_pad;
+        if (p->tsrc_valid) {      // dmvae_plan_load_batch_step: the targets come from the dataset through the permutation (gemm_bf16_body)
+            e.recon_kind |= 0x100;
+            e.aux0 = p->tsrc.data; e.ld0 = c.input_dim; e.aux1 = p->tsrc.perm; e.ld1 = p->tsrc.first;
+            e.aux2 = p->tsrc.st; e.d_off = c.max_batch; e.ld2 = p->tsrc.n_rows;
+            DMVAE_REQUIRE(p->tsrc.n_valid == n_valid, "dmvae_plan_forward_backward: n_valid=%d, but dmvae_plan_load_batch_step assembled %d rows", n_valid, p->tsrc.n_valid);
+        }
         if (dt == DMVAE_BF16 && p->o_cs_dl >= 0 && gemm_bf16_256_ok(DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_RECON, p->Bp, p->Ip, Kd, false)) {
             GemmArgs a;      // the macro-tile kernel also leaves dLoss/dlogits' column sums = the output bias gradient
             TRY(gemm_checked(s, dt, DMVAE_GEMM_FWD, p->Bp, p->Ip, Kd, WS(p, p->o_dec[nd - 1]), Kd, Wp(p, L.w_off), L.ldw, &e, 1, &a));
@@ -855,7 +859,7 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
             TRY(dx_dense(p, s, WS(p, p->o_ddec[i]), L.out_pad, L.out_pad, L.w_off, L.ldw, L.in_pad,
                          WS(p, p->o_dec[i - 1]), p->dec[i - 1].out_pad, WS(p, p->o_ddec[i - 1]), p->dec[i - 1].out_pad, nullptr,
                          WS(p, p->o_ddec[i - 1]), cso(p->o_cs_ddec, i - 1), p->dec[i - 1].out_pad));
-        } else if (!use_mid) {   // dZ -> [dmean | dlog_var] through the reparameterisation + KL gradients (use_mid: part of mid_bwd, below)
+        } else {   // dZ -> [dmean | dlog_var] through the reparameterisation + KL gradients
             dmvae_epilogue e;
             memset(&e, 0, sizeof(e));
             e.kind = DMVAE_EPI_LATENT; e.out = WS(p, p->o_dmv); e.ldo = 2 * p->Dp; e.d_off = p->Dp;
@@ -873,26 +877,9 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     TRY(flush_dw(p, s, 1));
   } else if (all || stage == 1) {
     // ---- backward: heads
-    if (use_mid) {    // dZ, the latent backward and both head dX GEMMs as one kernel over 16-row blocks
-        MidBwdArgs m;
-        memset(&m, 0, sizeof(m));
-        m.Bp = p->Bp; m.Dp = p->Dp; m.Kp = p->Kp; m.Hp = p->Hp; m.N0 = p->dec[0].out_pad;
-        m.ddec0 = reinterpret_cast<const bf16_t*>(WS(p, p->o_ddec[0])); m.ld_dd = p->dec[0].out_pad;
-        m.Wd0 = reinterpret_cast<const bf16_t*>(Wp(p, p->dec[0].w_off)); m.ld_wd0 = p->dec[0].ldw;
-        m.gmu = reinterpret_cast<const float*>(WS(p, p->o_gmu)); m.glv = reinterpret_cast<const float*>(WS(p, p->o_glv));
-        m.clv = reinterpret_cast<const float*>(WS(p, p->o_clv)); m.ld_g = p->Dp;
-        m.dmv = reinterpret_cast<bf16_t*>(WS(p, p->o_dmv)); m.ld_dmv = 2 * p->Dp;
-        m.dlg = reinterpret_cast<const bf16_t*>(WS(p, p->o_dlg)); m.ld_dlg = p->Kp;
-        m.Wmv = reinterpret_cast<const bf16_t*>(Wp(p, p->mv.w_off)); m.ld_wmv = p->mv.ldw;
-        m.Wlg = reinterpret_cast<const bf16_t*>(Wp(p, p->lg.w_off)); m.ld_wlg = p->lg.ldw;
-        m.hzc = reinterpret_cast<const bf16_t*>(WS(p, p->o_hzc)); m.ld_h = 2 * p->Hp;
-        m.dhzc = reinterpret_cast<bf16_t*>(WS(p, p->o_dhzc)); m.ld_dh = 2 * p->Hp;
-        if (fin_rides) m.fin = fin;
-        TRY(mid_bwd_launch(s, m));
-    }
     TRY(grad_dense(p, s, WS(p, p->o_hzc), 2 * p->Hp, p->Hp, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->mv.b_off));
     TRY(grad_dense(p, s, act_off(p, p->o_hzc, p->Hp), 2 * p->Hp, p->Hp, WS(p, p->o_dlg), p->Kp, p->Kp, p->lg.w_off, p->lg.ldw, p->lg.b_off));
-    if (!use_mid) {   // d(z-hidden) and d(c-hidden): independent siblings writing the two halves of dhzc -> one grouped grid (bf16)
+    {   // d(z-hidden) and d(c-hidden): independent siblings writing the two halves of dhzc -> one grouped grid (bf16)
         GemmArgs q[2];
         const bool grp = dt == DMVAE_BF16 && !heads_big;
         TRY(dx_dense(p, s, WS(p, p->o_dmv), 2 * p->Dp, 2 * p->Dp, p->mv.w_off, p->mv.ldw, p->Hp, WS(p, p->o_hzc), 2 * p->Hp, WS(p, p->o_dhzc), 2 * p->Hp,
@@ -903,15 +890,12 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     }
     // ---- backward: trunk
     TRY(grad_dense(p, s, WS(p, p->o_enc[ne - 1]), p->Tp, p->Tp, WS(p, p->o_dhzc), 2 * p->Hp, 2 * p->Hp, p->zc.w_off, p->zc.ldw, p->zc.b_off));
-    // heads dW group ([mean|log_var], logits, [zh|ch]).  On the side stream with the Adam update in its epilogue it would rewrite
-    // the [zh|ch] weights while the dX GEMM below still reads them: there it is flushed BEHIND that GEMM.
-    if (!(all && p->overlap_dw)) TRY(flush_dw(p, s, 1));
+    TRY(flush_dw(p, s, 1));      // heads dW group ([mean|log_var], logits, [zh|ch]): launched here when staged
   }
   if (all || stage == 2) {
     if (!p->vade) {
         TRY(dx_dense(p, s, WS(p, p->o_dhzc), 2 * p->Hp, 2 * p->Hp, p->zc.w_off, p->zc.ldw, p->Tp, WS(p, p->o_enc[ne - 1]), p->Tp,
                      WS(p, p->o_denc[ne - 1]), p->Tp, nullptr, WS(p, p->o_denc[ne - 1]), cso(p->o_cs_denc, ne - 1), p->Tp));
-        if (all && p->overlap_dw) TRY(flush_dw(p, s, 1));
     }
     for (int i = ne - 1; i >= 0; --i) {
         const PLayer& L = p->enc[i];
@@ -930,12 +914,6 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     TRY(flush_dw(p, s, 2));   // trunk dW group (everything queued so far when not staged)
     if (!p->conv.empty()) TRY(conv_trunk_backward(p, s));
   }
-    if (p->side_busy) {       // join: Adam / the gradient exchange / the next step must see the side stream's work
-        hipError_t e = hipEventRecord(p->ev_join, p->side);
-        if (e == hipSuccess) e = hipStreamWaitEvent(s, p->ev_join, 0);
-        p->side_busy = false;
-        if (e != hipSuccess) { set_error("side stream join: %s", hipGetErrorString(e)); return (int)e; }
-    }
     return 0;
 }
 
@@ -1022,6 +1000,7 @@ extern "C" int dmvae_plan_view(const dmvae_plan* p, const char* name, void** ptr
 // ====================================================================== thin C wrappers
 extern "C" int dmvae_gemm(void* stream, int dtype, int layout, int M, int N, int K, const void* A, int64_t lda,
                           const void* B, int64_t ldb, const dmvae_epilogue* epi, int split_k) {
+    DMVAE_REQUIRE(!epi || (epi->recon_kind == 0 || epi->recon_kind == 1), "dmvae_gemm: recon_kind %d (0 binary, 1 real)", epi ? epi->recon_kind : 0);
     return gemm_checked((hipStream_t)stream, dtype, layout, M, N, K, A, lda, B, ldb, epi, split_k);
 }
 extern "C" int dmvae_gemm_partials(int dtype, int M, int N) { return gemm_partials(dtype, M, N); }
@@ -1122,20 +1101,6 @@ extern "C" int dmvae_cast_bf16_to_f32(void* stream, const void* in, float* out, 
 }
 
 extern "C" int dmvae_debug_spin(void* stream, int microseconds) { return spin_launch((hipStream_t)stream, microseconds); }
-// probe (tools/chain_probe.py): nlayer square bias + ReLU layers [M x N] as ONE XCD-sliced launch; layer l reads act[l % 2], writes act[(l + 1) % 2]
-extern "C" int dmvae_debug_chain(void* stream, int variant, int nlayer, int M, int N, void* act0, void* act1, const void* const* W,
-                                 const float* const* bias, void* sync, int* err) {
-    DMVAE_REQUIRE(nlayer >= 1 && nlayer <= 8 && act0 && act1 && W && bias && sync && err, "dmvae_debug_chain: bad arguments");
-    GemmArgs layers[8];
-    for (int l = 0; l < nlayer; ++l) {
-        dmvae_epilogue e;
-        memset(&e, 0, sizeof(e));
-        e.kind = DMVAE_EPI_BIAS_RELU; e.out = (l % 2) ? act0 : act1; e.ldo = N; e.bias = bias[l];
-        TRY(gemm_checked((hipStream_t)stream, DMVAE_BF16, DMVAE_GEMM_FWD, M, N, N, (l % 2) ? act1 : act0, N, W[l], N, &e, 1, &layers[l]));
-    }
-    return chain_probe_launch((hipStream_t)stream, variant, nlayer, layers, reinterpret_cast<unsigned*>(sync), err);
-}
-
 extern "C" int dmvae_debug_stamps(void** device_ptr) {
     if (!device_ptr) return DMVAE_EINVAL;
     *device_ptr = gemm_bf16_stamps();
@@ -1211,7 +1176,7 @@ extern "C" int dmvae_debug_set_tile(int bm, int bn) {
 }
 
 extern "C" int dmvae_debug_set_knob(int which, int value) {
-    if (which == 9) { g_mid_bwd = value; return 0; }
+    if (which == 10) { g_dw_slices = value; return 0; }
     DMVAE_REQUIRE(which >= 0 && which <= 8, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, 3 = ring depth policy, 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy, 7 = short-K workgroups, 8 = first-tile stagger of the merged dW grid");
     gemm_bf16_set_knob(which, value);
     return 0;

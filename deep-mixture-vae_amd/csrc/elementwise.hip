@@ -46,6 +46,51 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(AdamArgs a) {
 }
 __global__ void adam_finish_kernel(dmvae_state* st) { st->adam_t += 1; }
 
+// The same update for a gradient that arrives as nslab (2..16) K-slice slabs of the weight-gradient GEMMs (split-K without float
+// atomics: the dW group of a large batch, csrc/api.hip grad_dense): element i of the gradient = slab 0 + slab 1 + ... in ASCENDING
+// order -- the order slab_reduce_kernel uses for <= 16 slabs, including its trailing + 0 (a sum of -0s becomes +0 there), so the
+// fused form and slab_reduce -> adam_tf give the same bits.  Elements of [seg_lo, seg_hi) (the prior tables: their gradient comes
+// complete from step_finalize) take a.g instead.  30 + 4 nslab bytes per parameter.
+__global__ __launch_bounds__(256) void adam_slabs_kernel(AdamArgs a, const float* __restrict__ slabs, int nslab, int64_t stride, int64_t seg_lo, int64_t seg_hi) {
+    const uint64_t t = a.st ? (a.t_host == ~0ull ? a.st->adam_t : a.st->adam_t + 1) : a.t_host;
+    const float lr_t = adam_lr_t(a.st ? a.st->lr : a.lr, a.b1, a.b2, t);
+    const int64_t n4 = a.n >> 2, stride4 = stride >> 2;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += step) {
+        float4 p = reinterpret_cast<float4*>(a.p)[i];
+        float4 m = reinterpret_cast<float4*>(a.m)[i];
+        float4 v = reinterpret_cast<float4*>(a.v)[i];
+        float4 g;
+        if (4 * i >= seg_lo && 4 * i < seg_hi) g = reinterpret_cast<const float4*>(a.g)[i];
+        else {
+            g = reinterpret_cast<const float4*>(slabs)[i];
+            for (int s = 1; s < nslab; ++s) {
+                const float4 b = reinterpret_cast<const float4*>(slabs)[(int64_t)s * stride4 + i];
+                g.x += b.x; g.y += b.y; g.z += b.z; g.w += b.w;
+            }
+            if (nslab < 16) { g.x += 0.f; g.y += 0.f; g.z += 0.f; g.w += 0.f; }
+        }
+        float* pp = &p.x; float* gp = &g.x; float* mp = &m.x; float* vp = &v.x;
+        if (a.pb && !a.ieee) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) adam_elem<true>(pp[j], mp[j], vp[j], gp[j], a.gscale, a.b1, a.b2, a.eps, lr_t);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) adam_elem<false>(pp[j], mp[j], vp[j], gp[j], a.gscale, a.b1, a.b2, a.eps, lr_t);
+        }
+        reinterpret_cast<float4*>(a.p)[i] = p;
+        reinterpret_cast<float4*>(a.m)[i] = m;
+        reinterpret_cast<float4*>(a.v)[i] = v;
+        if (a.pb) {
+            uint2 q;
+            q.x = pack2bf(p.x, p.y);
+            q.y = pack2bf(p.z, p.w);
+            reinterpret_cast<uint2*>(a.pb)[i] = q;
+        }
+        if (a.zero_grad) reinterpret_cast<float4*>(a.g)[i] = g;      // here: KEEP the summed gradient (store_grad), never zero it
+    }
+}
+
 int adam_launch(hipStream_t s, const AdamArgs& a) {
     const int64_t n4 = a.n >> 2;
     int blocks = (int)((n4 + 255) / 256);
@@ -54,6 +99,14 @@ int adam_launch(hipStream_t s, const AdamArgs& a) {
     ProfScope ps(s, "adam_tf", 12.0 * a.n, (28.0 + (a.pb ? 2.0 : 0.0) + (a.zero_grad ? 4.0 : 0.0)) * a.n);
     DMVAE_LAUNCH(adam_tf_kernel, dim3(blocks), dim3(256), 0, s, a);
     return check_launch("adam_tf");
+}
+int adam_slabs_launch(hipStream_t s, const AdamArgs& a, const float* slabs, int nslab, int64_t stride, int64_t seg_lo, int64_t seg_hi) {
+    if (a.n % 4 || stride % 4 || seg_lo % 4 || seg_hi % 4 || nslab < 2 || nslab > 16) { set_error("adam_slabs: sizes must be multiples of 4, 2..16 slabs"); return DMVAE_EINVAL; }
+    const int64_t n4 = a.n >> 2;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (n4 + 255) / 256));
+    ProfScope ps(s, "adam_slabs", (12.0 + nslab) * a.n, (24.0 + (a.pb ? 2.0 : 0.0) + 4.0 * nslab) * a.n);
+    DMVAE_LAUNCH(adam_slabs_kernel, dim3(blocks), dim3(256), 0, s, a, slabs, nslab, stride, seg_lo, seg_hi);
+    return check_launch("adam_slabs");
 }
 int adam_finish_launch(hipStream_t s, void* st) {
     DMVAE_LAUNCH(adam_finish_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<dmvae_state*>(st));

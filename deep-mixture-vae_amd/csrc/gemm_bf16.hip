@@ -72,11 +72,9 @@ namespace dmvae {
 // BKT = K depth of one ring slot (64; 32 is available to the dW layout: a 128x128 tile then gets a
 // 4-slot ring in the same 64 KiB, i.e. 48 KiB instead of 32 KiB in flight).
 // CONV: conv mode (GemmArgs::conv_c, gemm_epilogue.h) -- a compile-time variant, so the dense kernels carry none of it.
-// GATHER: the k-contiguous A operand's rows are rows of a bf16 dataset copy picked through the epoch's permutation (GatherSrc, kernels.h).
-template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW, int BKT = BK, bool CONV = false, bool GATHER = false>
+template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW, int BKT = BK, bool CONV = false>
 __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_raw, const int gstart, const int nwg, bf16_t* smem,
-                                               const dmvae_adam_ctx* ac = nullptr, const int kslice = -1, const GatherSrc* gs = nullptr) {
-    static_assert(!GATHER || (LAYOUT == DMVAE_GEMM_FWD && !CONV), "gather mode: the forward layout's A operand");
+                                               const dmvae_adam_ctx* ac = nullptr, const int kslice = -1) {
     constexpr bool A_KC = (LAYOUT != DMVAE_GEMM_DW);
     constexpr bool B_KC = (LAYOUT == DMVAE_GEMM_DX);
     constexpr int A_ELEMS = BM * BKT, B_ELEMS = BN * BKT, STAGE = A_ELEMS + B_ELEMS;
@@ -142,22 +140,6 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     unsigned goA[BM * BKT / (512 * NW)], goB[BN * BKT / (512 * NW)];
     stage_offsets<BM, A_KC, NW, BKT>(a.lda, wave, lane, goA);
     stage_offsets<BN, B_KC, NW, BKT>(a.ldb, wave, lane, goB);
-    if constexpr (GATHER) {       // row m of the batch = dataset row perm[first + m]; rows past n_valid: the all-zero row
-        const dmvae_state* gst = reinterpret_cast<const dmvae_state*>(gs->st);
-        const int64_t first = gst ? (int64_t)gst->batch_cursor * gs->batch : gs->first;
-        Ag = gs->shadow + kbeg;
-#pragma unroll
-        for (int i = 0; i < BM * BKT / (512 * NW); ++i) {
-            const int row = i * (8 * NW) + wave * 8 + (lane >> 3), m = m0 + row;
-            int64_t src = gs->zero_row;
-            if (m < gs->n_valid) {
-                src = first + m;
-                if (gs->perm) src = gs->perm[src];
-                if (src < 0 || src >= gs->n_rows) src = gs->zero_row;
-            }
-            goA[i] = 2u * (unsigned)(src * gs->ld_s + swz_kc(row, lane & 7) * 8);
-        }
-    }
     // Conv mode: K (or, for the weight gradient, M) runs over (tap, channel) with conv_c channels per tap, and an
     // operand row holds lda >= conv_c channels.  conv_c >= 64: a 64-wide tile lies inside one tap.  conv_c = 32 (the
     // 32-channel layers, stored with 32 zero pad channels): a tile covers TWO taps -- 16-byte chunks 0..3 belong to
@@ -277,10 +259,30 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     constexpr int NQ = BM * (BN / 4) / (64 * NW);
     float4 target[EPI == DMVAE_EPI_BIAS_RECON ? NQ : 1];       // BIAS_RECON: likewise the f32 reconstruction targets
     if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
+        // recon_kind bit 8 (the plan's step path, dmvae_plan_load_batch_step): no f32 copy of the batch exists -- row m's targets are
+        // row perm[first + m] of the dataset itself: aux0 = data [ld2 rows][ld0 = input_dim floats], aux1 = perm (int32 or null),
+        // ld1 = first, or batch_cursor * d_off when aux2 = the device state; rows >= m_valid and pad columns are zeros (masked anyway)
+        const bool tg = (a.epi.recon_kind & 0x100) != 0;
+        int64_t tfirst = 0;
+        if (tg) {
+            const dmvae_state* tst = reinterpret_cast<const dmvae_state*>(a.epi.aux2);
+            tfirst = tst ? (int64_t)tst->batch_cursor * a.epi.d_off : a.epi.ld1;
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int idx = q * (64 * NW) + tid;
             const int ml = idx / (BN / 4), c = idx % (BN / 4);
+            if (tg) {
+                const int m = m0 + ml, n = n0 + c * 4;
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < a.epi.m_valid && n + 3 < (int)a.epi.ld0) {
+                    int64_t src = tfirst + m;
+                    const int32_t* perm = reinterpret_cast<const int32_t*>(a.epi.aux1);
+                    if (perm) src = perm[src];
+                    if (src >= 0 && src < a.epi.ld2) t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.epi.aux0) + src * a.epi.ld0 + n);
+                }
+                target[q] = t;
+            } else
             target[q] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.epi.aux0) + (int64_t)(m0 + ml) * a.epi.ld0 + n0 + c * 4);
         }
     }
@@ -358,8 +360,10 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     static_assert(BM * BN * 4 <= NSTAGE * STAGE * 2, "fp32 tile must fit in the ring");
     // deterministic split-K (conv weight gradient, cfg.deterministic): K slice y stores into its own slab, summed in a fixed
     // order by slab_reduce afterwards -- no float atomics
+    // ... and likewise the K slices of a dense weight-gradient problem (GemmArgs::slab_stride != 0: the dW group of a large batch,
+    // whose tile count is fixed by the parameter shapes while K grows with the batch; the slabs are added by adam_slabs / slab_reduce)
     dmvae_epilogue epi_s = a.epi;
-    if constexpr (CONV && EPI == DMVAE_EPI_STORE_F32) {
+    if constexpr (EPI == DMVAE_EPI_STORE_F32 && (CONV || LAYOUT == DMVAE_GEMM_DW)) {
         const int ys = kslice >= 0 ? kslice : (int)blockIdx.y;
         epi_s.out = reinterpret_cast<float*>(epi_s.out) + (int64_t)ys * a.slab_stride;
         if (epi_s.out2) epi_s.out2 = reinterpret_cast<float*>(epi_s.out2) + (int64_t)ys * a.slab_stride2;
@@ -521,6 +525,7 @@ struct GroupedArgs {
     int kind[DMVAE_MAX_GROUP];
     int start[DMVAE_MAX_GROUP + 1];
     int cls_start[DMVAE_MAX_GROUP], cls_end[DMVAE_MAX_GROUP];
+    int nsl[DMVAE_MAX_GROUP];         // K slices of problem i (K / k_split; 1 = none): its workgroups are slice-major, [slice][tile]
     GemmArgs p[DMVAE_MAX_GROUP];
     dmvae_adam_ctx adam;      // DMVAE_EPI_ADAM launches only
     dmvae_finalize_args fin;  // DMVAE_EPI_RELU_MASK launches: fin.nblocks extra workgroups run step_finalize (0 = none)
@@ -562,19 +567,25 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_grouped_kernel(GroupedArgs 
     const int item = g.cls_start[i] + xcd_run_index((int)blockIdx.x, g.cls_start[i], g.cls_end[i]);
     i = 0;
     while (i + 1 < g.nprob && item >= g.start[i + 1]) ++i;
-    const int bid = item - g.start[i];
+    int bid = item - g.start[i];
     const int kind = g.kind[i];
     const int gs = 0, cnt = -1;                           // the body takes bid as the tile id
+    int ksl = -1;                                         // K slice of a split problem (DW / STORE_F32 into slabs), else blockIdx.y = 0
+    if (g.nsl[i] > 1) {
+        const int tiles_i = (g.start[i + 1] - g.start[i]) / g.nsl[i];
+        ksl = bid / tiles_i;
+        bid -= ksl * tiles_i;
+    }
 #if DMVAE_ABLATE == 6     // placement / timeline stamps of every workgroup (tools/stamps.py)
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // (a 4-slot ring of K depth 32 in the same 64 KiB was measured for the 128x128 dW tiles: no gain)
     if constexpr (SHORTK) {
-        gemm_bf16_body<64, 64, LAYOUT, EPI, 2, NW>(g.p[i], bid, gs, cnt, smem, ac);
+        gemm_bf16_body<64, 64, LAYOUT, EPI, 2, NW>(g.p[i], bid, gs, cnt, smem, ac, ksl);
     } else {
-        if (kind == 0) gemm_bf16_body<128, 128, LAYOUT, EPI, 2, NW>(g.p[i], bid, gs, cnt, smem, ac);
-        else if (kind == 1) gemm_bf16_body<128, 64, LAYOUT, EPI, 3, NW>(g.p[i], bid, gs, cnt, smem, ac);
-        else gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW>(g.p[i], bid, gs, cnt, smem, ac);
+        if (kind == 0) gemm_bf16_body<128, 128, LAYOUT, EPI, 2, NW>(g.p[i], bid, gs, cnt, smem, ac, ksl);
+        else if (kind == 1) gemm_bf16_body<128, 64, LAYOUT, EPI, 3, NW>(g.p[i], bid, gs, cnt, smem, ac, ksl);
+        else gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW>(g.p[i], bid, gs, cnt, smem, ac, ksl);
     }
 #if DMVAE_ABLATE == 6
     if (threadIdx.x == 0 && blockIdx.x < 2048) {
@@ -661,10 +672,11 @@ static int launch_conv(hipStream_t s, const GemmArgs& a, int split) {
 template <int LAYOUT, int EPI>
 static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const dmvae_adam_ctx* ctx = nullptr, const dmvae_finalize_args* fin = nullptr) {
     auto best_kind = [](const GemmArgs& p) { return (p.M % 128 == 0 && p.N % 128 == 0) ? 0 : (p.M % 128 == 0 ? 1 : 2); };
-    auto tiles = [](const GemmArgs& p, int kind) { return (p.M / (kind == 2 ? 64 : 128)) * (p.N / (kind == 0 ? 128 : 64)); };
+    auto nslices = [](const GemmArgs& p) { return (p.k_split > 0 && p.k_split < p.K) ? p.K / p.k_split : 1; };
+    auto tiles = [&](const GemmArgs& p, int kind) { return (p.M / (kind == 2 ? 64 : 128)) * (p.N / (kind == 0 ? 128 : 64)) * nslices(p); };     // workgroups: tiles x K slices
     // bytes one workgroup of this kind streams into LDS: these kernels run at the per-CU L2->LDS
     // intake rate (~70 GB/s), so a workgroup's duration is proportional to it
-    auto wg_bytes = [](const GemmArgs& p, int kind) { return 2.0 * ((kind == 2 ? 64 : 128) + (kind == 0 ? 128 : 64)) * (double)p.K; };
+    auto wg_bytes = [&](const GemmArgs& p, int kind) { return 2.0 * ((kind == 2 ? 64 : 128) + (kind == 0 ? 128 : 64)) * (double)(p.K / nslices(p)); };
     // Tile plan.  Every workgroup is resident at once (<= 2 per CU) and the dispatcher deals them
     // breadth-first in launch order (measured, tools/stamps.py): launched longest-first, workgroup
     // j lands on CU j mod 256, so CU c streams s[c] + s[c+256] + ... bytes.  Every problem may use
@@ -679,7 +691,7 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
         static std::mutex mu;
         static std::map<std::vector<int>, std::vector<int>> memo;
         std::vector<int> key;
-        for (int i = 0; i < nprob; ++i) { key.push_back(probs[i].M); key.push_back(probs[i].N); key.push_back(probs[i].K); }
+        for (int i = 0; i < nprob; ++i) { key.push_back(probs[i].M); key.push_back(probs[i].N); key.push_back(probs[i].K); key.push_back(nslices(probs[i])); }
         std::lock_guard<std::mutex> lk(mu);
         auto it = memo.find(key);
         if (it == memo.end()) {
@@ -719,6 +731,7 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
         const int i = order[o], kind = kinds[i];
         g.start[n] = total;
         g.kind[n] = kind;
+        g.nsl[n] = nslices(probs[i]);
         g.p[n] = probs[i];
         g.p[n].group_m = gemm_auto_group_m(probs[i].M / (kind == 2 ? 64 : 128), probs[i].N / (kind == 0 ? 128 : 64),
                                       kind == 2 ? 64 : 128, kind == 0 ? 128 : 64);
@@ -727,7 +740,7 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
         bytes += gemm_bytes(probs[i]);
         ++n;
     }
-    for (int i = nprob; i < DMVAE_MAX_GROUP; ++i) g.kind[i] = 2;
+    for (int i = nprob; i < DMVAE_MAX_GROUP; ++i) { g.kind[i] = 2; g.nsl[i] = 1; }
     for (int i = nprob; i <= DMVAE_MAX_GROUP; ++i) g.start[i] = total;
     // classes: runs of consecutive problems with one tile shape (see the kernel); knob 4 = 0 makes
     // every problem its own class (each problem spread over all eight XCDs)
@@ -741,7 +754,7 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
                 g.cls_start[i] = g.start[lo];
                 g.cls_end[i] = g.start[hi];
                 const int kind = g.kind[i], bm = kind == 2 ? 64 : 128, bn = kind == 0 ? 128 : 64;
-                const int t = g.start[i + 1] - g.start[i];
+                const int t = (g.start[i + 1] - g.start[i]) / g.nsl[i];
                 g.p[i].group_m = gemm_auto_group_m(g.p[i].M / bm, g.p[i].N / bn, bm, bn, std::min<double>(t, run));
             }
             lo = hi;
@@ -966,157 +979,6 @@ int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split) 
 #undef CASE
     set_error("dmvae_gemm(bf16): layout %d with epilogue %d is not instantiated", layout, epi);
     return DMVAE_EUNSUPPORTED;
-}
-
-// ---------------------------------------------------------------- first layer with the batch gather folded in
-// workgroups [0, ntiles): output tiles in gather mode; the rest: the batch's act / f32 copies (gather_kernel's loop, elementwise.hip)
-__device__ __forceinline__ void gather_rows_block(const GatherSrc& g, const int bid, const int nb, const int nthreads) {
-    const dmvae_state* gst = reinterpret_cast<const dmvae_state*>(g.st);
-    const int64_t first = gst ? (int64_t)gst->batch_cursor * g.batch : g.first;
-    const int quads = g.cols_pad >> 2;
-    const int64_t total = (int64_t)g.B_pad * quads;
-    for (int64_t i = (int64_t)bid * nthreads + threadIdx.x; i < total; i += (int64_t)nb * nthreads) {
-        const int r = (int)(i / quads), c = (int)(i % quads) * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (r < g.n_valid) {
-            int64_t src = first + r;
-            if (g.perm) src = g.perm[src];
-            if (src >= 0 && src < g.n_rows) {
-                const float* p = g.data + src * g.dim + c;
-                if (c + 3 < g.dim && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-                    const float4 q = *reinterpret_cast<const float4*>(p);
-                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = (c + j < g.dim) ? p[j] : 0.f;
-                }
-            }
-        }
-        if (g.out_act) ActIO<bf16_t>::store4(g.out_act, (int64_t)r * g.ld_act + c, v);
-        if (g.out_f32) ActIO<float>::store4(g.out_f32, (int64_t)r * g.ld_f32 + c, v);
-    }
-}
-
-template <int BM, int BN, int NSTAGE, int NW>
-__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_bf16_gather_kernel(GemmArgs a, GatherSrc g, int ntiles) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * (BM + BN) * BK];
-    if ((int)blockIdx.x >= ntiles) {
-        gather_rows_block(g, (int)blockIdx.x - ntiles, (int)gridDim.x - ntiles, 64 * NW);
-        return;
-    }
-    gemm_bf16_body<BM, BN, DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_RELU, NSTAGE, NW, BK, false, true>(a, blockIdx.x, 0, ntiles, smem, nullptr, -1, &g);
-}
-
-bool gemm_bf16_gather_ok(int M, int N, int K) {
-    return M % 64 == 0 && N % 64 == 0 && K % 64 == 0 && !gemm_bf16_256_ok(DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_RELU, M, N, K, false);
-}
-
-template <int BM, int BN, int NSTAGE, int NW>
-static int launch_gather(hipStream_t s, const GemmArgs& a, const GatherSrc& g) {
-    const int ntiles = (a.M / BM) * (a.N / BN);
-    // riders: the copies are ~B x cols x 10 bytes; as many workgroups as fill the CUs' second slots, at least 64
-    const int riders = std::max(64, std::min(256, 512 - std::min(ntiles, 512)));
-    ProfScope ps(s, "gemm_bf16_gather_kernel", 2.0 * a.M * a.N * (double)a.K,
-                 gemm_bytes(a) + (double)g.n_valid * g.dim * 4.0 + (double)g.B_pad * g.cols_pad * 6.0);
-    DMVAE_LAUNCH((gemm_bf16_gather_kernel<BM, BN, NSTAGE, NW>), dim3(ntiles + riders), dim3(64 * NW), 0, s, a, g, ntiles);
-    return check_launch("gemm_bf16_gather");
-}
-
-int gemm_bf16_gather_launch(hipStream_t s, const GemmArgs& a0, const GatherSrc& g) {
-    GemmArgs a = a0;
-    if (a.epi.kind != DMVAE_EPI_BIAS_RELU || !gemm_bf16_gather_ok(a.M, a.N, a.K) || a.conv_c) { set_error("gemm_bf16_gather: bias + ReLU forward layer, not the macro tile's"); return DMVAE_EUNSUPPORTED; }
-    if ((g.zero_row + 1) * g.ld_s * 2 >= ((int64_t)1 << 32)) { set_error("gemm_bf16_gather: dataset copy larger than 4 GiB"); return DMVAE_EUNSUPPORTED; }
-    const int t = gemm_bf16_tile_m(a.M, a.N, 1);
-    a.group_m = gemm_auto_group_m(a.M / (t / 1000), a.N / (t % 1000), t / 1000, t % 1000);
-    switch (t) {
-        case 128128: return launch_gather<128, 128, 2, 8>(s, a, g);
-        case 128064: return launch_gather<128, 64, 3, 8>(s, a, g);
-        case 64128: return launch_gather<64, 128, 3, 4>(s, a, g);
-        default: return launch_gather<64, 64, 4, 4>(s, a, g);
-    }
-}
-
-// ---------------------------------------------------------------- XCD-sliced layer chain (probe)
-// A dependent chain of dense layers is row-parallel: row block r of layer l + 1 needs row block r of layer l only.  Kernel
-// boundaries between the layers cost the fill / drain of a grid and, on this chip, an L2 write-back + invalidate (the eight
-// XCDs' L2s are not coherent with one another): every layer starts from cold activations.  Here ONE launch runs the whole
-// chain; the workgroups that share a physical XCD (HW_REG_XCC_ID, read at run time -- never assumed from blockIdx) own one
-// eighth of the rows through every layer, so a layer's output stays in THAT XCD's L2 for the next layer and the only
-// synchronisation is a barrier among the XCD's own workgroups.  Correctness does not depend on placement: membership is
-// measured, data only ever flows between workgroups of one measured XCD, and every wait is bounded (err != 0 instead of a hang).
-constexpr int CHAIN_MAX = 8;
-struct ChainArgs {
-    int nlayer, variant;          // variant 0: L1 invalidate only between layers; 1: agent-scope release / acquire fences (the kernel-boundary semantics)
-    unsigned* sync;               // zeroed by the host before the launch: [0] registrations, [16 + 64 x + 0] members of XCD x, [16 + 64 x + 1 + l] arrivals behind layer l
-    int* err;
-    GemmArgs layer[CHAIN_MAX];
-};
-static_assert(sizeof(ChainArgs) <= 4096, "kernel argument block");
-
-__device__ __forceinline__ bool chain_wait(const unsigned* p, unsigned target, int* err) {
-    for (int spin = 0; spin < (1 << 22); ++spin) {
-        if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
-        __builtin_amdgcn_s_sleep(2);
-    }
-    *err = 1;
-    return false;
-}
-
-template <int BM, int BN, int NSTAGE, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void chain_probe_kernel(ChainArgs c) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * (BM + BN) * BK];
-    __shared__ int sh[2];
-    const int xcc = (int)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;        // HW_REG_XCC_ID
-    unsigned* xs = c.sync + 16 + 64 * xcc;
-    if (threadIdx.x == 0) {
-        sh[0] = (int)__hip_atomic_fetch_add(xs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(c.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool ok = chain_wait(c.sync, gridDim.x, c.err);                    // every workgroup has registered: the XCD head counts are final
-        int nx = ok ? (int)__hip_atomic_load(xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        for (int x = 0; ok && x < 8; ++x)
-            if (__hip_atomic_load(c.sync + 16 + 64 * x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) { *c.err = 2; nx = 0; }     // an XCD without workgroups: its rows would have no owner
-        sh[1] = nx;
-    }
-    __syncthreads();
-    const int rank = sh[0], nx = sh[1];
-    if (nx == 0) return;
-    for (int l = 0; l < c.nlayer; ++l) {
-        const GemmArgs& a = c.layer[l];
-        const int tiles_m = a.M / BM, tiles_ms = tiles_m / 8, tiles_n = a.N / BN;      // (host: a.group_m = tiles_m, M % (8 BM) == 0)
-        for (int t = rank; t < tiles_ms * tiles_n; t += nx) {
-            const int tm = xcc * tiles_ms + t % tiles_ms, tn = t / tiles_ms;
-            gemm_bf16_body<BM, BN, DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_RELU, NSTAGE, NW>(a, tn * tiles_m + tm, 0, -1, smem);
-            __syncthreads();                                                    // the ring is free again
-        }
-        if (l + 1 == c.nlayer) break;
-        // XCD barrier: this workgroup's stores are in the XCD's L2 (vmcnt(0): acknowledged), then arrive / wait, then drop stale L1 lines
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (c.variant == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(xs + 1 + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sh[1] = chain_wait(xs + 1 + l, (unsigned)nx, c.err) ? nx : 0;
-        }
-        __syncthreads();
-        if (sh[1] == 0) return;
-        if (c.variant == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        else asm volatile("buffer_inv sc0" ::: "memory");
-    }
-}
-
-int chain_probe_launch(hipStream_t s, int variant, int nlayer, const GemmArgs* layers, unsigned* sync, int* err) {
-    if (nlayer < 1 || nlayer > CHAIN_MAX) { set_error("chain probe: 1..%d layers", CHAIN_MAX); return DMVAE_EINVAL; }
-    ChainArgs c{};
-    c.nlayer = nlayer; c.variant = variant; c.sync = sync; c.err = err;
-    for (int l = 0; l < nlayer; ++l) {
-        c.layer[l] = layers[l];
-        if (layers[l].M % (8 * 128) || layers[l].N % 64 || layers[l].epi.kind != DMVAE_EPI_BIAS_RELU) { set_error("chain probe: M %% 1024, N %% 64, bias + ReLU layers"); return DMVAE_EINVAL; }
-        c.layer[l].group_m = layers[l].M / 128;
-    }
-    hipError_t e = hipMemsetAsync(sync, 0, sizeof(unsigned) * (16 + 64 * 8), s);
-    if (e != hipSuccess) { set_error("chain probe: memset: %s", hipGetErrorString(e)); return (int)e; }
-    DMVAE_LAUNCH((chain_probe_kernel<128, 64, 3, 8>), dim3(256), dim3(512), 0, s, c);
-    return check_launch("chain_probe");
 }
 
 }  // namespace dmvae

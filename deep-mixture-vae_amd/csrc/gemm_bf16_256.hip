@@ -429,6 +429,9 @@ bool gemm_bf16_256_ok(int layout, int epi, int M, int N, int K, bool conv) {
     return tiles >= 192 && (K >= 1024 || (layout == DMVAE_GEMM_DX && N >= 4096 && M >= 4096));
 }
 
+template <int EPI>
+static int launch256_dw_multi(hipStream_t s, const GemmArgs* probs, int n, const dmvae_adam_ctx* ctx);
+
 template <int LAYOUT, int EPI>
 static int launch256(hipStream_t s, const GemmArgs& a0, const dmvae_adam_ctx* ctx) {
     GemmArgs a = a0;
@@ -465,6 +468,14 @@ static int launch256(hipStream_t s, const GemmArgs& a0, const dmvae_adam_ctx* ct
         bs.part = ws; bs.nslab = nslab; bs.n = a.N; bs.out = reinterpret_cast<float*>(a.epi.out2);
         extra = std::min(8, (a.N / 4 + 511) / 512);
     }
+    if constexpr (LAYOUT == DMVAE_GEMM_DW && EPI == DMVAE_EPI_ADAM) {
+        // a single weight-gradient problem with the fused update runs as a one-problem grid of the MERGED kernel: the single-problem
+        // instantiation gemm_bf16_256_kernel<DW, ADAM> compiled to 256 VGPRs + 15 spills; the merged one is clean
+        // (220-222 VGPRs) and is the one the step uses anyway.  Same tiles, same epilogue, same bits.
+        if (a.epi.out2) { a.csum_in = bs.part; a.csum_rows = bs.nslab; a.csum_ld = a.N; }
+        (void)extra;
+        return launch256_dw_multi<DMVAE_EPI_ADAM>(s, &a, 1, ctx);
+    } else {
     static const std::string nm = [] {
         char b[64];
         snprintf(b, sizeof(b), "gemm_bf16_256_kernel<%d, %d>", LAYOUT, EPI);
@@ -476,6 +487,7 @@ static int launch256(hipStream_t s, const GemmArgs& a0, const dmvae_adam_ctx* ct
     ProfScope ps(s, nm.c_str(), 2.0 * a.M * a.N * (double)a.K, bytes);
     DMVAE_LAUNCH((gemm_bf16_256_kernel<LAYOUT, EPI>), dim3(tiles + extra), dim3(512), 0, s, a, c, tiles, bs);
     return check_launch("gemm_bf16_256");
+    }
 }
 
 static int g_stagger = 0;       // tuning knob (dmvae_debug_set_knob 8): first-tile delay of the merged dW grid, units of 3.4 us spread over the 256 CUs.

@@ -132,7 +132,7 @@ __device__ __forceinline__ void epilogue_quad(const dmvae_epilogue& e, int m, in
             const float l = v[j] + b[j];
             v[j] = l;
             const bool ok = rowok && (n + j) < e.n_valid;
-            if (e.recon_kind == 0) {
+            if ((e.recon_kind & 0xff) == 0) {
                 float xe, sg;
                 xent_sigmoid(l, x[j], xe, sg);
                 loss += ok ? xe : 0.f;

@@ -44,6 +44,9 @@ int64_t latent_mfma_ws_bytes(int B_pad, int D, int K);
 int latent_mfma_launch(hipStream_t s, const dmvae_latent_args* a, float* ws, int64_t ws_bytes);
 int adam_launch(hipStream_t s, const AdamArgs& a);
 int adam_finish_launch(hipStream_t s, void* st);
+// TF-Adam on a gradient that arrives as nslab K-slice slabs (slab j at slabs + j * stride; same element offsets as the arenas);
+// [seg_lo, seg_hi): elements whose gradient is complete in a.g instead (prior tables)
+int adam_slabs_launch(hipStream_t s, const AdamArgs& a, const float* slabs, int nslab, int64_t stride, int64_t seg_lo, int64_t seg_hi);
 int slab_reduce_launch(hipStream_t s, const float* slabs, int64_t n, int nslab, int64_t stride, float* out);
 int colsum_prepare(int64_t max_n);
 float* colsum_global_scratch(int64_t* elems);
@@ -63,19 +66,6 @@ int spin_launch(hipStream_t s, int us);
 void* gemm_bf16_stamps();
 void* gemm_bf16_anatomy();
 void* gemm_bf16_256_anatomy();
-// Batch assembly folded into the first dense layer (Dataset.get_batches, includes/utils.py:449-463): the forward GEMM reads its
-// rows straight from a bf16 copy of the dataset through the epoch's permutation, and spare workgroups of the same launch write
-// the batch's act / f32 copies (weight gradient of the first layer, reconstruction targets) -- no gather launch in front.
-struct GatherSrc {
-    const bf16_t* shadow; int64_t ld_s; int64_t zero_row;      // bf16 dataset [>= n_rows + 1][ld_s], pad columns and row zero_row all zero
-    const float* data; int dim; int64_t n_rows;
-    const int32_t* perm; int64_t first; int batch, n_valid, B_pad;
-    bf16_t* out_act; int64_t ld_act; float* out_f32; int64_t ld_f32; int cols_pad;
-    const void* st;                                             // dmvae_state: first = batch_cursor * batch when set
-};
-bool gemm_bf16_gather_ok(int M, int N, int K);
-int gemm_bf16_gather_launch(hipStream_t s, const GemmArgs& a, const GatherSrc& g);
-int chain_probe_launch(hipStream_t s, int variant, int nlayer, const GemmArgs* layers, unsigned* sync, int* err);
 // CNN trunk (conv.hip)
 int conv_first_fwd_launch(hipStream_t s, int dtype, const void* x, int64_t bstride, int H, int64_t n_img, const void* W, int ldw,
                           const float* bias, int cout, void* out, int ld);
@@ -86,23 +76,5 @@ int zero_border_launch(hipStream_t s, int dtype, void* a, int P, int ld, int64_t
 int maxpool2_fwd_launch(hipStream_t s, int dtype, const void* in, int H, int ld, int64_t n_img, void* out, int out_border);
 int maxpool2_bwd_relu_launch(hipStream_t s, int dtype, const void* in, const void* dout, int H, int ld, int64_t n_img, void* din, int dout_border);
 int conv_wflip_launch(hipStream_t s, int dtype, const void* W, int cin, int cin_ld, int cout, int ldw, void* Wt, int Kt);
-
-// fused middle of the backward pass (mid_bwd.hip): dZ GEMM + latent backward epilogue + both head dX GEMMs over 16-row blocks
-struct MidBwdArgs {
-    int Bp, Dp, Kp, Hp, N0;                       // padded batch, latent, classes, head width, width of the first decoder layer
-    const bf16_t* ddec0; int64_t ld_dd;           // [Bp][N0]  gradient of the first decoder layer's output (ReLU-gated)
-    const bf16_t* Wd0; int64_t ld_wd0;            // [Dp][N0]  W_dec0 (row d: its N0 outputs contiguous)
-    const float* gmu; const float* glv; const float* clv; int64_t ld_g;    // [Bp][Dp] from the latent kernel
-    bf16_t* dmv; int64_t ld_dmv;                  // [Bp][2 Dp]  out: [dmean | dlog_var]
-    const bf16_t* dlg; int64_t ld_dlg;            // [Bp][Kp]   dlogits from the latent kernel
-    const bf16_t* Wmv; int64_t ld_wmv;            // [Hp][2 Dp]
-    const bf16_t* Wlg; int64_t ld_wlg;            // [Hp][Kp]
-    const bf16_t* hzc; int64_t ld_h;              // [Bp][2 Hp] forward activations [z-hidden | c-hidden] (the ReLU gates)
-    bf16_t* dhzc; int64_t ld_dh;                  // [Bp][2 Hp] out
-    dmvae_finalize_args fin;                      // fin.nblocks extra workgroups run step_finalize (0 = none)
-    int nrow_blocks;
-};
-bool mid_bwd_applies(int Bp, int Dp, int Kp, int Hp, int N0);
-int mid_bwd_launch(hipStream_t s, const MidBwdArgs& a);
 
 }  // namespace dmvae

@@ -34,9 +34,9 @@ EXPORTS = [
     "dmvae_adam_tf", "dmvae_adam_finish", "dmvae_gather_rows", "dmvae_philox_normal",
     "dmvae_philox_gumbel", "dmvae_cast_f32_to_bf16", "dmvae_cast_bf16_to_f32",
     "dmvae_plan_create", "dmvae_plan_destroy", "dmvae_plan_sizes", "dmvae_plan_tensor",
-    "dmvae_plan_bind", "dmvae_plan_load_batch", "dmvae_plan_load_batch_deferred", "dmvae_plan_gather_folds", "dmvae_plan_forward_backward",
+    "dmvae_plan_bind", "dmvae_plan_load_batch", "dmvae_plan_load_batch_step", "dmvae_plan_forward_backward",
     "dmvae_plan_update", "dmvae_plan_encode", "dmvae_plan_decode", "dmvae_plan_view",
-    "dmvae_prof_enable", "dmvae_prof_collect", "dmvae_debug_spin", "dmvae_debug_stamps", "dmvae_debug_anatomy", "dmvae_debug_anatomy256", "dmvae_debug_chain", "dmvae_debug_set_tile", "dmvae_debug_set_knob", "dmvae_abi_version", "dmvae_last_error",
+    "dmvae_prof_enable", "dmvae_prof_collect", "dmvae_debug_spin", "dmvae_debug_stamps", "dmvae_debug_anatomy", "dmvae_debug_anatomy256", "dmvae_debug_set_tile", "dmvae_debug_set_knob", "dmvae_abi_version", "dmvae_last_error",
 ]
 
 
@@ -172,8 +172,7 @@ def _load():
         "dmvae_plan_tensor": [vp, i32, P(TensorInfo)],
         "dmvae_plan_bind": [vp, P(Buffers)],
         "dmvae_plan_load_batch": [vp, vp, vp, i64, vp, i64, i32, i32],
-        "dmvae_plan_load_batch_deferred": [vp, vp, vp, vp, i64, i64, vp, i64, i32, i32],
-        "dmvae_plan_gather_folds": [vp],
+        "dmvae_plan_load_batch_step": [vp, vp, vp, i64, vp, i64, i32, i32],
         "dmvae_plan_forward_backward": [vp, vp, i32, vp, i64, vp, i64, f32],
         "dmvae_plan_update": [vp, vp, f32],
         "dmvae_plan_encode": [vp, vp, i32],
@@ -184,7 +183,6 @@ def _load():
         "dmvae_debug_stamps": [P(vp)],
         "dmvae_debug_anatomy": [P(vp)],
         "dmvae_debug_anatomy256": [P(vp)],
-        "dmvae_debug_chain": [vp, i32, i32, i32, i32, vp, vp, P(vp), P(vp), vp, vp],
         "dmvae_prof_collect": [P(ProfRow), i32],
         "dmvae_debug_set_tile": [i32, i32],
         "dmvae_debug_set_knob": [i32, i32],

@@ -169,11 +169,6 @@ class StepEngine:
         b = _lib.Buffers(ptr(self.param), ptr(self.grad), ptr(self.m), ptr(self.v),
                          ptr(self.param_bf16), ptr(self.work), ptr(self.state_t), n)
         check(lib.dmvae_plan_bind(self._plan, C.byref(b)), "dmvae_plan_bind")
-        self._shadows = {}
-        # MEASURED (cfg2, tools/ab_env.sh): folded 0.2858 vs plain gather 0.2826 ms/step -- the fused launch takes 22 us, the sum of
-        # the two it replaces: rows read 128 B at a time through the permutation come from HBM, and the spare workgroups' copies do
-        # not hide behind 13 K tiles.  Off unless DMVAE_GATHER_FOLD=1.
-        self._folds = bool(lib.dmvae_plan_gather_folds(self._plan)) and os.environ.get("DMVAE_GATHER_FOLD", "0") == "1"
         self.tensors = {}
         for i in range(sz.n_tensors):
             ti = _lib.TensorInfo()
@@ -304,39 +299,16 @@ class StepEngine:
         check(lib.dmvae_plan_load_batch(self._plan, self._stream(), ptr(data), data.shape[0], ptr(perm),
                                         int(first), n_valid, 1 if use_state_cursor else 0), "dmvae_plan_load_batch")
 
-    def _dataset_shadow(self, data):
-        """bf16 copy of a resident dataset, [N + pad][input_dim padded to 64], zero pad columns and zero rows behind the data:
-        what the first dense layer reads its batch rows from when the gather is folded into it (dmvae_plan_load_batch_deferred).
-        Cached per (storage, shape, version): an in-place change of `data` makes a new copy."""
-        key = (data.data_ptr(), tuple(data.shape), data._version)
-        hit = self._shadows.get(key)
-        if hit is None:
-            if torch.cuda.is_current_stream_capturing():
-                return None                              # never allocate inside a capture: the plain gather then
-            n = data.shape[0]
-            rows = (n + 1 + 63) // 64 * 64
-            ip = (self.input_dim + 63) // 64 * 64
-            sh = torch.empty((rows, ip), dtype=torch.bfloat16, device=self.device)
-            check(lib.dmvae_gather_rows(self._stream(), _lib.BF16, ptr(data), n, self.input_dim, None, 0, n, n, rows, ptr(sh), ip, None, ip, None),
-                  "dmvae_gather_rows")
-            if len(self._shadows) >= 2:
-                self._shadows.pop(next(iter(self._shadows)))
-            hit = self._shadows[key] = (sh, rows)
-        return hit
-
     def _load_batch_for_step(self, data, perm=None, first=0, n_valid=None, use_state_cursor=False):
-        """load_batch for the step paths (the encode follows at once): when the plan folds the gather into its first dense
-        layer (DMVAE_GATHER_FOLD=1, bf16 MLP trunk on the small-tile kernel) nothing is launched here; default: the plain gather."""
-        if not self._folds:
-            return self.load_batch(data, perm, first, n_valid, use_state_cursor)
+        """load_batch for the step paths (ONE forward_backward / train step follows at once): dmvae_plan_load_batch_step -- on bf16
+        plans only the bf16 copy of the batch is written and the reconstruction epilogue reads its targets from `data` through
+        `perm` (both must stay alive until the step has run; the "x" view is not valid afterwards)."""
         assert data.dtype == torch.float32 and data.is_contiguous() and data.shape[1] == self.input_dim
         assert perm is None or (perm.dtype == torch.int32 and perm.is_contiguous())
-        sh = self._dataset_shadow(data)
-        if sh is None:
-            return self.load_batch(data, perm, first, n_valid, use_state_cursor)
         n_valid = self.max_batch if n_valid is None else int(n_valid)
-        check(lib.dmvae_plan_load_batch_deferred(self._plan, self._stream(), ptr(data), ptr(sh[0]), sh[1], data.shape[0], ptr(perm),
-                                                 int(first), n_valid, 1 if use_state_cursor else 0), "dmvae_plan_load_batch_deferred")
+        self._step_src = (data, perm)                       # keep them alive
+        check(lib.dmvae_plan_load_batch_step(self._plan, self._stream(), ptr(data), data.shape[0], ptr(perm),
+                                             int(first), n_valid, 1 if use_state_cursor else 0), "dmvae_plan_load_batch_step")
 
     def forward_backward(self, n_valid=None, eps=None, gumbel=None, inv_B=None):
         n_valid = self.max_batch if n_valid is None else int(n_valid)
@@ -530,54 +502,14 @@ class StepEngine:
                 self.train_step(data, perm, None, None, None, 0, True, None, grad_scale, inv_B)
             self._graph = (g,)
             return g.replay
-        # data parallel.  MEASURED (one GPU, no-op exchange, `bench.py --dp-dry-run`): issuing the
-        # sequence eagerly is faster than replaying it as several small graphs with the collectives
-        # between them (three segments + three bucket updates: 0.362 vs 0.396 ms; one backward +
-        # Adam: 0.313 vs 0.326 ms) -- the host stays ahead of a 0.3 ms step and every graph launch
-        # has its own cost.  So the data-parallel step is issued eagerly; DMVAE_DP_GRAPHS=1 keeps the
-        # graph form (collectives outside capture) for re-measurement.
-        import os
-        if os.environ.get("DMVAE_DP_GRAPHS", "0") != "1" or getattr(grad_sync, "sharded", False):
-            def eager_step():
-                self.train_step(data, perm, None, None, None, 0, True, grad_sync, grad_scale, inv_B)
-            self._graph = None
-            return eager_step
-        if getattr(grad_sync, "overlap", False):
-            buckets = self.grad_buckets()
-            segs = [torch.cuda.CUDAGraph() for _ in range(3)]
-            upds = [torch.cuda.CUDAGraph() for _ in range(3)]
-            for stage, g in enumerate(segs):
-                with torch.cuda.graph(g, stream=side):
-                    if stage == 0:
-                        self._load_batch_for_step(data, perm, 0, None, True)
-                    self.forward_backward_stage(stage, None, None, None, inv_B)
-            for g, (lo, hi) in zip(upds, buckets):
-                with torch.cuda.graph(g, stream=side):
-                    self.update_range(lo, hi, grad_scale)
-            self._graph = (*segs, *upds)
-
-            def replay_overlapped():
-                handles = []
-                for g, (lo, hi) in zip(segs, buckets):
-                    g.replay()
-                    handles.append(grad_sync.start(self.grad[lo:hi]))
-                for h, g in zip(handles, upds):      # Adam of a bucket as soon as its sum has landed
-                    grad_sync.wait(h)
-                    g.replay()
-            return replay_overlapped
-        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga, stream=side):
-            self._load_batch_for_step(data, perm, 0, None, True)
-            self.forward_backward(None, None, None, inv_B)
-        with torch.cuda.graph(gb, stream=side):
-            self.update(grad_scale)
-        self._graph = (ga, gb)
-
-        def replay():
-            ga.replay()
-            grad_sync(self.grad)
-            gb.replay()
-        return replay
+        # data parallel: issued eagerly.  MEASURED (one GPU, no-op exchange, `bench.py --dp-dry-run`): replaying the sequence as
+        # several small graphs with the collectives between them was slower (three segments + three bucket updates: 0.362
+        # vs 0.396 ms; one backward + Adam: 0.313 vs 0.326 ms) -- the host stays ahead of a 0.3 ms step and every graph
+        # launch has its own cost; that form was removed.
+        def eager_step():
+            self.train_step(data, perm, None, None, None, 0, True, grad_sync, grad_scale, inv_B)
+        self._graph = None
+        return eager_step
 
 
 def latent_eval(mean, log_var, logits, prior_means, prior_log_vars, eps=None, gumbel=None, mode="exact",

@@ -17,6 +17,7 @@ import argparse
 import math
 import os
 import sys
+import zipfile
 
 import numpy as np
 
@@ -155,7 +156,7 @@ def main(argv):
             model.load_state_dict({k: f[k] for k in f.files})
         if rank == 0:
             print("Restored", ckpt_path)
-    except (OSError, ValueError, KeyError, RuntimeError) as e:
+    except (OSError, ValueError, KeyError, RuntimeError, EOFError, zipfile.BadZipFile) as e:
         # no checkpoint, one written by another revision (e.g. a torch.save zip at this path), a truncated archive,
         # other shapes / names: say why and carry on from the initial parameters, as the reference does
         # (bare except around saver.restore, train.py:251-258) and as DeepMixtureVAE._restore does

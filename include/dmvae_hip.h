@@ -328,15 +328,13 @@ int dmvae_plan_bind(dmvae_plan* p, const dmvae_buffers* b);
 /* batch assembly into the plan's input buffers (see dmvae_gather_rows) */
 int dmvae_plan_load_batch(dmvae_plan* p, void* stream, const float* data, int64_t n_rows,
                           const int32_t* perm, int64_t first, int n_valid, int use_state_cursor);
-/* The same for a caller that goes straight on to dmvae_plan_encode / _forward_backward / _train_step, with a bf16 copy of the
- * dataset: shadow = [shadow_rows >= n_rows + 1][input_dim padded to 64] bf16, pad columns and every row >= n_rows zero
- * (dmvae_gather_rows with perm = NULL, batch = n_valid = n_rows, B_pad = shadow_rows makes one).  When
- * dmvae_plan_gather_folds(plan) != 0 (bf16, MLP trunk, first layer on the small-tile kernel) no gather is launched: the first
- * dense layer reads its rows from the shadow through perm and spare workgroups of that launch write the batch's copies;
- * otherwise, or with shadow == NULL, exactly dmvae_plan_load_batch.  The batch buffers are only valid after the encode. */
-int dmvae_plan_load_batch_deferred(dmvae_plan* plan, void* stream, const float* data, const void* shadow, int64_t shadow_rows,
-                                   int64_t n_rows, const int32_t* perm, int64_t first, int n_valid, int use_state_cursor);
-int dmvae_plan_gather_folds(const dmvae_plan* plan);
+/* The same for a caller that goes straight on to ONE dmvae_plan_forward_backward / _train_step on this batch.  On bf16 plans whose
+ * output layer the small-tile kernel runs (input_dim a multiple of 4) only the bf16 copy of the batch is written: the f32 copy's one
+ * reader in a step, the reconstruction epilogue of the output layer (base_models.py:72-85), fetches its target rows from `data`
+ * through `perm` itself.  `data` and `perm` must stay alive and unchanged until that step has run; the "x" view is not valid
+ * afterwards.  Any other plan: exactly dmvae_plan_load_batch. */
+int dmvae_plan_load_batch_step(dmvae_plan* plan, void* stream, const float* data, int64_t n_rows, const int32_t* perm,
+                               int64_t first, int n_valid, int use_state_cursor);
 /* forward + loss + backward: fills the grad arena and the loss partials.
  * eps / gumbel: caller-supplied noise (parity mode) or NULL (on-device Philox). */
 int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_valid,

@@ -44,13 +44,6 @@ int dmvae_debug_anatomy(void** device_ptr);
 /* likewise for the last 256x256 macro-tile launch: 4096 x 8 uint64 {entry, K loop done, epilogue done (100 MHz ticks), HW_ID << 32 | XCC_ID,
  * entry, K loop done (shader cycles, s_memtime), 0, 0} (tools/anatomy256.py; tools/clock256.py: the clock held inside the K loop) */
 int dmvae_debug_anatomy256(void** device_ptr);
-/* probe (tools/chain_probe.py): nlayer (1..8) square bias + ReLU layers [M x N] x [N x N] (bf16, M % 1024 == 0, N % 64 == 0)
- * as ONE launch in which the workgroups of a physical XCD own one eighth of the rows through every layer; layer l reads
- * act[l % 2] and writes act[(l + 1) % 2].  variant 0: L1 invalidate between layers, 1: agent-scope fences.  sync: 2112 B of
- * device scratch (zeroed by the call); *err (device int, zeroed by the caller) != 0 when a bounded wait gave up. */
-int dmvae_debug_chain(void* stream, int variant, int nlayer, int M, int N, void* act0, void* act1,
-                      const void* const* W, const float* const* bias, void* sync, int* err);
-
 /* tuning aid: force the bf16 GEMM tile (64|128 x 64|128); (0,0) restores the heuristic */
 int dmvae_debug_set_tile(int bm, int bn);
 /* tuning aid: knob 0 = supertile height (tile rows) of the L2-friendly tile order,
@@ -66,8 +59,8 @@ int dmvae_debug_set_tile(int bm, int bn);
  *                      default 0: measured slower on the whole step),
  *             knob 8 = merged weight-gradient grid of the 256x256 kernel: first-tile delay, units of 3.4 us spread over the
  *                      256 CUs (default 0 = none, measured best; -1 = one launch per problem),
- *             knob 9 = the narrow middle of the backward pass (dZ GEMM + latent epilogue + both head dX GEMMs) as one kernel over
- *                      16-row blocks, csrc/mid_bwd.hip (0|1) */
+ *             knob 10 = K slices of the dense weight-gradient group of plans with >= 8192 batch rows (slabs + fixed-order sum in the
+ *                      Adam kernel): 0 = the plan's rule (2 from 16384 rows, else none), 1 = none, 2 | 4 = forced */
 int dmvae_debug_set_knob(int which, int value);
 
 #ifdef __cplusplus

@@ -159,34 +159,6 @@ def test_full_size_step_properties(name):
     _full_size_step_properties(name)
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg4"])
-def test_full_size_step_properties_with_the_fused_middle_backward(name):
-    """knob 9: dZ GEMM + latent backward + both head dX GEMMs as one kernel over 16-row blocks (csrc/mid_bwd.hip) -- the same
-    bit-exact properties, and its gradients against the tile-GEMM form of the same step"""
-    from dmvae_hip import _lib
-    kw, B, lr = FULL[name]
-    g = torch.Generator(device="cuda"); g.manual_seed(5)
-    X = torch.rand((B, kw["input_dim"]), device="cuda", generator=g) * (torch.rand((B, kw["input_dim"]), device="cuda", generator=g) < 0.19)
-    eps = torch.randn((B, kw["latent_dim"]), device="cuda", generator=g)
-    grads = {}
-    try:
-        for knob in (0, 1):
-            _lib.check(_lib.lib.dmvae_debug_set_knob(9, knob))
-            eng = make(kw, "bf16", B, seed=4, lr=lr)
-            eng.load_batch(X, None, 0, B)
-            eng.forward_backward(B, eps)
-            torch.cuda.synchronize()
-            grads[knob] = (eng.grad.clone(), eng.read_state().last_loss)
-            del eng
-        assert grads[0][1] == grads[1][1]                              # the forward pass is untouched
-        d = (grads[0][0] - grads[1][0]).norm().item() / grads[0][0].norm().item()
-        assert d <= 2e-2, d                                             # a different summation order over bf16 operands
-        _lib.check(_lib.lib.dmvae_debug_set_knob(9, 1))
-        _full_size_step_properties(name)
-    finally:
-        _lib.check(_lib.lib.dmvae_debug_set_knob(9, 0))
-
-
 def _full_size_step_properties(name):
     """At the batch size the config names, three steps (device Philox noise, batch cursor in the device state):
       two eager runs are bit-identical; HIP-graph replay == eager; Adam fused into the dW launch == backward

@@ -528,33 +528,6 @@ def test_adam_tf_matches_oracle_over_steps(hip, shadow, ieee):
     np.testing.assert_allclose(p1.cpu().numpy(), -0.002 * np.sign(g1.cpu().numpy()), rtol=1e-4)
 
 
-def test_xcd_sliced_chain_equals_separate_launches(hip):
-    """dmvae_debug_chain (tools/chain_probe.py): four layers in ONE launch, the workgroups of a physical XCD owning an eighth of the
-    rows with XCD-local barriers only, must give the bits of four separate launches -- whatever the placement (membership is read
-    from HW_REG_XCC_ID), on fresh inputs each time (a stale L1 line would show), and never hang (bounded waits -> err)."""
-    L = hip
-    torch.manual_seed(3)
-    M, N, NL = 1024, 256, 4
-    Ws = [(torch.randn(N, N, device="cuda") * (2.0 / N) ** 0.5).bfloat16() for _ in range(NL)]
-    bs = [0.01 * torch.randn(N, device="cuda") for _ in range(NL)]
-    Wp = (C.c_void_p * NL)(*[w.data_ptr() for w in Ws]); bp = (C.c_void_p * NL)(*[b.data_ptr() for b in bs])
-    sync = torch.zeros(1024, dtype=torch.int32, device="cuda"); err = torch.zeros(4, dtype=torch.int32, device="cuda")
-    for trial in range(3):
-        x0 = torch.relu(torch.randn(M, N, device="cuda")).bfloat16()
-        a = [x0.clone(), torch.zeros_like(x0)]
-        for l in range(NL):
-            e = L.Epilogue(); e.kind = L.EPI_BIAS_RELU
-            e.out, e.ldo, e.bias = a[(l + 1) % 2].data_ptr(), N, bs[l].data_ptr()
-            L.check(L.lib.dmvae_gemm(stream(), 1, 0, M, N, N, L.ptr(a[l % 2]), N, L.ptr(Ws[l]), N, C.byref(e), 1))
-        torch.cuda.synchronize()
-        want = a[NL % 2].clone()
-        a[0].copy_(x0); a[1].zero_()
-        L.check(L.lib.dmvae_debug_chain(stream(), 0, NL, M, N, L.ptr(a[0]), L.ptr(a[1]), Wp, bp, L.ptr(sync), L.ptr(err)))
-        torch.cuda.synchronize()
-        assert int(err[0].item()) == 0
-        assert torch.equal(a[NL % 2], want)
-
-
 def test_gather_rows_follows_dataset_order(hip):
     L = hip
     rng = np.random.RandomState(6)

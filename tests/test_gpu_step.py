@@ -178,38 +178,45 @@ def test_fused_update_equals_backward_then_adam(mode):
 
 
 @pytest.mark.parametrize("B", [256, 4096])
-def test_gather_folded_into_first_layer_equals_plain_gather(B, monkeypatch):
-    """train_step with the batch gather folded into the first dense layer's launch (dmvae_plan_load_batch_deferred: rows read
-    from a bf16 dataset copy through the permutation, spare workgroups write the batch's copies) must leave the bits of the
-    plain gather + step: batch buffers, loss, parameters -- shuffled rows, a ragged last batch, several steps, eager and replayed."""
+def test_step_path_without_the_f32_batch_copy_equals_plain_load(B):
+    """train_step assembles its batch with dmvae_plan_load_batch_step: only the bf16 copy is written and the output layer's
+    reconstruction epilogue reads its targets from the dataset through the permutation.  It must leave the bits of
+    load_batch (bf16 + f32 copies) + the same step: loss, parameters, moments -- shuffled rows, a ragged last batch, several
+    steps, eager and replayed from a graph with the cursor in the device state."""
     kw = dict(input_dim=784, latent_dim=64, n_classes=10)
     N = 3 * B + 77
     X = torch.as_tensor(O.synthetic_images(N, 784, seed=8)).cuda()
     perm = torch.randperm(N, device="cuda").to(torch.int32)
-    plain = make(kw, "bf16", B, seed=4)
-    monkeypatch.setenv("DMVAE_GATHER_FOLD", "1")          # (measured slower than the plain gather at cfg2: opt-in, runtime.py)
-    fold = make(kw, "bf16", B, seed=4)
-    monkeypatch.delenv("DMVAE_GATHER_FOLD")
-    assert fold._folds and not plain._folds
+    plain, stepp = make(kw, "bf16", B, seed=4), make(kw, "bf16", B, seed=4)
     rng = np.random.RandomState(2)
     for step, (first, n) in enumerate(((0, B), (B, B), (2 * B, B), (3 * B, 77))):
         ed = torch.as_tensor(rng.randn(n, 64).astype(np.float32)).cuda()
-        for eng in (plain, fold):
-            eng.train_step(X, perm, n, ed, None, first, False)
+        plain.load_batch(X, perm, first, n)                  # writes the f32 copy: the epilogue reads its targets there
+        plain.forward_backward_update(n, ed)
+        stepp.train_step(X, perm, n, ed, None, first, False)  # dmvae_plan_load_batch_step
         torch.cuda.synchronize()
-        assert plain.read_state().last_loss == fold.read_state().last_loss
+        assert plain.read_state().last_loss == stepp.read_state().last_loss, step
+        assert plain.read_state().last_recon == stepp.read_state().last_recon, step
         for name in ("param", "m", "v", "param_bf16"):
-            assert torch.equal(getattr(plain, name), getattr(fold, name)), (step, name)
-        assert torch.equal(plain.view("x", B, 784), fold.view("x", B, 784)), step
-    # device-side cursor + graph replay (the bench's form)
-    for eng in (plain, fold):
+            assert torch.equal(getattr(plain, name), getattr(stepp, name)), (step, name)
+    # device-side cursor + graph replay (the bench's form) against eager plain loads
+    for eng in (plain, stepp):
         eng.reset_epoch(3)
-    reps = [eng.capture_step(X, perm) for eng in (plain, fold)]
-    for _ in range(3):
-        for rp in reps: rp()
+    rp = stepp.capture_step(X, perm)
+    for i in range(3):
+        plain.load_batch(X, perm, 0, B, use_state_cursor=True)
+        plain.forward_backward_update(B)
+        rp()
     torch.cuda.synchronize()
-    assert plain.read_state().last_loss == fold.read_state().last_loss
-    assert torch.equal(plain.param, fold.param)
+    assert plain.read_state().last_loss == stepp.read_state().last_loss
+    assert torch.equal(plain.param, stepp.param)
+    # fp32 plans keep the copy (nothing changes there), and an n_valid that disagrees with the assembled batch is refused
+    f = make(kw, "fp32", 256, seed=4)
+    f.train_step(X, perm, 200, torch.zeros((200, 64), device="cuda"), None, 0, False)
+    np.testing.assert_array_equal(f.view("x", 200, 784).cpu().numpy(), X[perm[:200].long()].cpu().numpy())
+    stepp._load_batch_for_step(X, perm, 0, 77)
+    with pytest.raises(Exception, match="assembled 77 rows"):
+        stepp.forward_backward_update(B)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
