@@ -349,6 +349,9 @@ class DeepMixtureVAE(VAE):
         if not path:
             return
         sess = self._session
+        if sess is not None and sess.world_size > 1:      # sharded bf16 steps leave a rank's fp32 weights current on its own slice only
+            from dmvae_hip import make_exchange
+            self._engine.sync_master(make_exchange(4 * self._engine.param.numel()))      # collective: every rank is here
         if sess is None or sess.rank == 0:
             os.makedirs(os.path.dirname(path), exist_ok=True)
             tmp = path + ".tmp.npz"

@@ -158,6 +158,8 @@ struct dmvae_plan {
     std::vector<PLayer> enc, dec;
     PLayer zc, mv, lg, out;        // fused z|c hidden, fused mean|log_var, logits, output layer
     int64_t prior_off;             // prior_means [K][D] then prior_log_vars [K][D], contiguous
+    int64_t tail_off = 0;          // [tail_off, param_elems): every bias, then the prior tables -- the tensors the epilogues and the
+                                   // latent kernel read in fp32 (0.3 % of the arena), kept apart from the weight matrices
     int64_t param_elems;
     std::vector<dmvae_tensor_info> tensors;
     // workspace byte offsets
@@ -222,11 +224,16 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
     p->Kp = pad64(c->n_classes);
     p->vade = c->model == DMVAE_MODEL_VADE;
     p->Hp = pad64(p->vade ? 64 : c->head_dim);
-    int64_t off = 0;
+    // Arena layout: every weight matrix first (trunk, heads, decoder, output), then -- from tail_off, a multiple of 4096 elements --
+    // the SMALL fp32 tensors: every bias in the same layer order, then the prior tables.  The GEMMs read the weights through the bf16
+    // shadow; the biases (epilogues) and the prior tables (latent kernel) are read in fp32.  Kept apart, a data-parallel job can
+    // reduce-scatter / shard-update the weight range and all-gather its bf16 SHADOW (half the bytes) while the tail
+    // is all-reduced whole and updated on every rank (dmvae_plan_grad_buckets).  boff counts tail-relative until tail_off is known.
+    int64_t off = 0, boff = 0;
     auto place = [&](PLayer& L, const std::string& name, int in, int out_, int in_pad, int out_pad) {
         L.name = name; L.in = in; L.out = out_; L.in_pad = in_pad; L.out_pad = out_pad; L.ldw = out_pad;
         L.w_off = off; off += (int64_t)in_pad * out_pad;
-        L.b_off = off; off += out_pad;
+        L.b_off = boff; boff += out_pad;
     };
     int prev = c->input_dim, prev_pad = p->Ip;
     if (c->trunk == DMVAE_TRUNK_CNN) {
@@ -242,7 +249,7 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
             L.cin_ld = ld_in; L.cout_ld = L.cout; L.cin_np = pad64(L.cin); L.cout_np = pad64(L.cout); L.P = L.hw + 2;
             L.kdim = pad64(9 * L.cin); L.ktdim = pad64(9 * L.cout);
             L.w_off = off; off += (int64_t)L.kdim * L.cout_np;
-            L.b_off = off; off += L.cout_np;
+            L.b_off = boff; boff += L.cout_np;
             add_tensor(p, "W_" + L.name, L.w_off, 9 * L.cin, L.cout, L.cout_np);
             add_tensor(p, "b_" + L.name, L.b_off, 1, L.cout, L.cout_np);
             p->conv.push_back(L);
@@ -292,6 +299,14 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
     place(p->out, "out", prev, c->input_dim, prev_pad, p->Ip);
     add_tensor(p, "W_out", p->out.w_off, prev, c->input_dim, p->out.ldw);
     add_tensor(p, "b_out", p->out.b_off, 1, c->input_dim, p->Ip);
+    p->tail_off = align_up(off, 4096);
+    for (auto& L : p->conv) L.b_off += p->tail_off;
+    for (auto& L : p->enc) L.b_off += p->tail_off;
+    for (auto& L : p->dec) L.b_off += p->tail_off;
+    p->zc.b_off += p->tail_off; p->mv.b_off += p->tail_off; p->lg.b_off += p->tail_off; p->out.b_off += p->tail_off;
+    for (auto& t : p->tensors)
+        if (t.name[0] == 'b' && t.name[1] == '_') t.offset += p->tail_off;
+    off = p->tail_off + boff;
     p->prior_off = off;
     const int KD = c->n_classes * c->latent_dim;
     add_tensor(p, "prior_means", off, c->n_classes, c->latent_dim, c->latent_dim);
@@ -926,12 +941,13 @@ extern "C" int dmvae_plan_forward_backward_stage(dmvae_plan* p, void* stream, in
     DMVAE_REQUIRE(stage >= 0 && stage <= 2, "dmvae_plan_forward_backward_stage: stage %d (0, 1, 2)", stage);
     return forward_backward_impl(p, stream, n_valid, eps, ld_eps, gumbel, ld_gumbel, inv_B, stage);
 }
-extern "C" int dmvae_plan_grad_buckets(const dmvae_plan* p, int64_t bounds[4]) {
+extern "C" int dmvae_plan_grad_buckets(const dmvae_plan* p, int64_t bounds[5]) {
     DMVAE_REQUIRE(p && bounds, "dmvae_plan_grad_buckets: null pointer");
-    bounds[0] = 0;                                   // stage 2 completes [bounds[0], bounds[1])  (trunk)
-    bounds[1] = p->vade ? p->mv.w_off : p->zc.w_off; // stage 1 completes [bounds[1], bounds[2])  (heads)
-    bounds[2] = p->dec.empty() ? p->out.w_off : p->dec[0].w_off;   // stage 0 completes [bounds[2], bounds[3])  (decoder, prior tables)
-    bounds[3] = p->param_elems;
+    bounds[0] = 0;                                   // stage 2 completes [bounds[0], bounds[1])  (trunk weights)
+    bounds[1] = p->vade ? p->mv.w_off : p->zc.w_off; // stage 1 completes [bounds[1], bounds[2])  (heads weights)
+    bounds[2] = p->dec.empty() ? p->out.w_off : p->dec[0].w_off;   // stage 0 completes [bounds[2], bounds[3])  (decoder weights)
+    bounds[3] = p->tail_off;                         // [bounds[3], bounds[4]): the tail -- every bias, the prior tables: complete
+    bounds[4] = p->param_elems;                      // when the LAST segment has run (each segment writes its layers' biases)
     return 0;
 }
 

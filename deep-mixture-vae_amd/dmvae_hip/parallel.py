@@ -9,12 +9,16 @@ exchange runs on the flat fp32 gradient arena (torch.distributed: backend "nccl"
 is folded into the Adam kernel (grad_scale), so no separate scaling pass touches
 HBM.  Two forms (make_exchange picks; DMVAE_DP_MODE=sharded|allreduce overrides):
 
-  sharded    reduce-scatter(SUM) of the gradients -> TF-Adam on the OWNED 1/world
-             slice of the arena (m and v are only ever touched there) ->
-             all-gather of the updated fp32 parameters, bf16 shadow of the gathered
-             slices refreshed locally.  The default for world > 1: the optimizer's
-             HBM traffic (30 B per parameter) is divided by the world size, the wire
-             carries what a ring all-reduce carries.  SURVEY 8(e)'s preferred form.
+  sharded    the WEIGHT range of the arena (99.7 % of it; the arena keeps every bias
+             and the prior tables in a tail of their own, dmvae_plan_grad_buckets):
+             reduce-scatter(SUM) of the gradients -> TF-Adam on the OWNED 1/world slice
+             (m and v are only ever touched there) -> all-gather of the updated weights,
+             on bf16 plans as their bf16 SHADOW: 2 B per parameter on the wire instead of
+             4, and no cast pass afterwards.  The tail -- read in fp32 by
+             the epilogues and the latent kernel -- is all-reduced whole and updated on
+             every rank.  A rank's fp32 weights outside its slice are then stale until
+             StepEngine.sync_master() (checkpoint time).  The default for world > 1: the
+             optimizer's HBM traffic (30 B per parameter) is divided by the world size.
   allreduce  ONE all-reduce(SUM), every rank applies the whole update (replicated
              Adam): the bit-simplest form, kept as the reference the sharded form is
              tested against (identical bits on the owned slice).

@@ -328,68 +328,89 @@ class StepEngine:
                                                     ptr(gumbel), self.n_classes, inv_B), "dmvae_plan_forward_backward_stage")
 
     def grad_buckets(self):
-        """[(lo, hi)] element ranges of the gradient arena in the order the segments complete them."""
-        b = (C.c_int64 * 4)()
+        """([(lo, hi)] * 3, (tail_lo, tail_hi)): the element ranges of the WEIGHT part of the gradient arena in the order the
+        three segments complete them (decoder, heads, trunk), and the tail -- every bias, then the prior tables -- which is
+        complete when the last segment has run (dmvae_plan_grad_buckets)."""
+        b = (C.c_int64 * 5)()
         check(lib.dmvae_plan_grad_buckets(self._plan, b), "dmvae_plan_grad_buckets")
-        return [(b[2], b[3]), (b[1], b[2]), (b[0], b[1])]
+        return [(b[2], b[3]), (b[1], b[2]), (b[0], b[1])], (b[3], b[4])
 
     def update_range(self, lo, hi, grad_scale=1.0):
         check(lib.dmvae_plan_update_range(self._plan, self._stream(), float(grad_scale), int(lo), int(hi)), "dmvae_plan_update_range")
 
     def _step_with_exchange(self, grad_sync, grad_scale, n_valid=None, eps=None, gumbel=None, inv_B=None):
         """forward + backward + gradient exchange + Adam.  Bucketed and overlapped when the exchange says so
-        (`overlap`): each bucket's collective starts right behind the backward segment that completes it and its
-        Adam runs as soon as its sum has landed, while later buckets are still in flight; else one collective on
-        the whole arena.  Sharded exchange (parallel.ShardedExchange): reduce-scatter, Adam on the owned slice
-        only, all-gather of the updated parameters; else all-reduce + replicated Adam."""
-        n = self.param.numel()
+        (`overlap`): each weight bucket's collective starts right behind the backward segment that completes it and its
+        Adam runs as soon as its sum has landed, while later buckets are still in flight; else one collective per range
+        after the whole backward.
+
+        Sharded exchange (parallel.ShardedExchange): the WEIGHT range is reduce-scattered, TF-Adam runs on the owned slice
+        only (m and v are never touched elsewhere) and the updated weights are all-gathered -- on bf16 plans as their bf16
+        SHADOW, 2 B per parameter instead of 4 (the GEMMs read nothing else of a weight); a rank's fp32 copy of the weights
+        it does not own is then STALE until sync_master() (checkpoints, get_parameters).  The tail (every bias, the prior
+        tables: read in fp32 by the epilogues and the latent kernel, 0.3 % of the arena) is all-reduced whole and updated on
+        every rank, so the replicas agree in every bit the step reads.  Else: all-reduce + replicated Adam."""
+        buckets, (tlo, thi) = self.grad_buckets()
         if getattr(grad_sync, "sharded", False):
+            gather = self.param_bf16 if self.param_bf16 is not None else self.param      # what the all-gather carries
+            # the sharded part ends at a multiple of 64 * world (tail_off is a multiple of 4096: the same thing for every world
+            # that divides 64); whatever lies between is exchanged with the tail
+            tlo = tlo // grad_sync.align * grad_sync.align
             if grad_sync.overlap:
-                buckets = grad_sync.bucket_bounds(self.grad_buckets(), n)
-                # the plan's segments complete the UNROUNDED buckets in this order; rounding up keeps that true
+                wb = grad_sync.bucket_bounds(buckets, tlo)
+                assert len(wb) == 3          # one per segment; None = emptied by the rounding (its elements ride in a later bucket)
                 handles = []
-                assert len(buckets) == 3          # one per segment; None = emptied by the rounding (its elements ride in a later bucket)
                 for stage in range(3):
                     self.forward_backward_stage(stage, n_valid, eps, gumbel, inv_B)
-                    if buckets[stage] is not None:
-                        lo, hi = buckets[stage]
+                    if wb[stage] is not None:
+                        lo, hi = wb[stage]
                         handles.append(grad_sync.reduce_scatter(self.grad, lo, hi, async_op=True))
-                buckets = [b for b in buckets if b is not None]
+                th = grad_sync.start(self.grad[tlo:thi])
+                wb = [b for b in wb if b is not None]
                 gathers = []
-                for h, (lo, hi) in zip(handles, buckets):
+                for h, (lo, hi) in zip(handles, wb):
                     grad_sync.wait(h)
                     slo, shi = grad_sync.owned(lo, hi)
                     self.update_range(slo, shi, grad_scale)
-                    gathers.append(grad_sync.all_gather(self.param, lo, hi, async_op=True))
+                    gathers.append(grad_sync.all_gather(gather, lo, hi, async_op=True))
+                grad_sync.wait(th)
+                self.update_range(tlo, thi, grad_scale)
                 grad_sync.finish(gathers)
+                self._shard_ranges = wb
             else:
-                buckets = [(0, n)]
                 self.forward_backward(n_valid, eps, gumbel, inv_B)
-                grad_sync.reduce_scatter(self.grad, 0, n)
-                slo, shi = grad_sync.owned(0, n)
+                grad_sync.reduce_scatter(self.grad, 0, tlo)
+                grad_sync(self.grad[tlo:thi])
+                slo, shi = grad_sync.owned(0, tlo)
                 self.update_range(slo, shi, grad_scale)
-                grad_sync.all_gather(self.param, 0, n)
-            if self.param_bf16 is not None:      # the slices other ranks updated: refresh their bf16 shadow (the owned one is written by Adam)
-                for lo, hi in buckets:
-                    slo, shi = grad_sync.owned(lo, hi)
-                    for a, b in ((lo, slo), (shi, hi)):
-                        if b > a:
-                            check(lib.dmvae_cast_f32_to_bf16(self._stream(), ptr(self.param[a:b]), ptr(self.param_bf16[a:b]), b - a),
-                                  "dmvae_cast_f32_to_bf16")
+                self.update_range(tlo, thi, grad_scale)
+                grad_sync.all_gather(gather, 0, tlo)
+                self._shard_ranges = [(0, tlo)]
+            self._master_stale = self.param_bf16 is not None and grad_sync.world > 1
             return
         if getattr(grad_sync, "overlap", False):
-            buckets = self.grad_buckets()
             handles = []
             for stage, (lo, hi) in enumerate(buckets):
                 self.forward_backward_stage(stage, n_valid, eps, gumbel, inv_B)
                 handles.append(grad_sync.start(self.grad[lo:hi]))
-            for h, (lo, hi) in zip(handles, buckets):
+            handles.append(grad_sync.start(self.grad[tlo:thi]))
+            for h, (lo, hi) in zip(handles, buckets + [(tlo, thi)]):
                 grad_sync.wait(h)
                 self.update_range(lo, hi, grad_scale)
         else:
             self.forward_backward(n_valid, eps, gumbel, inv_B)
             grad_sync(self.grad)
             self.update(grad_scale)
+
+    def sync_master(self, grad_sync):
+        """COLLECTIVE (every rank calls it): after sharded bf16 steps a rank's fp32 weights are current on its owned slice only;
+        this all-gathers the fp32 master weights (in place) so that get_parameters / a checkpoint see the trained model.  A
+        no-op when nothing is stale."""
+        if getattr(self, "_master_stale", False) and getattr(grad_sync, "sharded", False):
+            for lo, hi in self._shard_ranges:          # the ranges the steps cut into owned slices (one per bucket when overlapped)
+                grad_sync.all_gather(self.param, lo, hi)
+            torch.cuda.synchronize(self.device)
+        self._master_stale = False
 
     def update(self, grad_scale=1.0):
         check(lib.dmvae_plan_update(self._plan, self._stream(), float(grad_scale)), "dmvae_plan_update")

@@ -184,6 +184,9 @@ def main(argv):
             accTest = model.get_accuracy(sess, test_data)
             if accTest > maxAcc:
                 maxAcc = accTest
+                if world > 1:      # (every rank scores the same test set with the same weights, so every rank is here) sharded bf16
+                    from dmvae_hip import make_exchange          # steps leave a rank's fp32 weights current on its own slice only
+                    model.engine.sync_master(make_exchange(4 * model.engine.param.numel()))
                 if rank == 0:
                     with open(ckpt_path + ".tmp", "wb") as f:
                         np.savez(f, **model.state_dict())

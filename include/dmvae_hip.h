@@ -344,13 +344,17 @@ int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_valid,
  * bucket of the gradient arena is final, so its all-reduce can run while the next segment computes
  * (the reference has no counterpart: it is single-process).  Segment 0 = forward, loss, decoder
  * backward; 1 = heads backward; 2 = trunk backward; call them in order with the same arguments.
- * dmvae_plan_grad_buckets: bounds[4] in arena elements; segment 0 completes [bounds[2], bounds[3]),
- * segment 1 [bounds[1], bounds[2]), segment 2 [bounds[0], bounds[1]).  Results are bit-identical
- * to dmvae_plan_forward_backward. */
+ * dmvae_plan_grad_buckets: bounds[5] in arena elements.  The arena holds every weight matrix first and, from
+ * bounds[3] (a multiple of 4096) on, the small fp32 tensors: every bias, then the prior tables.  Segment 0 completes
+ * the weights [bounds[2], bounds[3]), segment 1 [bounds[1], bounds[2]), segment 2 [bounds[0], bounds[1]); the tail
+ * [bounds[3], bounds[4]) is complete when segment 2 has run.  A data-parallel caller can reduce-scatter the weight
+ * buckets, update its owned slices and all-gather the bf16 SHADOW of the weights (the GEMMs read nothing else of
+ * them), and all-reduce + update the tail on every rank (the epilogues and the latent kernel read it in fp32).
+ * Results are bit-identical to dmvae_plan_forward_backward. */
 int dmvae_plan_forward_backward_stage(dmvae_plan* p, void* stream, int stage, int n_valid,
                                       const float* eps, int64_t ld_eps, const float* gumbel, int64_t ld_gumbel,
                                       float inv_B);
-int dmvae_plan_grad_buckets(const dmvae_plan* p, int64_t bounds[4]);
+int dmvae_plan_grad_buckets(const dmvae_plan* p, int64_t bounds[5]);
 /* Adam (+ bf16 shadow refresh); grad_scale = 1/world_size.  The loss finalize at the end of
  * dmvae_plan_forward_backward has already advanced state->adam_t for this step: every
  * forward_backward is to be followed by exactly one update. */

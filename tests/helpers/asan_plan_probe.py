@@ -14,6 +14,7 @@ CONFIGS = [
     dict(I=4096, D=512, K=256, enc=(4096,) * 4, head=4096, dec=(4096,) * 4, B=8192, dt=_lib.BF16, trunk=0),
     dict(I=784, D=64, K=10, enc=(500,), head=2000, dec=(2000, 500, 500), B=256, dt=_lib.BF16, trunk=1),
     dict(I=96, D=8, K=4, enc=(64,) * 8, head=64, dec=(64,) * 8, B=37, dt=_lib.F32, trunk=0),
+    dict(I=784, D=10, K=10, enc=(128,), head=64, dec=(500, 500, 2000), B=128, dt=_lib.BF16, trunk=1, model=1),      # VaDE(cnn=True)
 ]
 n_plans = 0
 for c in CONFIGS:
@@ -24,13 +25,13 @@ for c in CONFIGS:
         cfg.enc[i] = v
     for i, v in enumerate(c["dec"]):
         cfg.dec[i] = v
-    cfg.dtype, cfg.max_batch, cfg.trunk = c["dt"], c["B"], c["trunk"]
+    cfg.dtype, cfg.max_batch, cfg.trunk, cfg.model = c["dt"], c["B"], c["trunk"], c.get("model", 0)
     cfg.beta1, cfg.beta2, cfg.adam_eps = 0.9, 0.999, 1e-8
     h = C.c_void_p()
     _lib.check(_lib.lib.dmvae_plan_create(C.byref(cfg), C.byref(h)), "dmvae_plan_create")
     sz = _lib.Sizes()
     _lib.check(_lib.lib.dmvae_plan_sizes(h, C.byref(sz)), "dmvae_plan_sizes")
-    assert sz.param_elems > 0 and sz.work_bytes > 0 and sz.batch_pad >= c["B"] and sz.n_tensors >= 2 * (len(c["enc"]) + len(c["dec"]) + 6) + 2
+    assert sz.param_elems > 0 and sz.work_bytes > 0 and sz.batch_pad >= c["B"] and sz.n_tensors >= 2 * (len(c["enc"]) + len(c["dec"]) + (3 if c.get("model") else 6)) + 2
     end = 0
     for i in range(sz.n_tensors):
         ti = _lib.TensorInfo()
@@ -40,9 +41,9 @@ for c in CONFIGS:
     assert end <= sz.param_elems
     ti = _lib.TensorInfo()
     assert _lib.lib.dmvae_plan_tensor(h, sz.n_tensors, C.byref(ti)) == -1          # index past the table
-    b = (C.c_int64 * 4)()
+    b = (C.c_int64 * 5)()
     _lib.check(_lib.lib.dmvae_plan_grad_buckets(h, b), "dmvae_plan_grad_buckets")
-    assert 0 == b[0] <= b[1] <= b[2] <= b[3] == sz.param_elems
+    assert 0 == b[0] <= b[1] <= b[2] <= b[3] < b[4] == sz.param_elems and b[3] % 4096 == 0      # weight buckets, then the tail (biases, prior tables)
     assert _lib.lib.dmvae_plan_update(h, None, 1.0) != 0                            # not bound: an error, not a crash
     _lib.lib.dmvae_plan_destroy(h)
     n_plans += 1

@@ -126,11 +126,12 @@ def test_cnn_staged_backward_and_bucket_update_match_the_whole_step():
     gw, gs = whole.get_gradients(), staged.get_gradients()
     for k in gw:
         np.testing.assert_allclose(gs[k], gw[k], rtol=0, atol=1e-5 * (np.abs(gw[k]).max() + 1e-12), err_msg=k)
-    buckets = staged.grad_buckets()                           # in completion order: decoder, heads, trunk
+    buckets, tail = staged.grad_buckets()                     # in completion order: decoder, heads, trunk weights; then the tail
     off, rows, cols, ld = staged.tensors["W_conv5"]
-    assert buckets[2][0] <= off < buckets[2][1]               # conv parameters belong to the trunk bucket
+    assert buckets[2][0] <= off < buckets[2][1]               # conv kernels belong to the trunk bucket
+    assert tail[0] <= staged.tensors["b_conv5"][0] < tail[1]  # ... their biases to the tail
     whole.update(1.0)
-    for lo, hi in buckets:
+    for lo, hi in buckets + [tail]:
         staged.update_range(lo, hi, 1.0)
     torch.cuda.synchronize()
     pw, ps = whole.get_parameters(), staged.get_parameters()

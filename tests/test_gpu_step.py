@@ -231,9 +231,12 @@ def test_staged_backward_equals_whole_and_buckets_cover_the_arena(dtype):
     whole, staged = make(kw, dtype, B, seed=2), make(kw, dtype, B, seed=2)
     whole.load_batch(Xd, None, 0, B)
     whole.forward_backward(B, ed)
-    buckets = staged.grad_buckets()
-    assert buckets[2][0] == 0 and buckets[0][1] == staged.grad.numel()          # trunk first in the arena, decoder + priors last
+    buckets, (tlo, thi) = staged.grad_buckets()
+    assert buckets[2][0] == 0 and buckets[0][1] == tlo and tlo % 4096 == 0      # trunk weights first in the arena, decoder weights last, then the tail
     assert buckets[2][1] == buckets[1][0] and buckets[1][1] == buckets[0][0]    # contiguous, no gap
+    assert thi == staged.sizes.param_elems <= staged.grad.numel()
+    names = staged.tensors
+    assert all((names[k][0] >= tlo) == (k.startswith("b_") or k.startswith("prior")) for k in names)     # the tail = every bias + the prior tables
     staged.load_batch(Xd, None, 0, B)
     done = []
     for stage, (lo, hi) in enumerate(buckets):
@@ -242,6 +245,7 @@ def test_staged_backward_equals_whole_and_buckets_cover_the_arena(dtype):
         done.append((lo, hi))
         for dlo, dhi in done:      # finished buckets equal the whole-pass gradient already
             assert torch.equal(staged.grad[dlo:dhi], whole.grad[dlo:dhi]), (stage, dlo, dhi)
+    assert torch.equal(staged.grad[tlo:thi], whole.grad[tlo:thi])               # the tail is complete behind the last segment
     assert staged.read_state().last_loss == whole.read_state().last_loss
     whole.update(0.5)
     staged.update(0.5)
@@ -315,7 +319,7 @@ def test_encode_decode_views():
     np.testing.assert_allclose(eng.view("recon", B).cpu().numpy(), 1 / (1 + np.exp(-xl)), atol=2e-5)
 
 
-def _dp_rank(rank, world, port, overlap, out, mode="allreduce"):
+def _dp_rank(rank, world, port, overlap, out, mode="allreduce", dtype="fp32"):
     """one data-parallel rank on the shared GPU (gloo carries the collectives in this rehearsal)"""
     import torch.distributed as dist
     for p in (os.path.join(ROOT, "deep-mixture-vae_amd"), os.path.join(ROOT, "oracle")):
@@ -330,7 +334,7 @@ def _dp_rank(rank, world, port, overlap, out, mode="allreduce"):
     rng = np.random.RandomState(21)
     X = Or.synthetic_images(B, 784, seed=8)
     lo, hi = shard_range(B, rank, world)
-    eng = StepEngine(dtype="fp32", max_batch=hi - lo, mode="exact", **kw)
+    eng = StepEngine(dtype=dtype, max_batch=hi - lo, mode="exact", **kw)
     eng.init_parameters(3)
     ex = make_exchange()
     assert ex.enabled and ex.overlap == overlap and ex.sharded == (mode == "sharded")
@@ -340,7 +344,14 @@ def _dp_rank(rank, world, port, overlap, out, mode="allreduce"):
         ed = torch.as_tensor(eps[lo:hi]).cuda()
         eng.train_step(Xd, None, hi - lo, ed, None, grad_sync=ex, grad_scale=ex.grad_scale, inv_B=world / float(B))
     torch.cuda.synchronize()
-    out.put((rank, eng.param.cpu().numpy(), eng.read_state().adam_t, eng.m.cpu().numpy()))
+    if dtype == "bf16":      # bf16 plans: the sharded exchange gathers the bf16 SHADOW; the fp32 weights outside the owned slice are stale until sync_master
+        before = eng.param.cpu().numpy()
+        stale = bool(getattr(eng, "_master_stale", False))
+        eng.sync_master(ex)                  # collective
+        out.put((rank, eng.param.cpu().numpy(), eng.read_state().adam_t, eng.m.cpu().numpy(), eng.param_bf16.float().cpu().numpy(), before, stale,
+                 eng.grad_buckets()[1][0]))
+    else:
+        out.put((rank, eng.param.cpu().numpy(), eng.read_state().adam_t, eng.m.cpu().numpy()))
     dist.destroy_process_group()
 
 
@@ -374,6 +385,42 @@ def test_sharded_exchange_equals_allreduce_bit_for_bit(overlap):
         owned_somewhere |= touched
     assert (owned_somewhere | (ar[0][3] == 0)).all()             # every parameter with a gradient is owned by some rank
     assert (sh[0][3] != 0).sum() < 0.75 * (ar[0][3] != 0).sum()  # ... and a rank does not maintain the others' moments
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_sharded_exchange_gathers_the_bf16_shadow(overlap):
+    """bf16 plans (VERDICT r2 next #5 iv): reduce-scatter -> Adam on the owned weight slice -> all-gather of the bf16
+    SHADOW (2 B per parameter), the tail (biases, prior tables) all-reduced and updated on every rank.  After two steps on two ranks:
+    every bit a step READS -- the shadow of the weights, the fp32 tail -- is identical on both ranks and equal to what all-reduce +
+    replicated Adam leaves; a rank's fp32 weights outside its slice are stale (that is what proves the fp32 master was not sent) until
+    sync_master(), after which the fp32 arenas are those of the replicated run too."""
+    import socket
+    import torch.multiprocessing as mp
+    res = {}
+    for mode in ("allreduce", "sharded"):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        ctx = mp.get_context("spawn")
+        out = ctx.Queue()
+        procs = [ctx.Process(target=_dp_rank, args=(r, 2, port, overlap, out, mode, "bf16")) for r in range(2)]
+        for p in procs:
+            p.start()
+        res[mode] = sorted([out.get(timeout=300) for _ in procs], key=lambda t: t[0])
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    ar, sh = res["allreduce"], res["sharded"]
+    tlo = sh[0][7]
+    for r in range(2):
+        np.testing.assert_array_equal(sh[r][4], ar[0][4])            # the shadow the GEMMs read: same bits as the replicated run, on both ranks
+        np.testing.assert_array_equal(sh[r][5][tlo:], ar[0][1][tlo:])  # the fp32 tail (biases, prior tables), before any sync
+        np.testing.assert_array_equal(sh[r][1], ar[0][1])            # after sync_master: the whole fp32 arena
+        assert sh[r][6] and not ar[r][6]                             # the sharded bf16 step marked the master stale; the replicated one never does
+    final = ar[0][1][:tlo]
+    cur = [sh[r][5][:tlo] == final for r in range(2)]                 # before the sync: where a rank's fp32 weights are current
+    assert (cur[0] | cur[1]).all()                                   # every weight is current on the rank that owns it ...
+    for r in range(2):
+        assert 0.3 < 1.0 - cur[r].mean() < 0.55, cur[r].mean()       # ... and a rank's copy of the other's slices was NOT refreshed (two Adam steps
+                                                                     # move nearly every real weight; pad elements stay 0 everywhere)
 
 
 @pytest.mark.parametrize("overlap", [True, False])

@@ -444,7 +444,8 @@ _DP_CFGS = {
 
 
 def _plan_buckets(name):
-    """(param_elems, [(lo, hi)] in completion order) of a BASELINE config's plan -- no GPU involved"""
+    """(weight elements = where the small-tensor tail begins, [(lo, hi)] of the weight buckets in completion order) of a
+    BASELINE config's plan -- no GPU involved"""
     import ctypes as C
     from dmvae_hip import _lib
     k = _DP_CFGS[name]
@@ -461,10 +462,11 @@ def _plan_buckets(name):
     _lib.check(_lib.lib.dmvae_plan_create(C.byref(cfg), C.byref(h)))
     sz = _lib.Sizes()
     _lib.check(_lib.lib.dmvae_plan_sizes(h, C.byref(sz)))
-    b = (C.c_int64 * 4)()
+    b = (C.c_int64 * 5)()
     _lib.check(_lib.lib.dmvae_plan_grad_buckets(h, b))
     _lib.lib.dmvae_plan_destroy(h)
-    return int(sz.param_elems), [(b[2], b[3]), (b[1], b[2]), (b[0], b[1])]
+    assert b[3] % 4096 == 0 and b[4] == sz.param_elems and 0 < b[4] - b[3] < 0.02 * b[4]      # the tail: every bias + the prior tables, a few per mille
+    return int(b[3]), [(b[2], b[3]), (b[1], b[2]), (b[0], b[1])]          # the WEIGHT range (what the sharded exchange cuts) and its buckets
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
@@ -481,7 +483,7 @@ def test_sharded_layout_of_the_baseline_plans(name, world):
         ex = ShardedExchange.__new__(ShardedExchange)
         ex.group, ex.enabled, ex.world, ex.rank, ex.align = None, False, world, rank, 64 * world
         n = ex.padded(n_real)
-        assert n % (64 * world) == 0 and 0 <= n - n_real < 64 * world
+        assert n == n_real                                       # the weight range ends at a multiple of 4096: already aligned for 2 / 4 / 8 ranks
         b = ex.bucket_bounds(raw, n)
         assert len(b) == 3 and None not in b                       # real plans: no bucket collapses
         assert b[0][1] == n and b[-1][0] == 0 and all(b[i][0] == b[i + 1][1] for i in range(2))
