@@ -120,6 +120,9 @@ using namespace dmvae;
 // tuning knob (dmvae_debug_set_knob 10): K slices of the dense weight-gradient group (0 = the plan's rule, 1 = none, 2 / 4 = forced where
 // the plan has the slabs); see dmvae_plan::dw_slices_max
 static int g_dw_slices = 0;
+// tuning knob (dmvae_debug_set_knob 11): with K slices, the layers whose shape divides by 256 on the macro tile (1, default) or every
+// layer on the small tiles (0)
+static int g_dw_macro = 1;
 
 // ====================================================================== plan
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -182,6 +185,8 @@ struct dmvae_plan {
     int dw_slices_max = 1;            // 1: the plan has no slabs
     int64_t o_dwslab = 0;
     int dw_slices_now = 1;            // slices of the pass being enqueued
+    bool dw_macro_now = false;        // ... and whether its 256-divisible layers take the macro tile (their bias gradient: a bias-only strip)
+    int dw_macro_tiles = 0;           // 256x256 tiles of those layers (per K slice)
     bool fused_update = false;        // set for the duration of dmvae_plan_train_step on a bf16 plan
     bool staged = false;              // dmvae_plan_forward_backward_stage: every segment launches its own dW group
     // dmvae_plan_load_batch_step: the batch was assembled for a step that follows at once -- no f32 copy of it exists; the output
@@ -397,6 +402,11 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
         if (c->dtype == DMVAE_BF16 && p->conv.empty() && Bp >= 8192 && Bp % (4 * 64) == 0 && !macro) {
             p->dw_slices_max = 4;
             p->o_dwslab = take((int64_t)p->dw_slices_max * p->param_elems * 4);
+            auto cnt = [&](const PLayer& L) { if (L.in_pad % 256 == 0 && L.out_pad % 256 == 0) p->dw_macro_tiles += (L.in_pad / 256) * (L.out_pad / 256); };
+            for (auto& L : p->enc) cnt(L);
+            for (auto& L : p->dec) cnt(L);
+            if (!p->vade) { cnt(p->zc); cnt(p->lg); }
+            cnt(p->mv); cnt(p->out);
         }
     }
     // the step path may leave the batch's f32 copy out (dmvae_plan_load_batch_step): bf16, 16-byte aligned dataset rows, and an
@@ -681,6 +691,14 @@ static int grad_dense(dmvae_plan* p, hipStream_t s, const void* X, int64_t ldx, 
         TRY(gemm_checked(s, DMVAE_BF16, DMVAE_GEMM_DW, Mdim, N, p->Bp, X, ldx, dY, ldy, &e, 1, &a));
         a.ws = reinterpret_cast<float*>(WS(p, p->o_cs)); a.ws_elems = p->cs_elems;     // bias-gradient slab sums of a 256x256-tile problem
         if (nsl > 1) { a.k_split = p->Bp / nsl; a.slab_stride = a.slab_stride2 = p->param_elems; }       // slice y -> slab y (gemm_bf16_body)
+        if (nsl > 1 && p->dw_macro_now && gemm_bf16_256_slice_ok(Mdim, N, p->Bp / nsl)) {
+            // this layer's slices run on the macro tile (gemm_bf16.hip peel_large_dw); the macro tile has no ones-operand pass, so the
+            // bias gradient comes from a bias-only strip of the grouped small-tile launch: same K slices, same slabs
+            GemmArgs b = a;
+            b.M = 64; b.bias_only = 1;
+            a.epi.out2 = nullptr;
+            p->dw_queue.push_back(b);
+        }
         auto cs = p->csum_of.find(dY);
         if (cs != p->csum_of.end() && cs->second.second == N) {      // ... unless dY's producer left its column sums
             a.csum_in = cs->second.first; a.csum_ld = N; a.csum_rows = p->Bp / 256;
@@ -787,8 +805,16 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     if (all || stage == 0) {      // K slices of this pass's dW groups (dw_slices_max).  MEASURED (tools/knob_step.py <cfg> 10 1 2 4, same box):
         // cfg3 (16384 rows) 1.0065 / 0.9778 / 0.9855 ms per step for 1 / 2 / 4 slices; cfg4 (8192 rows) 0.6623 / 0.7003 / 0.7126 -- the
         // slabs' extra 8 B per parameter and the separate Adam pass pay only once a tile's K loop is > 128 K tiles: two slices from 16384 rows
-        const int want = g_dw_slices > 0 ? g_dw_slices : (p->Bp >= 16384 ? 2 : 1);
+        // With the 256-divisible layers (three quarters of the flops of the MNIST-shaped stacks: [z|c]-hidden, 2048 -> 512, 512 -> 512)
+        // on the macro tile: four slices make 4 x 56 = 224 macro workgroups -- one round of the chip at 1.3-1.4 PFLOP/s against the
+        // small tiles' 0.74 in this layout (both operands through the transposing LDS read).
+        // MEASURED (same box, tools/knob_step.py <cfg> 11 0 1): cfg3 (16384 rows) 0.9565 (small tiles, two slices) -> 0.9388 ms per step
+        // (macro launch 98 us at 1.40 PFLOP/s + the small-tile remainder 120 us + the Adam pass 40 us); cfg4 (8192 rows) 0.6474
+        // (unsliced, fused Adam) vs 0.7248: a 2048-deep slice does not carry the slabs' extra pass -- from 16384 rows only.
+        const bool macro = g_dw_macro && p->dw_slices_max >= 4 && 4 * p->dw_macro_tiles >= 160 && p->Bp >= 16384 && gemm_bf16_256_slice_ok(256, 256, p->Bp / 4);
+        const int want = g_dw_slices > 0 ? g_dw_slices : macro ? 4 : (p->Bp >= 16384 ? 2 : 1);
         p->dw_slices_now = (p->dw_slices_max > 1 && want > 1 && p->Bp % (want * 64) == 0) ? std::min(want, p->dw_slices_max) : 1;
+        p->dw_macro_now = g_dw_macro && p->dw_slices_now > 1;
     }
     const int nd = (int)p->dec.size(), ne = (int)p->enc.size();
     auto cso = [](const std::vector<int64_t>& v, int i) -> int64_t { return v.empty() ? -1 : v[i]; };      // column-sum partials of a dY (bf16, Bp % 256 == 0)
@@ -1193,6 +1219,7 @@ extern "C" int dmvae_debug_set_tile(int bm, int bn) {
 
 extern "C" int dmvae_debug_set_knob(int which, int value) {
     if (which == 10) { g_dw_slices = value; return 0; }
+    if (which == 11) { g_dw_macro = value; return 0; }
     DMVAE_REQUIRE(which >= 0 && which <= 8, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, 3 = ring depth policy, 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy, 7 = short-K workgroups, 8 = first-tile stagger of the merged dW grid");
     gemm_bf16_set_knob(which, value);
     return 0;

@@ -72,7 +72,10 @@ namespace dmvae {
 // BKT = K depth of one ring slot (64; 32 is available to the dW layout: a 128x128 tile then gets a
 // 4-slot ring in the same 64 KiB, i.e. 48 KiB instead of 32 KiB in flight).
 // CONV: conv mode (GemmArgs::conv_c, gemm_epilogue.h) -- a compile-time variant, so the dense kernels carry none of it.
-template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW, int BKT = BK, bool CONV = false>
+// BONLY (DW layout, STORE_F32): a BIAS-ONLY strip -- the problem's A operand is never loaded or multiplied; only the column sums of
+// B = dY (the ones-operand MFMA) are produced, into epi.out2.  The weight gradient of such a layer is computed elsewhere (the
+// 256x256 macro tile, gemm_bf16_256.hip, which has no ones-operand pass); this strip rides in the grouped launch beside it.
+template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW, int BKT = BK, bool CONV = false, bool BONLY = false>
 __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_raw, const int gstart, const int nwg, bf16_t* smem,
                                                const dmvae_adam_ctx* ac = nullptr, const int kslice = -1) {
     constexpr bool A_KC = (LAYOUT != DMVAE_GEMM_DW);
@@ -80,7 +83,8 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     constexpr int A_ELEMS = BM * BKT, B_ELEMS = BN * BKT, STAGE = A_ELEMS + B_ELEMS;
     constexpr int WM = NW / 2;                       // waves along M (2 along N)
     constexpr int TM = BM / (16 * WM), TN = BN / 32; // 16x16 tiles per wave (wave tile = BM/WM x BN/2)
-    constexpr int LOADS = (BM + BN) * BKT / (512 * NW);   // LDS-DMA instructions per lane per K tile
+    static_assert(!BONLY || (LAYOUT == DMVAE_GEMM_DW && EPI == DMVAE_EPI_STORE_F32 && !CONV), "bias-only strips: dense DW / STORE_F32");
+    constexpr int LOADS = ((BONLY ? 0 : BM) + BN) * BKT / (512 * NW);   // LDS-DMA instructions per lane per K tile
     static_assert(NSTAGE >= 2 && NSTAGE <= 8 && LOADS * (NSTAGE - 1) <= 63, "ring depth / vmcnt range");
     // smem: NSTAGE * STAGE elements, the kernel's ONLY LDS object (owned by the __global__ wrapper)
 
@@ -129,7 +133,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     // fragment against an all-ones A operand (exact: products with 1.0, fp32 accumulate), in
     // the workgroups of the first tile row only -- no separate column-sum pass over dY.
     constexpr bool DW = (LAYOUT == DMVAE_GEMM_DW);
-    const bool do_bias = DW && a.epi.out2 != nullptr && tm == 0;
+    const bool do_bias = DW && a.epi.out2 != nullptr && (tm == 0 || BONLY);
     f32x4 bacc[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) bacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -195,7 +199,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
 #pragma unroll
             for (int i = 0; i < BM * BKT / (512 * NW); ++i) o[i] = goA[i] + selA[i] * cv_delta;
             glds_tile(Ag + cv_off, o, s, 1024u * NW);
-        } else {
+        } else if constexpr (!BONLY) {
             glds_tile(Ag + tc * stepA, goA, s, 1024u * NW);
         }
         glds_tile(Bg + tc * stepB, goB, s + 2u * A_ELEMS, 1024u * NW);
@@ -210,8 +214,10 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
 #pragma unroll
         for (int j = 0; j < TN; ++j) bfr[j] = ones;
 #else
+        if constexpr (!BONLY) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = read_frag<A_KC>(As, foA[ks][i][0], foA[ks][i][1]);
+            for (int i = 0; i < TM; ++i) af[i] = read_frag<A_KC>(As, foA[ks][i][0], foA[ks][i][1]);
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) bfr[j] = read_frag<B_KC>(Bs, foB[ks][j][0], foB[ks][j][1]);
 #endif
@@ -225,6 +231,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
 #else
         // the wave that has its fragments goes first: two waves share a SIMD, the other one is waiting on
         // LDS or the barrier anyway (measured on the step, tools/ab_libs.sh: 0.3136 -> 0.3110 ms)
+        if constexpr (!BONLY) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -233,6 +240,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
                 // operands swapped: D[row = n][col = m] -> each lane owns 4 consecutive n of one m
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+        }
 #endif
         if constexpr (DW) {
             if (do_bias) {
@@ -370,6 +378,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     }
     float* ct = reinterpret_cast<float*>(smem);
 #if DMVAE_ABLATE != 5
+    if constexpr (!BONLY) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -431,6 +440,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
         } else {
             epilogue_quad<EPI, bf16_t>(epi_s, m0 + ml, n0 + c * 4, v, loss, nullptr, nullptr, HAS_BIAS ? bq : nullptr);
         }
+    }
     }
 #else
 #pragma unroll
@@ -585,6 +595,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_grouped_kernel(GroupedArgs 
     } else {
         if (kind == 0) gemm_bf16_body<128, 128, LAYOUT, EPI, 2, NW>(g.p[i], bid, gs, cnt, smem, ac, ksl);
         else if (kind == 1) gemm_bf16_body<128, 64, LAYOUT, EPI, 3, NW>(g.p[i], bid, gs, cnt, smem, ac, ksl);
+        else if (kind == 3) {      // bias-only strip (see BONLY): M = 64 by construction, one workgroup per 64 columns and K slice
+            if constexpr (LAYOUT == DMVAE_GEMM_DW && EPI == DMVAE_EPI_STORE_F32)
+                gemm_bf16_body<64, 64, LAYOUT, EPI, 4, NW, BK, false, true>(g.p[i], bid, gs, cnt, smem, ac, ksl);
+        }
         else gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW>(g.p[i], bid, gs, cnt, smem, ac, ksl);
     }
 #if DMVAE_ABLATE == 6
@@ -671,12 +685,18 @@ static int launch_conv(hipStream_t s, const GemmArgs& a, int split) {
 // not give every CU a workgroup.
 template <int LAYOUT, int EPI>
 static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const dmvae_adam_ctx* ctx = nullptr, const dmvae_finalize_args* fin = nullptr) {
-    auto best_kind = [](const GemmArgs& p) { return (p.M % 128 == 0 && p.N % 128 == 0) ? 0 : (p.M % 128 == 0 ? 1 : 2); };
+    auto best_kind = [](const GemmArgs& p) { return p.bias_only ? 3 : (p.M % 128 == 0 && p.N % 128 == 0) ? 0 : (p.M % 128 == 0 ? 1 : 2); };
     auto nslices = [](const GemmArgs& p) { return (p.k_split > 0 && p.k_split < p.K) ? p.K / p.k_split : 1; };
-    auto tiles = [&](const GemmArgs& p, int kind) { return (p.M / (kind == 2 ? 64 : 128)) * (p.N / (kind == 0 ? 128 : 64)) * nslices(p); };     // workgroups: tiles x K slices
+    auto tiles = [&](const GemmArgs& p, int kind) {      // workgroups: tiles x K slices
+        if (kind == 3) return (p.N / 64) * nslices(p);
+        return (p.M / (kind == 2 ? 64 : 128)) * (p.N / (kind == 0 ? 128 : 64)) * nslices(p);
+    };
     // bytes one workgroup of this kind streams into LDS: these kernels run at the per-CU L2->LDS
     // intake rate (~70 GB/s), so a workgroup's duration is proportional to it
-    auto wg_bytes = [&](const GemmArgs& p, int kind) { return 2.0 * ((kind == 2 ? 64 : 128) + (kind == 0 ? 128 : 64)) * (double)(p.K / nslices(p)); };
+    auto wg_bytes = [&](const GemmArgs& p, int kind) {
+        if (kind == 3) return 2.0 * 64 * (double)(p.K / nslices(p));
+        return 2.0 * ((kind == 2 ? 64 : 128) + (kind == 0 ? 128 : 64)) * (double)(p.K / nslices(p));
+    };
     // Tile plan.  Every workgroup is resident at once (<= 2 per CU) and the dispatcher deals them
     // breadth-first in launch order (measured, tools/stamps.py): launched longest-first, workgroup
     // j lands on CU j mod 256, so CU c streams s[c] + s[c+256] + ... bytes.  Every problem may use
@@ -691,7 +711,7 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
         static std::mutex mu;
         static std::map<std::vector<int>, std::vector<int>> memo;
         std::vector<int> key;
-        for (int i = 0; i < nprob; ++i) { key.push_back(probs[i].M); key.push_back(probs[i].N); key.push_back(probs[i].K); key.push_back(nslices(probs[i])); }
+        for (int i = 0; i < nprob; ++i) { key.push_back(probs[i].M); key.push_back(probs[i].N); key.push_back(probs[i].K); key.push_back(nslices(probs[i]) * 2 + (probs[i].bias_only ? 1 : 0)); }
         std::lock_guard<std::mutex> lk(mu);
         auto it = memo.find(key);
         if (it == memo.end()) {
@@ -712,7 +732,7 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
                 for (double l : load) mx = std::max(mx, l);
                 if (mx < best_max * 0.99 || (mx < best_max * 1.01 && sum < best_sum)) { best_max = std::min(mx, best_max); best_sum = sum; best = cur; }
                 int i = 0;                               // next assignment: odometer over [best_kind, 2]
-                while (i < nprob && cur[i] == 2) { cur[i] = kinds[i]; ++i; }
+                while (i < nprob && (cur[i] == 2 || kinds[i] == 3)) { cur[i] = kinds[i]; ++i; }      // (a bias-only strip has one form)
                 if (i == nprob) break;
                 ++cur[i];
             }
@@ -733,8 +753,8 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
         g.kind[n] = kind;
         g.nsl[n] = nslices(probs[i]);
         g.p[n] = probs[i];
-        g.p[n].group_m = gemm_auto_group_m(probs[i].M / (kind == 2 ? 64 : 128), probs[i].N / (kind == 0 ? 128 : 64),
-                                      kind == 2 ? 64 : 128, kind == 0 ? 128 : 64);
+        g.p[n].group_m = gemm_auto_group_m(probs[i].M / (kind >= 2 ? 64 : 128), probs[i].N / (kind == 0 ? 128 : 64),
+                                      kind >= 2 ? 64 : 128, kind == 0 ? 128 : 64);
         total += tiles(probs[i], kind);
         flops += 2.0 * probs[i].M * probs[i].N * (double)probs[i].K;
         bytes += gemm_bytes(probs[i]);
@@ -753,7 +773,7 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
             for (int i = lo; i < hi; ++i) {
                 g.cls_start[i] = g.start[lo];
                 g.cls_end[i] = g.start[hi];
-                const int kind = g.kind[i], bm = kind == 2 ? 64 : 128, bn = kind == 0 ? 128 : 64;
+                const int kind = g.kind[i], bm = kind >= 2 ? 64 : 128, bn = kind == 0 ? 128 : 64;
                 const int t = (g.start[i + 1] - g.start[i]) / g.nsl[i];
                 g.p[i].group_m = gemm_auto_group_m(g.p[i].M / bm, g.p[i].N / bn, bm, bn, std::min<double>(t, run));
             }
@@ -816,6 +836,9 @@ static int peel_large_dw(hipStream_t s, const GemmArgs* probs, int nprob, const 
         any = any || (probs[i].k_split == probs[i].K && gemm_bf16_256_ok(DMVAE_GEMM_DW, probs[i].epi.kind, probs[i].M, probs[i].N, probs[i].K, probs[i].conv_c != 0));
     for (int i = 0; i < nprob; ++i) {
         const GemmArgs& p = probs[i];
+        // K slices into slabs (the dW group of a large batch): the caller (csrc/api.hip grad_dense) has taken the bias gradient off the
+        // problems it wants on the macro tile (a bias-only strip of the grouped launch produces it)
+        if (p.k_split != p.K && !p.bias_only && !p.epi.out2 && p.slab_stride && gemm_bf16_256_slice_ok(p.M, p.N, p.k_split)) { large.push_back(p); continue; }
         const bool own = p.k_split == p.K && gemm_bf16_256_ok(DMVAE_GEMM_DW, p.epi.kind, p.M, p.N, p.K, p.conv_c != 0);
         const bool rides = any && gemm_bf16_256_rides() && p.k_split == p.K && !p.conv_c && p.M % 256 == 0 && p.N % 256 == 0 && p.K >= 1024 &&
                            (p.epi.kind == DMVAE_EPI_STORE_F32 || p.epi.kind == DMVAE_EPI_ADAM);

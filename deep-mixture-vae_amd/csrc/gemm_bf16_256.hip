@@ -131,7 +131,20 @@ __device__ __forceinline__ void bias_seg_block(const BiasSeg& bs, const dmvae_ad
 
 // one 256x256 output tile; bid = tile id within the problem (the caller did the XCD-aware remap)
 template <int LAYOUT, int EPI>
-__device__ __forceinline__ void gemm256_tile(const GemmArgs& a, const dmvae_adam_ctx& ac, const int bid, bf16_t* smem) {
+// kslice >= 0 (DW layout, STORE_F32, GemmArgs::k_split < K): the tile's K range is [kslice * k_split, (kslice + 1) * k_split) and its
+// partial product goes to slab kslice (out + kslice * slab_stride): deterministic split-K, the slabs are added in a fixed order later
+__device__ __forceinline__ void gemm256_tile(const GemmArgs& a, const dmvae_adam_ctx& ac, const int bid, bf16_t* smem, const int kslice = -1) {
+    // (scalars, not a modified copy of the argument block: the LDS-DMA takes its tile pointer from SGPRs)
+    int kdim = a.K;
+    int64_t koffA = 0, koffB = 0, slab_off = 0;
+    if constexpr (LAYOUT == DMVAE_GEMM_DW && EPI == DMVAE_EPI_STORE_F32) {
+        if (kslice >= 0) {           // both operands are [K][..] in this layout: the slice is a row offset
+            kdim = a.k_split;
+            koffA = (int64_t)kslice * a.k_split * a.lda;
+            koffB = (int64_t)kslice * a.k_split * a.ldb;
+            slab_off = (int64_t)kslice * a.slab_stride;
+        }
+    }
     constexpr bool A_KC = (LAYOUT != DMVAE_GEMM_DW);
     constexpr bool B_KC = (LAYOUT == DMVAE_GEMM_DX);
     ANAT256(0);
@@ -150,10 +163,10 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& a, const dmvae_adam
         tn = in / gm;
     }
     const int m0 = tm * 256, n0 = tn * 256;
-    const int nk = a.K / BK;
+    const int nk = kdim / BK;
 
-    const bf16_t* Ag = reinterpret_cast<const bf16_t*>(a.A) + (A_KC ? (int64_t)m0 * a.lda : (int64_t)m0);
-    const bf16_t* Bg = reinterpret_cast<const bf16_t*>(a.B) + (B_KC ? (int64_t)n0 * a.ldb : (int64_t)n0);
+    const bf16_t* Ag = reinterpret_cast<const bf16_t*>(a.A) + koffA + (A_KC ? (int64_t)m0 * a.lda : (int64_t)m0);
+    const bf16_t* Bg = reinterpret_cast<const bf16_t*>(a.B) + koffB + (B_KC ? (int64_t)n0 * a.ldb : (int64_t)n0);
     const int64_t stepA = A_KC ? (int64_t)BK : (int64_t)BK * a.lda;
     const int64_t stepB = B_KC ? (int64_t)BK : (int64_t)BK * a.ldb;
     const int64_t hiA = A_KC ? (int64_t)128 * a.lda : (int64_t)128;     // A-hi relative to A-lo
@@ -312,6 +325,8 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& a, const dmvae_adam
                                                    EPI == DMVAE_EPI_RELU_MASK ? pre[b] : nullptr);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) cs[j] += bf2f(f2bf(sv[j]));       // the value the weight-gradient GEMM will read
+                    } else if constexpr (EPI == DMVAE_EPI_STORE_F32) {       // (K slice: its slab)
+                        ActIO<float>::store4(reinterpret_cast<float*>(a.epi.out) + slab_off, (int64_t)m * a.epi.ldo + n, v);
                     } else {
                         epilogue_quad<EPI, bf16_t>(a.epi, m, n, v, loss, nullptr, nullptr, HAS_BIAS ? bq : nullptr);
                     }
@@ -374,7 +389,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(GemmArgs a, dmvae
 constexpr int MULTI_MAX = 12;
 struct Multi256 {
     int nprob, stagger;
-    int start[MULTI_MAX + 1];            // tile workgroups of problem i: [start[i], start[i+1])
+    int start[MULTI_MAX + 1];            // tile workgroups of problem i: [start[i], start[i+1]) -- K slices x tiles, slice-major
+    int nsl[MULTI_MAX];                  // K slices of problem i (1 = none)
     int extra[MULTI_MAX + 1];            // bias-gradient workgroups of problem i, behind all tiles: start[nprob] + [extra[i], extra[i+1])
     GemmArgs p[MULTI_MAX];
     BiasSeg bs[MULTI_MAX];
@@ -397,7 +413,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_dw_multi_kernel(Multi256
         const int n = (b * m.stagger) >> 8;
         for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(127);
     }
-    gemm256_tile<DMVAE_GEMM_DW, EPI>(m.p[i], m.ac, xcd_run_index(b, m.start[i], m.start[i + 1]), smem);
+    int item = xcd_run_index(b, m.start[i], m.start[i + 1]), ksl = -1;
+    if (m.nsl[i] > 1) {
+        const int tiles_i = (m.start[i + 1] - m.start[i]) / m.nsl[i];
+        ksl = item / tiles_i;
+        item -= ksl * tiles_i;
+    }
+    gemm256_tile<DMVAE_GEMM_DW, EPI>(m.p[i], m.ac, item, smem, ksl);
 }
 
 // ---------------------------------------------------------------- host side
@@ -507,9 +529,14 @@ static int launch256_dw_multi(hipStream_t s, const GemmArgs* probs, int n, const
     for (int i = 0; i < n; ++i) {
         GemmArgs a = probs[i];
         const int tiles = (a.M / 256) * (a.N / 256);
+        const int nsl = (a.k_split > 0 && a.k_split < a.K) ? a.K / a.k_split : 1;
+        if (nsl > 1 && (EPI != DMVAE_EPI_STORE_F32 || !a.slab_stride || a.epi.out2 || a.k_split % BK)) {
+            set_error("gemm_bf16_256 (merged dW): K slices need the STORE_F32 epilogue into slabs and no fused bias gradient"); return DMVAE_EINVAL;
+        }
         a.group_m = gemm_auto_group_m(a.M / 256, a.N / 256, 256, 256, std::max(1.0, std::min(tiles, 256) / 8.0));
         m.p[i] = a;
-        m.start[i] = total; total += tiles;
+        m.nsl[i] = nsl;
+        m.start[i] = total; total += tiles * nsl;
         m.extra[i] = extra;
         if (a.epi.out2) {
             if (!a.csum_in || a.csum_ld != a.N) { set_error("gemm_bf16_256 (merged dW): a problem with a bias gradient needs its column-sum partials"); return DMVAE_EINVAL; }
@@ -522,12 +549,16 @@ static int launch256_dw_multi(hipStream_t s, const GemmArgs* probs, int n, const
         else bytes += 4.0 * a.M * a.N;
     }
     for (int i = n; i <= MULTI_MAX; ++i) { m.start[i] = total; m.extra[i] = extra; }
+    for (int i = n; i < MULTI_MAX; ++i) m.nsl[i] = 1;
     static const std::string nm = std::string("gemm_bf16_256_dw_multi_kernel<") + std::to_string(EPI) + ">";
     ProfScope ps(s, nm.c_str(), flops, bytes);
     DMVAE_LAUNCH((gemm_bf16_256_dw_multi_kernel<EPI>), dim3(total + extra), dim3(512), 0, s, m);
     return check_launch("gemm_bf16_256_dw_multi");
 }
 bool gemm_bf16_256_rides() { return g_policy256 >= 1 && g_stagger >= 0; }
+// K slices of a weight-gradient problem on the macro tile (partial products into slabs): the shape divides, and a slice is deep
+// enough to amortise the tile's prologue / epilogue (the rule of gemm_bf16_256_ok)
+bool gemm_bf16_256_slice_ok(int M, int N, int k_split) { return g_policy256 >= 1 && g_stagger >= 0 && M % 256 == 0 && N % 256 == 0 && k_split % BK == 0 && k_split >= 1024; }
 
 // slab column sums of dY for problems whose producers left none ([nslab][N] floats each, at a.csum_in -- already pointed into the
 // scratch by the caller): ONE launch for up to COLSUM_MAX problems of the same K
@@ -574,7 +605,7 @@ int gemm_bf16_256_dw_all(hipStream_t s, const GemmArgs* probs, int n, const dmva
         for (size_t lo = 0; lo < merge.size(); lo += MULTI_MAX) {
             const int cnt = (int)std::min<size_t>(MULTI_MAX, merge.size() - lo);
             int rc;
-            if (cnt == 1) rc = gemm_bf16_256_launch(s, DMVAE_GEMM_DW, merge[lo], ctx);
+            if (cnt == 1 && merge[lo].k_split == merge[lo].K) rc = gemm_bf16_256_launch(s, DMVAE_GEMM_DW, merge[lo], ctx);
             else if (merge[lo].epi.kind == DMVAE_EPI_ADAM) rc = launch256_dw_multi<DMVAE_EPI_ADAM>(s, merge.data() + lo, cnt, ctx);
             else rc = launch256_dw_multi<DMVAE_EPI_STORE_F32>(s, merge.data() + lo, cnt, ctx);
             if (rc) return rc;
@@ -585,7 +616,11 @@ int gemm_bf16_256_dw_all(hipStream_t s, const GemmArgs* probs, int n, const dmva
     };
     for (int i = 0; i < n; ++i) {
         GemmArgs a = probs[i];
-        if (a.k_split != a.K) { set_error("gemm_bf16_256: no split-K"); return DMVAE_EINVAL; }
+        if (a.k_split != a.K) {          // K slices into slabs: always through the merged kernel (it knows the slices), no bias gradient here
+            if (a.epi.kind != DMVAE_EPI_STORE_F32 || !a.slab_stride || a.epi.out2) { set_error("gemm_bf16_256: K slices need STORE_F32 into slabs, bias gradient elsewhere"); return DMVAE_EINVAL; }
+            merge.push_back(a);
+            continue;
+        }
         const bool has_part = a.csum_in && a.csum_ld == a.N;
         if (g_stagger < 0 || (a.epi.out2 && !has_part && (!a.ws || (int64_t)64 * a.N > a.ws_elems))) {
             // not mergeable (merging off, or a bias gradient with neither partials nor a scratch of the caller's): alone, in stream order

@@ -38,6 +38,9 @@ struct GemmArgs {
     float* csum_out = nullptr; int64_t csum_ld = 0;
     // DW layout, 256x256 kernel: such partials of this problem's dY, [csum_rows][csum_ld] (replaces the slab column sums)
     const float* csum_in = nullptr; int csum_rows = 0;
+    // DW layout, grouped small-tile launch: a BIAS-ONLY strip -- M = 64 pro forma, A is never read; only epi.out2 (the column sums of B)
+    // is produced.  The layer's weight gradient itself runs on the macro tile (K slices into slabs, csrc/api.hip launch_dw_queue).
+    int bias_only = 0;
 };
 
 // element offset of K position k (multiple of the tile depth) of a conv-mode A operand

@@ -60,7 +60,9 @@ int dmvae_debug_set_tile(int bm, int bn);
  *             knob 8 = merged weight-gradient grid of the 256x256 kernel: first-tile delay, units of 3.4 us spread over the
  *                      256 CUs (default 0 = none, measured best; -1 = one launch per problem),
  *             knob 10 = K slices of the dense weight-gradient group of plans with >= 8192 batch rows (slabs + fixed-order sum in the
- *                      Adam kernel): 0 = the plan's rule (2 from 16384 rows, else none), 1 = none, 2 | 4 = forced */
+ *                      Adam kernel): 0 = the plan's rule (4 where the 256-divisible layers take the macro tile, else 2 from 16384 rows, else none),
+ *                      1 = none, 2 | 4 = forced,
+ *             knob 11 = with K slices: the 256-divisible layers' slices on the 256x256 macro tile (1, default) or everything on the small tiles (0) */
 int dmvae_debug_set_knob(int which, int value);
 
 #ifdef __cplusplus
