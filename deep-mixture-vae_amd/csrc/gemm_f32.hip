@@ -34,19 +34,19 @@ __device__ __forceinline__ void f32_stage_store(float* s, const float4& r, int t
     }
 }
 
+// one output tile (bx) of K slice by of problem a; smem = 4 * FBK * FLD floats
 template <int LAYOUT, int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
+__device__ __forceinline__ void gemm_f32_body(const GemmArgs& a, const int bx, const int by, float* smem) {
     constexpr bool A_KC = (LAYOUT != DMVAE_GEMM_DW);
     constexpr bool B_KC = (LAYOUT == DMVAE_GEMM_DX);
     constexpr int T = FBK * FLD;
-    __shared__ __attribute__((aligned(16))) float smem[4 * T];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, g = lane >> 4;
     const int tiles_n = a.N / FBN;
-    const int m0 = (blockIdx.x / tiles_n) * FBM, n0 = (blockIdx.x % tiles_n) * FBN;
-    const int kbeg = blockIdx.y * a.k_split;
+    const int m0 = (bx / tiles_n) * FBM, n0 = (bx % tiles_n) * FBN;
+    const int kbeg = by * a.k_split;
     const int nk = a.k_split / FBK;
 
     const float* Ag = reinterpret_cast<const float*>(a.A);
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
     float loss = 0.f;
     dmvae_epilogue epi = a.epi;
     if constexpr (EPI == DMVAE_EPI_STORE_F32) {      // K-slice slabs
-        epi.out = reinterpret_cast<float*>(epi.out) + (int64_t)blockIdx.y * a.slab_stride;
-        if (epi.out2) epi.out2 = reinterpret_cast<float*>(epi.out2) + (int64_t)blockIdx.y * a.slab_stride2;
+        epi.out = reinterpret_cast<float*>(epi.out) + (int64_t)by * a.slab_stride;
+        if (epi.out2) epi.out2 = reinterpret_cast<float*>(epi.out2) + (int64_t)by * a.slab_stride2;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -170,8 +170,45 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
     }
     if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
         const float t = block_sum_256(loss, smem);
-        if (tid == 0) a.epi.partials[blockIdx.x] = t;
+        if (tid == 0) a.epi.partials[bx] = t;
     }
+}
+
+template <int LAYOUT, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * FBK * FLD];
+    gemm_f32_body<LAYOUT, EPI>(a, (int)blockIdx.x, (int)blockIdx.y, smem);
+}
+
+// The three contractions of the latent stage's MFMA form (latent_mfma.hip: G1 forward layout, G2 dX layout, G3 dW layout; all
+// STORE_F32, all reading only what latent_pre wrote) as ONE grid: workgroups [0, n1) = G1, [n1, n1 + n2) = G2, the rest G3; inside a
+// problem the id is slice-major (K slice = id / tiles).  Three launches of 6-25 us each were boundary-bound.
+struct F32Trio { GemmArgs p[3]; int start[4]; int tiles[3]; };
+__global__ __launch_bounds__(256) void gemm_f32_trio_kernel(F32Trio t) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * FBK * FLD];
+    const int b = (int)blockIdx.x;
+    if (b < t.start[1]) gemm_f32_body<DMVAE_GEMM_FWD, DMVAE_EPI_STORE_F32>(t.p[0], b % t.tiles[0], b / t.tiles[0], smem);
+    else if (b < t.start[2]) gemm_f32_body<DMVAE_GEMM_DX, DMVAE_EPI_STORE_F32>(t.p[1], (b - t.start[1]) % t.tiles[1], (b - t.start[1]) / t.tiles[1], smem);
+    else gemm_f32_body<DMVAE_GEMM_DW, DMVAE_EPI_STORE_F32>(t.p[2], (b - t.start[2]) % t.tiles[2], (b - t.start[2]) / t.tiles[2], smem);
+}
+int gemm_f32_trio(hipStream_t s, const GemmArgs& g1, int split1, const GemmArgs& g2, int split2, const GemmArgs& g3, int split3) {
+    F32Trio t;
+    const GemmArgs* g[3] = {&g1, &g2, &g3};
+    const int sp[3] = {split1, split2, split3};
+    int total = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (g[i]->epi.kind != DMVAE_EPI_STORE_F32 || g[i]->M % FBM || g[i]->N % FBN || sp[i] < 1 || g[i]->K % (sp[i] * FBK) || g[i]->conv_c || g[i]->epi.out2) {
+            set_error("gemm_f32_trio: STORE_F32 problems on the 64 x 64 x %d tile grid only", FBK); return DMVAE_EINVAL;
+        }
+        t.p[i] = *g[i];
+        t.p[i].k_split = g[i]->K / sp[i];
+        t.tiles[i] = (g[i]->M / FBM) * (g[i]->N / FBN);
+        t.start[i] = total;
+        total += t.tiles[i] * sp[i];
+    }
+    t.start[3] = total;
+    DMVAE_LAUNCH(gemm_f32_trio_kernel, dim3(total), dim3(256), 0, s, t);
+    return check_launch("gemm_f32_trio");
 }
 
 template <int LAYOUT, int EPI>

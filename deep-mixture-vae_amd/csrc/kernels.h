@@ -34,6 +34,8 @@ int gemm_bf16_256_dw_all(hipStream_t s, const GemmArgs* probs, int n, const dmva
 void gemm_bf16_force_tile(int t);
 void gemm_bf16_set_knob(int which, int v);
 int gemm_f32_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split);
+// three STORE_F32 problems (forward / dX / dW layout, in that order) with split1 / split2 / split3 K slices as ONE grid (latent_mfma.hip)
+int gemm_f32_trio(hipStream_t s, const GemmArgs& g1, int split1, const GemmArgs& g2, int split2, const GemmArgs& g3, int split3);
 int latent_nblocks(int B_pad, int D, int K);
 int latent_launch(hipStream_t s, const dmvae_latent_args* a);
 // VaDE's latent stage (latent_vade.hip): mode 2

@@ -298,14 +298,14 @@ __global__ __launch_bounds__(256) void latent_post_kernel(LatentMfmaArgs L, int 
     }
 }
 
-static int f32_gemm(hipStream_t s, int layout, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb, float* out, int64_t ldo,
-                    int split, int64_t slab_stride) {
+static GemmArgs f32_problem(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb, float* out, int64_t ldo,
+                            int split, int64_t slab_stride) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.k_split = K / split; g.group_m = 8; g.conv_p = 0; g.conv_c = 0;
     memset(&g.epi, 0, sizeof(g.epi));
     g.epi.kind = DMVAE_EPI_STORE_F32; g.epi.out = out; g.epi.ldo = ldo; g.epi.m_valid = M; g.epi.n_valid = N;
     g.slab_stride = slab_stride;
-    return gemm_f32_dispatch(s, layout, g, split);
+    return g;
 }
 
 int latent_mfma_launch(hipStream_t s, const dmvae_latent_args* a, float* ws, int64_t ws_bytes) {
@@ -324,9 +324,12 @@ int latent_mfma_launch(hipStream_t s, const dmvae_latent_args* a, float* ws, int
     if (rc) return rc;
     {
         ProfScope ps(s, "latent_gemm_f32", 2.0 * a->B_pad * (double)w.Kp * (2.0 * w.Dp + 2.0 * w.Dp + w.XW), 4.0 * a->B_pad * (3.0 * w.Kp + 2.0 * w.XW + 2.0 * w.Dp));
-        rc = f32_gemm(s, DMVAE_GEMM_FWD, a->B_pad, 2 * w.Dp, w.Kp, ws + w.Wm, w.Kp, ws + w.T1, 2 * w.Dp, ws + w.AC, 2 * w.Dp, 1, 0);
-        if (!rc) rc = f32_gemm(s, DMVAE_GEMM_DX, a->B_pad, w.Kp, 2 * w.Dp, ws + w.X1, w.XW, ws + w.T2, 2 * w.Dp, ws + w.S, w.Kp, w.nsplit_s, (int64_t)a->B_pad * w.Kp);
-        if (!rc) rc = f32_gemm(s, DMVAE_GEMM_DW, w.Kp, w.XW, a->B_pad, ws + w.Wm, w.Kp, ws + w.X1, w.XW, ws + w.G, w.XW, w.nsplit, (int64_t)w.Kp * w.XW);
+        // G1 (forward layout), G2 (dX layout, K slices into slabs), G3 (dW layout, batch slices into slabs): all three read only what
+        // latent_pre wrote -- ONE grid (gemm_f32_trio) instead of three launches
+        const GemmArgs g1 = f32_problem(a->B_pad, 2 * w.Dp, w.Kp, ws + w.Wm, w.Kp, ws + w.T1, 2 * w.Dp, ws + w.AC, 2 * w.Dp, 1, 0);
+        const GemmArgs g2 = f32_problem(a->B_pad, w.Kp, 2 * w.Dp, ws + w.X1, w.XW, ws + w.T2, 2 * w.Dp, ws + w.S, w.Kp, w.nsplit_s, (int64_t)a->B_pad * w.Kp);
+        const GemmArgs g3 = f32_problem(w.Kp, w.XW, a->B_pad, ws + w.Wm, w.Kp, ws + w.X1, w.XW, ws + w.G, w.XW, w.nsplit, (int64_t)w.Kp * w.XW);
+        rc = gemm_f32_trio(s, g1, 1, g2, w.nsplit_s, g3, w.nsplit);
     }
     if (rc) return rc;
     {
