@@ -203,7 +203,7 @@ def respawn_ranks(args):
     import socket
     import subprocess
     have = torch.cuda.device_count()        # counting devices does not initialise the GPU
-    if have < args.gpus:
+    if have < args.gpus and args.backend != "gloo":      # (a gloo rehearsal lets the ranks share one card)
         print("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have), file=sys.stderr)
         sys.exit(2)
     s = socket.socket()
@@ -367,9 +367,13 @@ def main():
                    # a gloo rehearsal on one card also says 0 and names its backend)
                    "rccl_ranks": (world if (world > 1 or force_dp) and args.backend == "nccl" else 0),
                    "collective_backend": (("rccl (torch.distributed nccl)" if args.backend == "nccl" else "gloo (rehearsal)") if (world > 1 or force_dp) else None),
+                   # what has run BEFORE this line was printed: gloo at world 2 / 4 / 8 (CPU), two processes on the real kernels over gloo,
+                   # a one-rank RCCL communicator (identity collectives) -- never a multi-rank RCCL job (gpurun gives one GPU)
+                   "multi_rank_rccl_verified_before_this_run": False,
                    "hip_graph": (not args.no_graph) and sync is None, "float_atomics": False,
                    "update": "stand-alone adam" if args.cnn and sync is None else "adam fused into the dW launch" if sync is None else
-                             ("%s, %s" % ("reduce-scatter -> adam on the owned 1/world slice -> all-gather" if getattr(sync, "sharded", False) else "all-reduce -> replicated adam",
+                             ("%s, %s" % ("weights: reduce-scatter -> adam on the owned 1/world slice -> all-gather of the %s; biases + prior tables: all-reduce -> replicated adam"
+                                          % ("bf16 shadow" if args.dtype == "bf16" else "fp32 weights") if getattr(sync, "sharded", False) else "all-reduce -> replicated adam",
                                           "three buckets overlapped with the backward pass" if getattr(sync, "overlap", False) else "one collective after the backward pass"))},
         "step_flops_algorithmic": fpi * B,
         "step_mfma_frac_of_peak": round(fpi * B / (ms_step * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4),
