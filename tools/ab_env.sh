@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: alternate bench runs (graph replay, no profiling) with and without an environment switch:
-#   tools/ab_env.sh DMVAE_FINALIZE_INLINE=1 [rounds]
+#   tools/ab_env.sh DMVAE_KNOBS=10=1 [rounds]
 cd $GRAFT_REPO_ROOT
 V=$1; R=${2:-4}
 for r in $(seq $R); do
