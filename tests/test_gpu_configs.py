@@ -269,3 +269,82 @@ def test_fp32_step_with_the_oracles_own_relu_masks():
         h = clear(h, "dec%d" % i)
     # same batch / noise stream as fp32_step_vs_oracle draws from seed 1
     fp32_step_vs_oracle(kw, B, own_masks=True, p_override=p, seed=1)
+
+
+@pytest.mark.parametrize("slices,macro", [(2, 0), (4, 0), (4, 1)])
+def test_dw_group_in_k_slices_equals_the_unsliced_group(slices, macro):
+    """dW group in K slices (batches >= 8192 rows have the slabs; the plan's rule turns them on from 16384 rows, knobs 10 / 11 force them
+    here at cfg4's 8192): every problem cut into `slices` K ranges that store partial products into slabs, the 256-divisible layers on
+    the macro tile with bias-only strips (macro = 1), the slabs added in ascending order by slab_reduce (backward alone) or inside
+    the Adam kernel (fused step).  Against the unsliced group on the same batch and noise: loss identical (the forward pass is
+    untouched), every gradient tensor within 1e-3 of its Frobenius norm (another summation order over bf16 products); inside the
+    sliced form: fused step == backward + stand-alone Adam bit for bit, two runs bit-identical."""
+    from dmvae_hip import _lib
+    kw, B, lr = FULL["cfg4"]
+    g = torch.Generator(device="cuda"); g.manual_seed(21)
+    X = torch.rand((B, 784), device="cuda", generator=g) * (torch.rand((B, 784), device="cuda", generator=g) < 0.19)
+    eps = torch.randn((B, kw["latent_dim"]), device="cuda", generator=g)
+
+    def run(fused):
+        eng = make(kw, "bf16", B, seed=4, lr=lr)
+        eng.load_batch(X, None, 0, B)
+        if fused:
+            eng.forward_backward_update(B, eps)
+        else:
+            eng.forward_backward(B, eps)
+            torch.cuda.synchronize()
+            grad = eng.grad.clone()
+            eng.update(1.0)
+        torch.cuda.synchronize()
+        out = (eng.read_state().last_loss, eng.param.clone(), eng.m.clone(), eng.v.clone(), eng.param_bf16.clone(), None if fused else grad,
+               {k: eng._strided(eng.grad, k).clone() for k in eng.tensors} if not fused else None)
+        del eng
+        return out
+
+    try:
+        _lib.check(_lib.lib.dmvae_debug_set_knob(10, 1))
+        base = run(False)
+        _lib.check(_lib.lib.dmvae_debug_set_knob(10, slices))
+        _lib.check(_lib.lib.dmvae_debug_set_knob(11, macro))
+        plain, plain2, fused = run(False), run(False), run(True)
+    finally:
+        _lib.check(_lib.lib.dmvae_debug_set_knob(10, 0))
+        _lib.check(_lib.lib.dmvae_debug_set_knob(11, 1))
+    assert plain[0] == base[0] == fused[0]
+    for i in (1, 2, 3, 4):
+        assert torch.equal(plain[i], plain2[i]) and torch.equal(plain[i], fused[i]), i          # reproducible; fused == unfused
+    assert torch.equal(plain[5], plain2[5]) and not torch.equal(plain[5], base[5])                # (the slices ARE another summation order)
+    for k in base[6]:
+        d = (plain[6][k] - base[6][k]).norm().item() / (base[6][k].norm().item() + 1e-30)
+        assert d <= 1e-3, (k, d)
+
+
+def test_bf16_plan_with_ieee_adam_matches_the_fp32_arithmetic():
+    """dmvae_config.adam_ieee: a bf16 plan whose Adam quotient uses the IEEE square root and division.  Fused and
+    stand-alone updates stay bit-identical under the switch, and the parameters after one step differ from the default (hardware sqrt /
+    reciprocal) by at most a few ulps of the step size."""
+    from dmvae_hip import StepEngine
+    kw, B = CFG2, 512
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    X = torch.rand((B, 784), device="cuda", generator=g) * (torch.rand((B, 784), device="cuda", generator=g) < 0.19)
+    eps = torch.randn((B, 64), device="cuda", generator=g)
+    res = {}
+    for ieee in (False, True):
+        for fused in (False, True):
+            eng = StepEngine(dtype="bf16", max_batch=B, deterministic=True, seed=77, adam_ieee=ieee, **kw)
+            eng.init_parameters(4)
+            eng.load_batch(X, None, 0, B)
+            if fused:
+                eng.forward_backward_update(B, eps)
+            else:
+                eng.forward_backward(B, eps)
+                eng.update(1.0)
+            torch.cuda.synchronize()
+            res[(ieee, fused)] = (eng.param.clone(), eng.m.clone(), eng.v.clone())
+            del eng
+    for ieee in (False, True):
+        for a, b in zip(res[(ieee, False)], res[(ieee, True)]):
+            assert torch.equal(a, b)
+    assert torch.equal(res[(False, True)][1], res[(True, True)][1]) and torch.equal(res[(False, True)][2], res[(True, True)][2])      # m, v: same arithmetic
+    d = (res[(False, True)][0] - res[(True, True)][0]).abs().max().item()
+    assert 0 < d <= 1.5e-8, d          # the quotients differ by ~1 ulp of a step <= lr = 2e-3; in p - quotient that is at most one ulp of p (|p| < 0.125: 2^-27)
