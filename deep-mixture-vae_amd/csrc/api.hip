@@ -399,14 +399,21 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
         for (auto& L : p->dec) chk(L);
         if (!p->vade) { chk(p->zc); chk(p->lg); }
         chk(p->mv); chk(p->out);
-        if (c->dtype == DMVAE_BF16 && p->conv.empty() && Bp >= 8192 && Bp % (4 * 64) == 0 && !macro) {
+        // every layer's problem + a bias strip for each layer the macro tile may take must fit ONE grouped launch queue: the fused
+        // step sums the slabs once, behind it
+        int n_dw = 0, n_elig = 0, tiles = 0;
+        auto cnt = [&](const PLayer& L) {
+            ++n_dw;
+            if (L.in_pad % 256 == 0 && L.out_pad % 256 == 0) { ++n_elig; tiles += (L.in_pad / 256) * (L.out_pad / 256); }
+        };
+        for (auto& L : p->enc) cnt(L);
+        for (auto& L : p->dec) cnt(L);
+        if (!p->vade) { cnt(p->zc); cnt(p->lg); }
+        cnt(p->mv); cnt(p->out);
+        if (c->dtype == DMVAE_BF16 && p->conv.empty() && Bp >= 8192 && Bp % (4 * 64) == 0 && !macro && n_dw + n_elig < DMVAE_MAX_GROUP) {
             p->dw_slices_max = 4;
             p->o_dwslab = take((int64_t)p->dw_slices_max * p->param_elems * 4);
-            auto cnt = [&](const PLayer& L) { if (L.in_pad % 256 == 0 && L.out_pad % 256 == 0) p->dw_macro_tiles += (L.in_pad / 256) * (L.out_pad / 256); };
-            for (auto& L : p->enc) cnt(L);
-            for (auto& L : p->dec) cnt(L);
-            if (!p->vade) { cnt(p->zc); cnt(p->lg); }
-            cnt(p->mv); cnt(p->out);
+            p->dw_macro_tiles = tiles;
         }
     }
     // the step path may leave the batch's f32 copy out (dmvae_plan_load_batch_step): bf16, 16-byte aligned dataset rows, and an
