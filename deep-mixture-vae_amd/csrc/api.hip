@@ -123,6 +123,7 @@ static int g_dw_slices = 0;
 // tuning knob (dmvae_debug_set_knob 11): with K slices, the layers whose shape divides by 256 on the macro tile (1, default) or every
 // layer on the small tiles (0)
 static int g_dw_macro = 1;
+static int g_heads_dx_form = 0;             // tuning knob (dmvae_debug_set_knob 12): the dX of the two head layers as one grouped launch (0 / 1) or as two launches (2)
 
 // ====================================================================== plan
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -934,6 +935,10 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
                      grp ? &q[0] : nullptr, WS(p, p->o_dhzc), p->o_cs_dhzc, 2 * p->Hp, 0));
         TRY(dx_dense(p, s, WS(p, p->o_dlg), p->Kp, p->Kp, p->lg.w_off, p->lg.ldw, p->Hp, act_off(p, p->o_hzc, p->Hp), 2 * p->Hp,
                      const_cast<void*>(act_off(p, p->o_dhzc, p->Hp)), 2 * p->Hp, grp ? &q[1] : nullptr, WS(p, p->o_dhzc), p->o_cs_dhzc, 2 * p->Hp, p->Hp));
+        if (grp && g_heads_dx_form == 2) {       // z-hidden as its own launch, c-hidden (and the riding finalize blocks) as a group of one
+            TRY(gemm_bf16_dispatch(s, DMVAE_GEMM_DX, q[0], 1));
+            TRY(gemm_bf16_grouped(s, DMVAE_GEMM_DX, q + 1, 1, fin_rides ? &fin : nullptr));
+        } else
         if (grp) TRY(gemm_bf16_grouped(s, DMVAE_GEMM_DX, q, 2, fin_rides ? &fin : nullptr));
     }
     // ---- backward: trunk
@@ -1227,7 +1232,8 @@ extern "C" int dmvae_debug_set_tile(int bm, int bn) {
 extern "C" int dmvae_debug_set_knob(int which, int value) {
     if (which == 10) { g_dw_slices = value; return 0; }
     if (which == 11) { g_dw_macro = value; return 0; }
-    DMVAE_REQUIRE(which >= 0 && which <= 8, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, 3 = ring depth policy, 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy, 7 = short-K workgroups, 8 = first-tile stagger of the merged dW grid");
+    if (which == 12) { g_heads_dx_form = value; return 0; }
+    DMVAE_REQUIRE(which >= 0 && which <= 9, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, 3 = ring depth policy, 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy, 7 = short-K workgroups, 8 = first-tile stagger of the merged dW grid");
     gemm_bf16_set_knob(which, value);
     return 0;
 }

@@ -127,8 +127,10 @@ __device__ __forceinline__ void step_finalize_block(const int blk, const dmvae_f
     }
     const int col = (blk - 1) * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;
     float s = 0.f;
-    if (col < f.ncol)
+    if (col < f.ncol) {
+#pragma unroll 8                          // (eight loads in flight per lane; the order of the additions is unchanged)
         for (int r = rg; r < f.nblk; r += 16) s += f.part[(int64_t)r * f.ncol + col];
+    }
     red[rg][threadIdx.x & 15] = s;
     __syncthreads();
     if (threadIdx.x < 16 && col < f.ncol) {

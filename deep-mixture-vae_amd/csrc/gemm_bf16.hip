@@ -539,12 +539,13 @@ struct GroupedArgs {
     GemmArgs p[DMVAE_MAX_GROUP];
     dmvae_adam_ctx adam;      // DMVAE_EPI_ADAM launches only
     dmvae_finalize_args fin;  // DMVAE_EPI_RELU_MASK launches: fin.nblocks extra workgroups run step_finalize (0 = none)
+    int lead, lead_work;      // ... in the first `lead` (fin.nblocks rounded up to 8) workgroup ids of the grid; ADAM launches: the lead_work workgroups of the extra segment, likewise
 };
 // SHORTK: every problem has K <= 128 (one or two K tiles: the dX of the narrow heads).  Such a workgroup is all prologue
 // and epilogue -- what helps is MORE of them per CU: 64x64 tiles on a 2-slot ring = 32 KiB of LDS, four to five workgroups
 // per CU instead of two.
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4, bool SHORTK = false>
-__global__ __launch_bounds__(64 * NW) void gemm_bf16_grouped_kernel(GroupedArgs g) {
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_bf16_grouped_kernel(GroupedArgs g) {      // (eight waves: <= 128 VGPRs, so that two workgroups share a CU)
     // every problem takes the largest tile its shape divides (traffic per flop ~ (BM+BN)/(BM*BN)):
     // kind 0 = 128x128 / 2 stages, 1 = 128x64 / 3, 2 = 64x64 / 4  -- one LDS array of the largest ring
     __shared__ __attribute__((aligned(16))) bf16_t smem[SHORTK ? 2 * (64 + 64) * BK : 3 * (128 + 64) * BK];   // 72 KiB >= 2*(128+128)*64, 4*(64+64)*64
@@ -566,15 +567,21 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_grouped_kernel(GroupedArgs 
     // each problem: an XCD then works on one or two problems with large blocks of their tiles
     // instead of an eighth of every problem, so far fewer operand panels are fetched by more
     // than one L2.  The workgroup mix per XCD / CU is unchanged (a permutation inside a class).
+    int bx = (int)blockIdx.x;
     if constexpr (EPI == DMVAE_EPI_RELU_MASK) {
-        if ((int)blockIdx.x >= g.start[g.nprob]) {   // the extra workgroups: loss scalars / Adam step / prior-table gradients
-            step_finalize_block((int)blockIdx.x - g.start[g.nprob], g.fin, reinterpret_cast<float(*)[17]>(smem));
+        // the riding workgroups (loss scalars / Adam step / prior-table gradients: chains of dependent memory latencies, no bandwidth)
+        // hold the FIRST ids of the grid, so they run under the tiles instead of behind the last one; g.lead is a multiple of 8, which
+        // keeps id % 8 -- the XCD a workgroup lands on -- what the tile mapping below assumes
+        if (bx < g.lead) {
+            if (NW > 4 && threadIdx.x >= 256) return;    // (written for four waves; a finished wave leaves the barrier count)
+            if (bx < g.fin.nblocks) step_finalize_block(bx, g.fin, reinterpret_cast<float(*)[17]>(smem));
             return;
         }
+        bx -= g.lead;
     }
     int i = 0;
-    while (i + 1 < g.nprob && (int)blockIdx.x >= g.start[i + 1]) ++i;
-    const int item = g.cls_start[i] + xcd_run_index((int)blockIdx.x, g.cls_start[i], g.cls_end[i]);
+    while (i + 1 < g.nprob && bx >= g.start[i + 1]) ++i;
+    const int item = g.cls_start[i] + xcd_run_index(bx, g.cls_start[i], g.cls_end[i]);
     i = 0;
     while (i + 1 < g.nprob && item >= g.start[i + 1]) ++i;
     int bid = item - g.start[i];
@@ -630,6 +637,7 @@ static int g_shortk = 0;                    // tuning knob (dmvae_debug_set_knob
                                             // MEASURED (tools/knob_ab.py 7 0 1): cfg2 0.2948 (off) vs 0.2985 ms (on), cfg4 0.6834 vs 0.6845: off
 static int g_conv_short = 2;                // tuning knob (dmvae_debug_set_knob 5): >= 1 short-K conv tiles as 4-wave / 2-slot workgroups, 2 also 3-slot rings for the 64x64 weight-gradient tiles (tools/cnn_knob.py: 3.539 / 3.290 / 3.270 ms)
 static int g_grouped_cls = 1;               // tuning knob (dmvae_debug_set_knob 4): XCD runs cut per tile-shape class (1) or per problem (0)
+static int g_dx_group_nw = 0;               // tuning knob (dmvae_debug_set_knob 9): waves per workgroup of a grouped dX launch, 0 = automatic, 4, 8
 static int g_grouped_mixed = 1;             // tuning knob (dmvae_debug_set_knob 2): 0 all 64x64, 1 planned per-problem tiles, 2 largest tile each shape divides
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4>
 static const char* kernel_name(bool grouped) {   // the template instantiation, as rocprofv3 prints it
@@ -781,7 +789,8 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
         }
     int extra = 0;
     g.fin = dmvae_finalize_args{};
-    if (fin && EPI == DMVAE_EPI_RELU_MASK) { g.fin = *fin; extra = fin->nblocks; }
+    g.lead = 0; g.lead_work = 0;
+    if (fin && EPI == DMVAE_EPI_RELU_MASK) { g.fin = *fin; g.lead = (fin->nblocks + 7) & ~7; extra = g.lead; }
     g.adam = dmvae_adam_ctx{};
     if (ctx) {
         g.adam = *ctx;
@@ -803,6 +812,14 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
     if constexpr (LAYOUT != DMVAE_GEMM_DW) {
         if (shortk) {
             DMVAE_LAUNCH((gemm_bf16_grouped_kernel<64, 64, LAYOUT, EPI, 2, 4, true>), dim3(total + extra), dim3(256), 0, s, g);
+            return check_launch("gemm_bf16_grouped");
+        }
+    }
+    // the dX of the two head layers is all mask read and output written (K = 2 D | the padded class count): eight waves per
+    // workgroup keep twice the epilogue loads / stores in flight per CU
+    if constexpr (LAYOUT == DMVAE_GEMM_DX && EPI == DMVAE_EPI_RELU_MASK) {
+        if (g_dx_group_nw == 8) {
+            DMVAE_LAUNCH((gemm_bf16_grouped_kernel<64, 64, LAYOUT, EPI, 4, 8>), dim3(total + extra), dim3(512), 0, s, g);
             return check_launch("gemm_bf16_grouped");
         }
     }
@@ -900,6 +917,7 @@ void gemm_bf16_set_knob(int which, int v) {
     if (which == 6) gemm_bf16_256_set_policy(v);
     if (which == 7) g_shortk = v;
     if (which == 8) gemm_bf16_256_set_stagger(v);
+    if (which == 9) g_dx_group_nw = v;
 }
 
 // Tile choice, BM*1000+BN.  These GEMMs run at the per-CU L2->LDS streaming rate, so the figure
