@@ -551,9 +551,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_bf16_grouped_ke
     __shared__ __attribute__((aligned(16))) bf16_t smem[SHORTK ? 2 * (64 + 64) * BK : 3 * (128 + 64) * BK];   // 72 KiB >= 2*(128+128)*64, 4*(64+64)*64
     const dmvae_adam_ctx* ac = EPI == DMVAE_EPI_ADAM ? &g.adam : nullptr;
     if constexpr (EPI == DMVAE_EPI_ADAM) {
-        if ((int)blockIdx.x >= g.start[g.nprob]) {   // the extra workgroup(s): arena segment whose gradient is already in memory
+        if ((int)blockIdx.x < g.lead) {              // the extra workgroup(s): arena segment whose gradient is already in memory (first ids, see below)
+            if ((int)blockIdx.x >= g.lead_work) return;
             const int64_t n4 = g.adam.seg_n >> 2;
-            for (int64_t q = (int64_t)((int)blockIdx.x - g.start[g.nprob]) * (64 * NW) + threadIdx.x; q < n4; q += (int64_t)((int)gridDim.x - g.start[g.nprob]) * (64 * NW)) {
+            for (int64_t q = (int64_t)blockIdx.x * (64 * NW) + threadIdx.x; q < n4; q += (int64_t)g.lead_work * (64 * NW)) {
                 const int64_t off = g.adam.seg_off + 4 * q;
                 const float4 gq = *reinterpret_cast<const float4*>(g.adam.grad + off);
                 const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
@@ -568,6 +569,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_bf16_grouped_ke
     // instead of an eighth of every problem, so far fewer operand panels are fetched by more
     // than one L2.  The workgroup mix per XCD / CU is unchanged (a permutation inside a class).
     int bx = (int)blockIdx.x;
+    if constexpr (EPI == DMVAE_EPI_ADAM) bx -= g.lead;
     if constexpr (EPI == DMVAE_EPI_RELU_MASK) {
         // the riding workgroups (loss scalars / Adam step / prior-table gradients: chains of dependent memory latencies, no bandwidth)
         // hold the FIRST ids of the grid, so they run under the tiles instead of behind the last one; g.lead is a multiple of 8, which
@@ -798,7 +800,7 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
         double elems = (double)ctx->seg_n;
         for (int i = 0; i < nprob; ++i) elems += (double)probs[i].M * probs[i].N + (probs[i].epi.out2 ? probs[i].N : 0);
         bytes += elems * (24.0 + (ctx->param_bf16 ? 2.0 : 0.0) + (ctx->store_grad ? 4.0 : 0.0)) + 4.0 * ctx->seg_n;
-        if (ctx->seg_n > 0) extra = (int)std::min<int64_t>(4, (ctx->seg_n / 4 + 255) / 256);
+        if (ctx->seg_n > 0) { g.lead_work = (int)std::min<int64_t>(4, (ctx->seg_n / 4 + 255) / 256); g.lead = 8; extra = g.lead; }
     }
     // reported under a name that says what the grid is (rocprofv3 prints the <64, 64, ...> instantiation: the 64x64
     // tile is only the smallest of the three the kernel dispatches to per problem)

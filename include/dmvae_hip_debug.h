@@ -62,7 +62,10 @@ int dmvae_debug_set_tile(int bm, int bn);
  *             knob 10 = K slices of the dense weight-gradient group of plans with >= 8192 batch rows (slabs + fixed-order sum in the
  *                      Adam kernel): 0 = the plan's rule (4 where the 256-divisible layers take the macro tile, else 2 from 16384 rows, else none),
  *                      1 = none, 2 | 4 = forced,
- *             knob 11 = with K slices: the 256-divisible layers' slices on the 256x256 macro tile (1, default) or everything on the small tiles (0) */
+ *             knob 11 = with K slices: the 256-divisible layers' slices on the 256x256 macro tile (1, default) or everything on the small tiles (0)
+ *             knob 9  = waves per workgroup of a grouped dX launch (0 / 4 = four, 8 = eight at <= 128 VGPRs; tools/heads_dx_probe.py, tools/knob_step.py:
+ *                       85.6 vs 90.0 us alone at 16384 rows, 0.9785 vs 0.9651 ms in the step -- four)
+ *             knob 12 = the dX of the two head layers as one grouped launch (0 / 1, default) or as two launches (2: 0.9424 vs 0.9366 ms at 16384 rows) */
 int dmvae_debug_set_knob(int which, int value);
 
 #ifdef __cplusplus
