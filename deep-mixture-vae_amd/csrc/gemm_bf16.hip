@@ -317,7 +317,11 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
         for (int q = 0; q < NQ; ++q) {
             const int idx = q * (64 * NW) + tid;
             const int ml = idx / (BN / 4), c = idx % (BN / 4);
+#if DMVAE_ABLATE == 8      // (tools/ablate.sh 8: no mask read -- the upper bound of what a 1-bit mask could save)
+            gate[q] = make_uint2(0x3f803f80u, 0x3f803f80u); (void)ml; (void)c;
+#else
             gate[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.epi.aux0) + (int64_t)(m0 + ml) * a.epi.ld0 + n0 + c * 4);
+#endif
         }
     }
     // Only real tiles are issued.  (Round 1 clamped tile ids past the K range to the last tile to keep every vmcnt count a
