@@ -782,7 +782,9 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
     if (g_grouped_cls)
         for (int lo = 0; lo < nprob;) {
             int hi = lo + 1;
-            while (hi < nprob && g.kind[hi] == g.kind[lo]) ++hi;
+            // (a class is problems of one tile shape AND comparable K: an XCD's run is a share of the class by workgroup COUNT, so
+            //  with the heads' dX pair -- K = 2 D next to K = 64 -- in one class, four XCDs got the long workgroups and four waited)
+            while (hi < nprob && g.kind[hi] == g.kind[lo] && 2 * std::min(g.p[hi].K / g.nsl[hi], g.p[lo].K / g.nsl[lo]) > std::max(g.p[hi].K / g.nsl[hi], g.p[lo].K / g.nsl[lo])) ++hi;
             const double run = std::max(1.0, (g.start[hi] - g.start[lo]) / 8.0);
             for (int i = lo; i < hi; ++i) {
                 g.cls_start[i] = g.start[lo];
