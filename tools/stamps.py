@@ -42,3 +42,16 @@ for kind in (0, 1, 2):
               % (kind, len(d), d[0] / 100.0, d[len(d) // 2] / 100.0, d[-1] / 100.0, kl[len(kl) // 2], kl[-1], ep[len(ep) // 2], ep[-1]))
 late = sorted(rows, key=lambda r: -r[2])[:8]
 print("last finishers:", [(r[0], r[6], round((r[1] - t_min) / 100.0, 1), round((r[2] - t_min) / 100.0, 1)) for r in late])
+# the stragglers: which XCD / CU, their K loop and epilogue, and what shared the CU with them
+cu_of = {}
+for cu, l in cus.items():
+    for k, a, b, i in l: cu_of[i] = cu
+print("id    kind xcc  K loop  epilogue  end    | co-resident on the CU (kind, start, end)")
+for r in sorted(rows, key=lambda r: -r[2])[:24]:
+    i = r[0]; cu = cu_of[i]
+    others = [(k, round(a, 1), round(b, 1)) for k, a, b, j in cus[cu] if j != i]
+    print("%-5d %-4d %-3d  %6.1f  %6.1f   %6.1f | %s" % (i, r[6], r[4], kloop[i], (r[2] - r[1]) / 100.0 - kloop[i], (r[2] - t_min) / 100.0, others))
+byx = collections.defaultdict(list)
+for r in rows:
+    if r[6] == 0: byx[r[4]].append((r[2] - t_min) / 100.0)
+print("kind-0 end time by XCD (median / max):", {x: (round(sorted(v)[len(v) // 2], 1), round(max(v), 1)) for x, v in sorted(byx.items())})
