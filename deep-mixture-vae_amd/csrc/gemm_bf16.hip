@@ -946,6 +946,12 @@ int gemm_bf16_tile_m(int M, int N, int split) {
         const double score = (double)c[0] * c[1] / (c[0] + c[1]) * (wgs >= 256.0 ? 1.0 : wgs / 256.0);
         if (score > best * 1.0001) { best = score; pick = c[0] * 1000 + c[1]; }
     }
+    // one 128x128 workgroup per CU (no second resident workgroup to overlap its load / multiply / store phases with) loses to two
+    // 128x64 ones: MEASURED on the step at 8192 rows (tools/tile_step.py cfg4 0,0 128,64: 0.6308 -> 0.6226 ms with every launch on
+    // 128x64; the 500-wide layers are the ones this rule moves)
+    // (the same step one size down -- 64x64 instead of a single 128x64 workgroup per CU, the 500-wide layers at 4096 rows -- loses:
+    //  0.2741 -> 0.2819 ms)
+    if (pick == 128128 && (double)(M / 128) * (N / 128) * split <= 256.0 && (double)(M / 128) * (N / 64) * split >= 384.0) pick = 128064;
     return pick;
 }
 
