@@ -67,6 +67,12 @@ def parse():
     ap.add_argument("--latent_dim", type=int, default=64)
     ap.add_argument("--n_clusters", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--mode", default="exact", choices=["exact", "relaxed"], help="exact: the checked-in graph, KL as the expectation over q(c|x) "
+                    "(priors.py:130-145, cluster_sample False); relaxed: the Gumbel-Softmax sample zeta = softmax((logits + g) / tau) "
+                    "(priors.py:170-181) feeding the cluster_sample branch of the KL (priors.py:118-128), Gumbel noise from the device Philox stream")
+    ap.add_argument("--temperature", type=float, default=1.0, help="tau of --mode relaxed")
+    ap.add_argument("--stable-warmup", dest="stable_warmup", type=int, default=8, help="after --warmup steps, run untimed 20-step regions until two "
+                    "consecutive ones agree within 1 %% (the clock ramp: the first region after 5-20 steps reads 3-4 %% slow), at most this many; 0 = off")
     ap.add_argument("--rows", type=int, default=65536, help="synthetic dataset rows resident in HBM")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying a HIP graph")
     ap.add_argument("--deterministic", action="store_true", help="no float atomics (split-K off)")
@@ -269,7 +275,7 @@ def main():
         args.enc_layers = str(enc[0])
     dec = tuple(int(v) for v in args.dec_layers.split(","))
     eng = StepEngine(I, D, K, enc_layers=enc, head_dim=args.head_dim, dec_layers=dec, dtype=args.dtype, max_batch=B,
-                     seed=1234 + rank, deterministic=args.deterministic, cnn=args.cnn)
+                     seed=1234 + rank, deterministic=args.deterministic, cnn=args.cnn, mode=args.mode, temperature=args.temperature)
     eng.init_parameters(0)
     eng.write_state(lr=args.lr)
     ex = make_exchange(4 * eng.param.numel())
@@ -307,7 +313,29 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    regions = []
+    # untimed: the chip's clock (and, N > 1, RCCL's channels) settle over the first few hundred microseconds of back-to-back steps --
+    # region 1 of the round-3 driver line read 3.9 % slow behind 5 warm-up steps.  Run 20-step regions until two in a row agree
+    # within 1 % (every rank takes the same decision: the slowest rank's clock decides), then time.
+    settle = []
+    if args.stable_warmup > 0:
+        prev = None
+        for _ in range(args.stable_warmup):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
+            cur = time.perf_counter() - t0
+            if world > 1:
+                import torch.distributed as dist
+                t = torch.tensor([cur], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                cur = t.item()
+            settle.append(cur / 20)
+            if prev is not None and abs(cur - prev) <= 0.01 * prev:
+                break
+            prev = cur
+    regions, rank_regions = [], []
     for _ in range(max(1, args.repeats)):       # each region: EXACTLY --steps steps between barrier + synchronize
         torch.cuda.synchronize()
         barrier()
@@ -316,6 +344,7 @@ def main():
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
+        mine = time.perf_counter() - t0             # this rank's own finish (before the closing barrier)
         barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
@@ -324,9 +353,29 @@ def main():
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)          # the slowest rank's clock
             el = t.item()
+            lo = torch.tensor([mine], dtype=torch.float64, device=dev)
+            hi = lo.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            rank_regions.append((lo.item(), hi.item()))
         regions.append(el)
     elapsed = sorted(regions)[len(regions) // 2]               # the median region
     st = eng.read_state()
+
+    # N > 1 (or a forced one-rank communicator): what of the exchange is EXPOSED -- the time from the end of the backward pass's last
+    # kernel to the end of the step's last kernel or collective (event pair on the compute stream around everything
+    # _step_with_exchange issues behind the backward pass), averaged over a few eager steps; and the step with a no-op exchange.
+    exch = None
+    if sync is not None and getattr(sync, "enabled", False):
+        exch = eng.measure_exchange(data, perm, sync, ex.grad_scale, steps=10)
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([exch["exposed_us"], exch["step_us"]], dtype=torch.float64, device=dev)
+            tmax, tmin = t.clone(), t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+            exch["exposed_us_max_over_ranks"], exch["exposed_us_min_over_ranks"] = round(tmax[0].item(), 1), round(tmin[0].item(), 1)
+            exch["step_us_max_over_ranks"], exch["step_us_min_over_ranks"] = round(tmax[1].item(), 1), round(tmin[1].item(), 1)
 
     # ---- per-kernel HIP-event timing: eager launches of the same step, event pair around each launch
     rows = []
@@ -352,11 +401,11 @@ def main():
     ms_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
     fpi = flops_per_image(I, D, K, enc, args.head_dim, dec, args.cnn)
-    is_cfg2 = (I, D, K, B, enc, args.head_dim, dec, args.dtype, args.cnn) == (784, 64, 10, 4096, (500, 500), 2000, (2000, 500, 500), "bf16", False)
+    is_cfg2 = (I, D, K, B, enc, args.head_dim, dec, args.dtype, args.cnn, args.mode) == (784, 64, 10, 4096, (500, 500), 2000, (2000, 500, 500), "bf16", False, "exact")
     arch = ("cnn(32,32,p,64,64,p,128,128,p)-" if args.cnn else "") + "%d-%s-(%d|%d)-z%d/K%d-%s-%d" % (I, "-".join(map(str, enc)), args.head_dim, args.head_dim, D, K, "-".join(map(str, dec)), I)
     out = {
         "metric": "images/sec (train), MNIST K=10 z=64 batch=4096/GPU bf16" if is_cfg2
-                  else "images/sec (train), DMVAE %s batch=%d/GPU %s" % (arch, B, args.dtype),
+                  else "images/sec (train), DMVAE %s batch=%d/GPU %s%s" % (arch, B, args.dtype, "" if args.mode == "exact" else " relaxed (Gumbel-Softmax)"),
         "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
@@ -380,6 +429,13 @@ def main():
         "last_loss": round(float(st.last_loss), 4),
     }
     out["repeat_ms_per_step"] = [round(1e3 * r / args.steps, 4) for r in regions]
+    out["settle_ms_per_step"] = [round(1e3 * r, 4) for r in settle]          # the untimed 20-step regions run until two agreed within 1 %
+    out["config"]["mode"] = ("exact (expectation over q(c|x), priors.py:130-145)" if args.mode == "exact" else
+                             "relaxed (Gumbel-Softmax sample, tau = %g, device Philox Gumbel noise; priors.py:118-128,170-181)" % args.temperature)
+    if rank_regions:      # per-rank finish of each timed region before the closing barrier: min / max over ranks, ms per step
+        out["rank_ms_per_step_min_max"] = [[round(1e3 * a / args.steps, 4), round(1e3 * b / args.steps, 4)] for a, b in rank_regions]
+    if exch is not None:
+        out["exchange"] = exch
     out["timing"] = "median of %d regions of %d steps, each bracketed by barrier + synchronize" % (len(regions), args.steps)
     if rows:
         ps = float(args.profile_steps)

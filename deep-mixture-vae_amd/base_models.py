@@ -408,6 +408,13 @@ class DeepMixtureVAE(VAE):
         self._replay = None        # the step graph was captured for the main optimizer's state; recapture after pretraining
         return loss
 
+    def _sync_master(self, sess):
+        """COLLECTIVE under data parallelism (every rank calls it at the same point): bring the fp32 master weights up to date on
+        every rank after sharded bf16 steps, before anything reads or rewrites the whole fp32 arena (StepEngine.sync_master)."""
+        if sess is not None and sess.world_size > 1:
+            from dmvae_hip import make_exchange
+            self._engine.sync_master(make_exchange(4 * self._engine.param.numel()))
+
     def pretrain_vae(self, session, data, n_epochs):
         """base_models.py:322-350."""
         sess = session or self._session
@@ -420,6 +427,7 @@ class DeepMixtureVAE(VAE):
             if loss <= min_loss:
                 min_loss = loss
                 self._save("vae")
+        self._sync_master(sess)       # the next stage sets parameters / runs the replicated Adam over the whole fp32 arena
         return min_loss
 
     def pretrain_prior(self, session, data, n_epochs):

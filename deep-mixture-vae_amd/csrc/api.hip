@@ -190,11 +190,14 @@ struct dmvae_plan {
     int dw_macro_tiles = 0;           // 256x256 tiles of those layers (per K slice)
     bool fused_update = false;        // set for the duration of dmvae_plan_train_step on a bf16 plan
     bool staged = false;              // dmvae_plan_forward_backward_stage: every segment launches its own dW group
+    int stage_groups = 3;             // ... or (2) segments 0 and 1 share one: dmvae_plan_set_stage_groups
     // dmvae_plan_load_batch_step: the batch was assembled for a step that follows at once -- no f32 copy of it exists; the output
     // layer's reconstruction epilogue reads its targets from the dataset through the same permutation (bf16 plans whose output
     // layer runs on the small-tile kernel, input_dim a multiple of 4)
     struct { const float* data; int64_t n_rows; const int32_t* perm; int64_t first; int n_valid; const void* st; } tsrc{};
     bool tsrc_valid = false;          // cleared by dmvae_plan_load_batch (which writes the f32 copy)
+    bool tsrc_used = false;           // a forward pass has consumed that batch: the device cursor has moved on (step_finalize), so a second
+                                      // pass without a reload would pair the old bf16 batch with the NEXT batch's targets -- refused
     bool tgt_gather = false;          // the plan is eligible
     bool vade = false;                // cfg.model == DMVAE_MODEL_VADE: no head hidden layers, no logits; latent mode 2
     // bias gradients of the macro-tile path: the GEMM that PRODUCES a dY (256x256 kernel, ReLU-gate / recon epilogue) leaves
@@ -492,6 +495,7 @@ extern "C" int dmvae_plan_load_batch_step(dmvae_plan* p, void* stream, const flo
     p->tsrc.data = data; p->tsrc.n_rows = n_rows; p->tsrc.perm = perm; p->tsrc.first = first; p->tsrc.n_valid = n_valid;
     p->tsrc.st = use_state_cursor ? p->buf.state : nullptr;
     p->tsrc_valid = true;
+    p->tsrc_used = false;
     return gather_launch((hipStream_t)stream, DMVAE_BF16, data, n_rows, p->cfg.input_dim, perm, first, p->cfg.max_batch, n_valid, p->Bp,
                          WS(p, p->o_x), p->Ip, nullptr, p->Ip, p->Ip, use_state_cursor ? p->buf.state : nullptr);
 }
@@ -725,6 +729,7 @@ static int grad_dense(dmvae_plan* p, hipStream_t s, const void* X, int64_t ldx, 
 static int flush_dw(dmvae_plan* p, hipStream_t s, int group) {
     if (p->dw_queue.empty()) return 0;
     if (!p->staged && group != 2) return 0;
+    if (p->staged && p->stage_groups == 2 && group == 0) return 0;      // two launches: segment 0's problems go out with segment 1's
     return launch_dw_queue(p, s, group == 2);
 }
 
@@ -734,13 +739,21 @@ static int launch_dw_queue(dmvae_plan* p, hipStream_t target, bool with_prior) {
     int rc;
     if (p->dw_slices_now > 1) {    // K slices into slabs, then their fixed-order sum: inside the Adam kernel (fused step) or into the gradient arena
         const float* slab = reinterpret_cast<const float*>(WS(p, p->o_dwslab));
-        int64_t lo = p->param_elems, hi = 0;
+        // the group's WEIGHT range and its BIAS range (the biases live in the arena tail, behind every weight matrix): kept apart,
+        // because under the staged backward the span between them belongs to other segments -- buckets whose collective may
+        // already be in flight (earlier segments) or whose gradients are not written yet (later ones)
+        int64_t wlo = p->param_elems, whi = 0, blo = p->param_elems, bhi = 0;
         for (auto& a : p->dw_queue) {
             const int64_t w0 = reinterpret_cast<const float*>(a.epi.out) - slab;
-            lo = std::min(lo, w0);
-            hi = std::max(hi, w0 + (int64_t)a.M * a.epi.ldo);
-            if (a.epi.out2) hi = std::max(hi, (reinterpret_cast<const float*>(a.epi.out2) - slab) + (int64_t)a.N);
+            wlo = std::min(wlo, w0);
+            whi = std::max(whi, w0 + (int64_t)a.M * a.epi.ldo);
+            if (a.epi.out2) {
+                const int64_t b0 = reinterpret_cast<const float*>(a.epi.out2) - slab;
+                blo = std::min(blo, b0);
+                bhi = std::max(bhi, b0 + (int64_t)a.N);
+            }
         }
+        const int64_t lo = std::min(wlo, blo), hi = std::max(whi, bhi);
         rc = gemm_bf16_grouped_dw(target, p->dw_queue.data(), (int)p->dw_queue.size());
         p->dw_queue.clear();
         if (rc) return rc;
@@ -756,7 +769,13 @@ static int launch_dw_queue(dmvae_plan* p, hipStream_t target, bool with_prior) {
             // [hi, param_elems): the prior tables (gradient complete in the arena, written by step_finalize) and the arena's zero tail
             return adam_slabs_launch(target, a, slab, p->dw_slices_now, p->param_elems, hi, p->param_elems);
         }
-        return slab_reduce_launch(target, slab + lo, hi - lo, p->dw_slices_now, p->param_elems, p->buf.grad + lo);
+        if (!p->staged || bhi <= blo || blo <= whi)       // whole pass: every layer is in this group, the span between is only the tail's alignment pad (zeros)
+            return slab_reduce_launch(target, slab + lo, hi - lo, p->dw_slices_now, p->param_elems, p->buf.grad + lo);
+        // staged (data parallel): this segment's weights and this segment's biases, nothing in between (one reduce over
+        // [lo, hi) rewrote the weight gradients of EARLIER segments -- whose reduce-scatter / all-reduce was already running -- with
+        // local sums, and wrote stale slab values over biases that later segments had yet to produce)
+        TRY(slab_reduce_launch(target, slab + wlo, whi - wlo, p->dw_slices_now, p->param_elems, p->buf.grad + wlo));
+        return slab_reduce_launch(target, slab + blo, bhi - blo, p->dw_slices_now, p->param_elems, p->buf.grad + blo);
     }
     if (p->fused_update) {    // dmvae_plan_train_step: the Adam update rides in the epilogue of this launch
         dmvae_adam_ctx c;
@@ -880,6 +899,9 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
             e.aux0 = p->tsrc.data; e.ld0 = c.input_dim; e.aux1 = p->tsrc.perm; e.ld1 = p->tsrc.first;
             e.aux2 = p->tsrc.st; e.d_off = c.max_batch; e.ld2 = p->tsrc.n_rows;
             DMVAE_REQUIRE(p->tsrc.n_valid == n_valid, "dmvae_plan_forward_backward: n_valid=%d, but dmvae_plan_load_batch_step assembled %d rows", n_valid, p->tsrc.n_valid);
+            DMVAE_REQUIRE(!p->tsrc_used, "dmvae_plan_forward_backward: the batch assembled by dmvae_plan_load_batch_step has been consumed by an earlier pass "
+                                         "(it has no f32 copy and the batch cursor has advanced): load the batch again, or use dmvae_plan_load_batch");
+            p->tsrc_used = true;
         }
         if (dt == DMVAE_BF16 && p->o_cs_dl >= 0 && gemm_bf16_256_ok(DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_RECON, p->Bp, p->Ip, Kd, false)) {
             GemmArgs a;      // the macro-tile kernel also leaves dLoss/dlogits' column sums = the output bias gradient
@@ -978,6 +1000,11 @@ extern "C" int dmvae_plan_forward_backward_stage(dmvae_plan* p, void* stream, in
                                                  const float* gumbel, int64_t ld_gumbel, float inv_B) {
     DMVAE_REQUIRE(stage >= 0 && stage <= 2, "dmvae_plan_forward_backward_stage: stage %d (0, 1, 2)", stage);
     return forward_backward_impl(p, stream, n_valid, eps, ld_eps, gumbel, ld_gumbel, inv_B, stage);
+}
+extern "C" int dmvae_plan_set_stage_groups(dmvae_plan* p, int n_groups) {
+    DMVAE_REQUIRE(p && (n_groups == 2 || n_groups == 3), "dmvae_plan_set_stage_groups: 2 or 3 weight-gradient launches per staged backward");
+    p->stage_groups = n_groups;
+    return 0;
 }
 extern "C" int dmvae_plan_grad_buckets(const dmvae_plan* p, int64_t bounds[5]) {
     DMVAE_REQUIRE(p && bounds, "dmvae_plan_grad_buckets: null pointer");

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DMVAE_HIP_LIB: another build of the SAME library (e.g. a measurement variant from tools/ablate.sh)
 LIB_PATH = os.environ.get("DMVAE_HIP_LIB") or os.path.join(_HERE, "libdmvae_hip.so")
 
-ABI_VERSION = 2          # DMVAE_ABI_VERSION of include/dmvae_hip.h
+ABI_VERSION = 3          # DMVAE_ABI_VERSION of include/dmvae_hip.h
 F32, BF16 = 0, 1
 ADAM_ZERO_GRAD, ADAM_IEEE = 1, 2
 GEMM_FWD, GEMM_DX, GEMM_DW = 0, 1, 2
@@ -28,7 +28,7 @@ MODEL_DMVAE, MODEL_VADE = 0, 1
 
 EXPORTS = [
     "dmvae_gemm", "dmvae_gemm_partials", "dmvae_gemm_grouped_dw", "dmvae_gemm_grouped", "dmvae_gemm_grouped_dw_adam", "dmvae_plan_train_step", "dmvae_latent_ws_bytes", "dmvae_latent_nblocks_vade",
-    "dmvae_plan_forward_backward_stage", "dmvae_plan_grad_buckets", "dmvae_plan_update_range",
+    "dmvae_plan_forward_backward_stage", "dmvae_plan_grad_buckets", "dmvae_plan_set_stage_groups", "dmvae_plan_update_range",
 "dmvae_latent_nblocks", "dmvae_latent_fwd",
     "dmvae_recon_fwd_bwd", "dmvae_recon_nblocks", "dmvae_colsum", "dmvae_loss_finalize",
     "dmvae_adam_tf", "dmvae_adam_finish", "dmvae_gather_rows", "dmvae_philox_normal",
@@ -150,6 +150,7 @@ def _load():
         "dmvae_plan_train_step": [vp, vp, i32, vp, i64, vp, i64, f32],
         "dmvae_plan_forward_backward_stage": [vp, vp, i32, i32, vp, i64, vp, i64, f32],
         "dmvae_plan_grad_buckets": [vp, P(i64)],
+        "dmvae_plan_set_stage_groups": [vp, i32],
         "dmvae_plan_update_range": [vp, vp, f32, i64, i64],
         "dmvae_latent_nblocks": [i32, i32, i32],
         "dmvae_latent_nblocks_vade": [i32],

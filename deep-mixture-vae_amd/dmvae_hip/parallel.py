@@ -23,11 +23,15 @@ HBM.  Two forms (make_exchange picks; DMVAE_DP_MODE=sharded|allreduce overrides)
              Adam): the bit-simplest form, kept as the reference the sharded form is
              tested against (identical bits on the owned slice).
 
-Both come bucketed (three segments of the backward pass, each collective started
-right behind its segment) or as one collective after the whole backward; the
-bucketed form pays three smaller dW grids + host hand-overs per step, so it is
-chosen only when the arena is large enough for the wire time to matter
-(>= 64 MiB, i.e. the 4096-wide configuration; DMVAE_DP_OVERLAP=0|1 overrides).
+Both come bucketed (segments of the backward pass, each collective started right
+behind its segment) or as one collective after the whole backward.  Three buckets
+(a collective behind each of decoder / heads / trunk) pay three smaller dW grids +
+host hand-overs per step: chosen from 64 MiB (the 4096-wide configuration).  Two
+buckets (decoder + heads behind segment 1 as ONE weight-gradient launch, the trunk
+behind segment 2) pay one grid more than the single-process step: the MNIST-sized
+arenas (19-24 MB), where one exposed reduce-scatter / all-gather pair is ~15 % of
+the step at 8 ranks.  Below 8 MiB: one pair after the backward.
+DMVAE_DP_OVERLAP=0|1 and DMVAE_DP_BUCKETS=2|3 override (make_exchange).
 """
 import os
 
@@ -101,6 +105,7 @@ class GradExchange:
     # arena) is exposed.  DMVAE_DP_OVERLAP=0 falls back to the single all-reduce.
     sharded = False
     _overlap = None           # make_exchange sets it from the arena size; None = the environment switch alone
+    n_buckets = 3             # overlapped form: 3 = a collective behind every backward segment; 2 = decoder + heads behind segment 1, trunk behind 2
 
     @property
     def overlap(self):
@@ -174,7 +179,7 @@ class ShardedExchange(GradExchange):
     # skips its local copy).  _in_place asserts exactly that aliasing, so no other overlap of input and output can be
     # passed by accident.  Covered by: gloo at world 2 / 4 / 8 (CPU; gloo copies), two processes on the real kernels, a
     # one-rank RCCL communicator (identity).  NOT yet covered: a multi-rank RCCL run (gpurun gives one GPU) -- the
-    # bench line says so (`multi_rank_rccl_verified: false`); DMVAE_DP_MODE=allreduce is the conventional fallback.
+    # bench line says so (`multi_rank_rccl_verified_before_this_run: false`); DMVAE_DP_MODE=allreduce is the conventional fallback.
     def _in_place(self, flat, lo, hi):
         slo, shi = self.owned(lo, hi)
         whole, mine = flat[lo:hi], flat[slo:shi]
@@ -202,5 +207,14 @@ def make_exchange(param_bytes=0, group=None):
     mode = os.environ.get("DMVAE_DP_MODE", "sharded")
     ex = ShardedExchange(group) if mode == "sharded" else GradExchange(group)
     ov = os.environ.get("DMVAE_DP_OVERLAP")
-    ex._overlap = (param_bytes >= 64 * 2 ** 20) if ov is None else ov != "0"
+    ex._overlap = (param_bytes >= OVERLAP_MIN_BYTES) if ov is None else ov != "0"
+    nb = os.environ.get("DMVAE_DP_BUCKETS")
+    ex.n_buckets = int(nb) if nb in ("2", "3") else (3 if param_bytes >= 64 * 2 ** 20 else 2)
     return ex
+
+
+# Arena size from which the exchange is cut into buckets that overlap the backward pass.  >= 64 MiB (the 4096-wide stack: 702 MB):
+# three buckets, the exchange must hide.  MNIST-sized arenas (19-24 MB): TWO buckets -- one weight-gradient launch more than the
+# single-process step instead of two more; measured with a one-rank RCCL communicator it costs less than the
+# wire time it takes off the critical path at 8 ranks.  Below 8 MiB a collective is latency, not bytes: one pair after the backward.
+OVERLAP_MIN_BYTES = 8 * 2 ** 20

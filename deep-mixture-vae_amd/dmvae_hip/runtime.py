@@ -204,13 +204,25 @@ class StepEngine:
     def _to_host(self, view, name):
         return view.detach().cpu().numpy().copy()
 
+    def _require_current_master(self, what):
+        """Sharded bf16 data-parallel steps (ShardedExchange) keep a rank's fp32 master weights -- and its Adam moments --
+        current on its OWNED slice only; the rest of the fp32 arena is stale until sync_master() (a collective) has run.
+        Everything that reads or updates the whole fp32 arena refuses to run on stale data instead of returning it."""
+        if getattr(self, "_master_stale", False):
+            raise RuntimeError("%s: the fp32 master weights are stale outside this rank's slice after sharded data-parallel steps; "
+                               "call StepEngine.sync_master(exchange) on EVERY rank first (it is a collective)" % what)
+
     def get_parameters(self):
+        self._require_current_master("get_parameters")
         return {k: self._to_host(self.param_view(k), k) for k in self.tensors}
 
     def get_gradients(self):
         return {k: self._to_host(self.grad_view(k), k) for k in self.tensors}
 
     def set_parameters(self, params):
+        if set(self.tensors) <= set(params):          # every tensor is overwritten: nothing stale survives
+            self._master_stale = False
+        self._require_current_master("set_parameters (it re-derives the whole bf16 shadow from the fp32 arena)")
         for k, v in params.items():
             dst = self.param_view(k)
             dst.copy_(torch.as_tensor(np.asarray(v, dtype=np.float32)).to(self.device).reshape(dst.shape))
@@ -252,6 +264,7 @@ class StepEngine:
         self.write_state(adam_t=0, noise_step=0, kl_ratio=st.kl_ratio, lr=st.lr)
 
     def refresh_shadow(self):
+        self._require_current_master("refresh_shadow")
         if self.param_bf16 is not None:
             check(lib.dmvae_cast_f32_to_bf16(self._stream(), ptr(self.param), ptr(self.param_bf16),
                                              self.param.numel()), "dmvae_cast_f32_to_bf16")
@@ -335,8 +348,27 @@ class StepEngine:
         check(lib.dmvae_plan_grad_buckets(self._plan, b), "dmvae_plan_grad_buckets")
         return [(b[2], b[3]), (b[1], b[2]), (b[0], b[1])], (b[3], b[4])
 
+    def set_stage_groups(self, n):
+        """2: segments 0 and 1 of the staged backward share ONE weight-gradient launch (decoder + heads complete after segment 1);
+        3: one launch per segment (dmvae_plan_set_stage_groups)."""
+        check(lib.dmvae_plan_set_stage_groups(self._plan, int(n)), "dmvae_plan_set_stage_groups")
+
     def update_range(self, lo, hi, grad_scale=1.0):
         check(lib.dmvae_plan_update_range(self._plan, self._stream(), float(grad_scale), int(lo), int(hi)), "dmvae_plan_update_range")
+
+    def _stage_groups(self, grad_sync, buckets):
+        """The overlapped exchange's grouping of the three backward segments: 3 buckets = a collective behind every segment; 2 buckets
+        (grad_sync.n_buckets, parallel.make_exchange) = decoder + heads behind segment 1 as ONE bucket (one weight-gradient launch
+        for both, dmvae_plan_set_stage_groups), the trunk behind segment 2.  Returns (segments per group, weight bucket per group)."""
+        nb = int(getattr(grad_sync, "n_buckets", 3) or 3)
+        if getattr(self, "_stage_groups_set", None) != nb:
+            self.set_stage_groups(2 if nb == 2 else 3)
+            self._stage_groups_set = nb
+        if nb == 2:
+            (lo0, hi0), (lo1, hi1), trunk = buckets
+            assert hi1 == lo0          # heads lie right below the decoder in the arena
+            return [(0, 1), (2,)], [(lo1, hi0), trunk]
+        return [(0,), (1,), (2,)], list(buckets)
 
     def _step_with_exchange(self, grad_sync, grad_scale, n_valid=None, eps=None, gumbel=None, inv_B=None):
         """forward + backward + gradient exchange + Adam.  Bucketed and overlapped when the exchange says so
@@ -351,19 +383,25 @@ class StepEngine:
         tables: read in fp32 by the epilogues and the latent kernel, 0.3 % of the arena) is all-reduced whole and updated on
         every rank, so the replicas agree in every bit the step reads.  Else: all-reduce + replicated Adam."""
         buckets, (tlo, thi) = self.grad_buckets()
+        ev = getattr(self, "_exch_events", None)        # measure_exchange: (backward's last kernel enqueued, step's last work enqueued)
+        mark = (lambda: ev[0].record(torch.cuda.current_stream(self.device))) if ev else (lambda: None)
         if getattr(grad_sync, "sharded", False):
             gather = self.param_bf16 if self.param_bf16 is not None else self.param      # what the all-gather carries
             # the sharded part ends at a multiple of 64 * world (tail_off is a multiple of 4096: the same thing for every world
             # that divides 64); whatever lies between is exchanged with the tail
             tlo = tlo // grad_sync.align * grad_sync.align
             if grad_sync.overlap:
+                groups, buckets = self._stage_groups(grad_sync, buckets)
                 wb = grad_sync.bucket_bounds(buckets, tlo)
-                assert len(wb) == 3          # one per segment; None = emptied by the rounding (its elements ride in a later bucket)
+                assert len(wb) == len(groups)          # one per group of segments; None = emptied by the rounding (its elements ride in a later bucket)
                 handles = []
-                for stage in range(3):
-                    self.forward_backward_stage(stage, n_valid, eps, gumbel, inv_B)
-                    if wb[stage] is not None:
-                        lo, hi = wb[stage]
+                for gi, stages in enumerate(groups):
+                    for stage in stages:
+                        self.forward_backward_stage(stage, n_valid, eps, gumbel, inv_B)
+                    if gi + 1 == len(groups):
+                        mark()
+                    if wb[gi] is not None:
+                        lo, hi = wb[gi]
                         handles.append(grad_sync.reduce_scatter(self.grad, lo, hi, async_op=True))
                 th = grad_sync.start(self.grad[tlo:thi])
                 wb = [b for b in wb if b is not None]
@@ -379,6 +417,7 @@ class StepEngine:
                 self._shard_ranges = wb
             else:
                 self.forward_backward(n_valid, eps, gumbel, inv_B)
+                mark()
                 grad_sync.reduce_scatter(self.grad, 0, tlo)
                 grad_sync(self.grad[tlo:thi])
                 slo, shi = grad_sync.owned(0, tlo)
@@ -389,9 +428,13 @@ class StepEngine:
             self._master_stale = self.param_bf16 is not None and grad_sync.world > 1
             return
         if getattr(grad_sync, "overlap", False):
+            groups, buckets = self._stage_groups(grad_sync, buckets)
             handles = []
-            for stage, (lo, hi) in enumerate(buckets):
-                self.forward_backward_stage(stage, n_valid, eps, gumbel, inv_B)
+            for gi, (stages, (lo, hi)) in enumerate(zip(groups, buckets)):
+                for stage in stages:
+                    self.forward_backward_stage(stage, n_valid, eps, gumbel, inv_B)
+                if gi + 1 == len(groups):
+                    mark()
                 handles.append(grad_sync.start(self.grad[lo:hi]))
             handles.append(grad_sync.start(self.grad[tlo:thi]))
             for h, (lo, hi) in zip(handles, buckets + [(tlo, thi)]):
@@ -399,13 +442,42 @@ class StepEngine:
                 self.update_range(lo, hi, grad_scale)
         else:
             self.forward_backward(n_valid, eps, gumbel, inv_B)
+            mark()
             grad_sync(self.grad)
             self.update(grad_scale)
+
+    def measure_exchange(self, data, perm, grad_sync, grad_scale, steps=10):
+        """What of a data-parallel step lies BEHIND its backward pass: `steps` eager steps, each with an event recorded on the compute
+        stream right behind the backward pass's last kernel and one behind the step's last enqueue (by then the compute stream has
+        waited for every collective).  exposed_us = that tail: the collectives that no backward segment covers, plus the Adam
+        launches; step_us = the whole step (event pair around it).  A measurement aid for bench.py --gpus N (the first multi-rank
+        run should explain itself); the training state advances by `steps` steps."""
+        s = torch.cuda.current_stream(self.device)
+        e_b = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        e_0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        e_1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        for i in range(steps):
+            e_0[i].record(s)
+            self._exch_events = (e_b[i],)
+            try:
+                self.train_step(data, perm, None, None, None, 0, True, grad_sync, grad_scale)
+            finally:
+                self._exch_events = None
+            e_1[i].record(s)
+        torch.cuda.synchronize(self.device)
+        tail = sorted(e_b[i].elapsed_time(e_1[i]) for i in range(steps))
+        whole = sorted(e_0[i].elapsed_time(e_1[i]) for i in range(steps))
+        return {"exposed_us": round(1e3 * tail[steps // 2], 1), "step_us": round(1e3 * whole[steps // 2], 1), "steps": steps,
+                "what": "median over eager steps: exposed_us = end of the backward pass's last kernel -> end of the step (collectives not covered "
+                        "by a backward segment + Adam launches); step_us = the whole eager step"}
 
     def sync_master(self, grad_sync):
         """COLLECTIVE (every rank calls it): after sharded bf16 steps a rank's fp32 weights are current on its owned slice only;
         this all-gathers the fp32 master weights (in place) so that get_parameters / a checkpoint see the trained model.  A
-        no-op when nothing is stale."""
+        no-op when nothing is stale.  get_parameters / state_dict / update / forward_backward_update RAISE while the master is
+        stale (_require_current_master).  The Adam moments m, v stay sharded: a rank only ever holds its own slice's, so
+        checkpoints are WEIGHTS ONLY (as the reference's Saver(TRAINABLE_VARIABLES), train.py:233-236) and a resumed job
+        starts a fresh optimizer -- also under another world size or exchange mode."""
         if getattr(self, "_master_stale", False) and getattr(grad_sync, "sharded", False):
             for lo, hi in self._shard_ranges:          # the ranges the steps cut into owned slices (one per bucket when overlapped)
                 grad_sync.all_gather(self.param, lo, hi)
@@ -413,11 +485,13 @@ class StepEngine:
         self._master_stale = False
 
     def update(self, grad_scale=1.0):
+        self._require_current_master("update (replicated Adam over the whole arena)")
         check(lib.dmvae_plan_update(self._plan, self._stream(), float(grad_scale)), "dmvae_plan_update")
 
     def forward_backward_update(self, n_valid=None, eps=None, gumbel=None, inv_B=None):
         """forward + loss + backward + Adam with the update fused into the dW launch
         (dmvae_plan_train_step): single-process training, the gradient arena is not written."""
+        self._require_current_master("forward_backward_update (fused Adam over the whole arena)")
         n_valid = self.max_batch if n_valid is None else int(n_valid)
         if eps is not None:
             assert eps.dtype == torch.float32 and eps.is_contiguous() and eps.shape == (n_valid, self.latent_dim)

@@ -182,10 +182,21 @@ def main(argv):
             loss = model.train_op(sess, train_data, anneal_term)
             accTrain = model.get_accuracy(sess, train_data)
             accTest = model.get_accuracy(sess, test_data)
-            if accTest > maxAcc:
-                maxAcc = accTest
-                if world > 1:      # (every rank scores the same test set with the same weights, so every rank is here) sharded bf16
-                    from dmvae_hip import make_exchange          # steps leave a rank's fp32 weights current on its own slice only
+            improved = accTest > maxAcc
+            if world > 1:
+                # the branch below holds a COLLECTIVE (sync_master): rank 0 decides and every rank follows.  Each rank scores the same
+                # test set with the same weights, but an accuracy may still differ by a sample between ranks (VaDE's k noise draws from
+                # the process-global NumPy RNG; a last-bit difference in a logit) -- ranks deciding for themselves could then split
+                # at the all-gather and hang the job
+                import torch
+                import torch.distributed as dist
+                flag = torch.tensor([1 if improved else 0], dtype=torch.int32, device=model.engine.device if dist.get_backend() == "nccl" else "cpu")
+                dist.broadcast(flag, src=0)
+                improved = bool(int(flag.item()))
+            if improved:
+                maxAcc = max(maxAcc, accTest)
+                if world > 1:      # sharded bf16 steps leave a rank's fp32 weights current on its own slice only
+                    from dmvae_hip import make_exchange
                     model.engine.sync_master(make_exchange(4 * model.engine.param.numel()))
                 if rank == 0:
                     with open(ckpt_path + ".tmp", "wb") as f:

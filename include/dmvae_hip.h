@@ -32,7 +32,8 @@ extern "C" {
 /* 2: dmvae_buffers.arena_elems, dmvae_config.model, dmvae_latent_args.mfma_ws(_bytes), dmvae_config.adam_ieee and
  *    dmvae_prof_row.kernel_ms were added after version 1; a client compiled against an older header passes shorter
  *    structs, so every binding checks dmvae_abi_version() == DMVAE_ABI_VERSION when it loads the library. */
-#define DMVAE_ABI_VERSION 2
+/* 3: dmvae_plan_set_stage_groups added (no struct changed). */
+#define DMVAE_ABI_VERSION 3
 
 enum { DMVAE_F32 = 0, DMVAE_BF16 = 1 };
 
@@ -355,6 +356,13 @@ int dmvae_plan_forward_backward_stage(dmvae_plan* p, void* stream, int stage, in
                                       const float* eps, int64_t ld_eps, const float* gumbel, int64_t ld_gumbel,
                                       float inv_B);
 int dmvae_plan_grad_buckets(const dmvae_plan* p, int64_t bounds[5]);
+/* How many weight-gradient launches the staged backward issues: 3 (default) = one per segment, as above; 2 = segment 0's
+ * weight-gradient problems stay queued and go out with segment 1's in ONE grouped launch, so that [bounds[1], bounds[3])
+ * -- decoder + heads, 86 % of the weights of the MNIST-shaped stacks -- is complete when segment 1 has run and its
+ * collective can overlap segment 2 (the trunk), at the price of two weight-gradient grids per step instead of three
+ * (MNIST-sized arenas: three small grids fill the chip worse than they hide wire time).
+ * Results stay bit-identical to dmvae_plan_forward_backward. */
+int dmvae_plan_set_stage_groups(dmvae_plan* p, int n_groups);
 /* Adam (+ bf16 shadow refresh); grad_scale = 1/world_size.  The loss finalize at the end of
  * dmvae_plan_forward_backward has already advanced state->adam_t for this step: every
  * forward_backward is to be followed by exactly one update. */

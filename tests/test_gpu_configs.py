@@ -348,3 +348,154 @@ def test_bf16_plan_with_ieee_adam_matches_the_fp32_arithmetic():
     assert torch.equal(res[(False, True)][1], res[(True, True)][1]) and torch.equal(res[(False, True)][2], res[(True, True)][2])      # m, v: same arithmetic
     d = (res[(False, True)][0] - res[(True, True)][0]).abs().max().item()
     assert 0 < d <= 1.5e-8, d          # the quotients differ by ~1 ulp of a step <= lr = 2e-3; in p - quotient that is at most one ulp of p (|p| < 0.125: 2^-27)
+
+
+# ---------------------------------------------------------------- full-size INDEPENDENT gradient parity
+# The property tests above compare the full-size paths with themselves (fused == unfused, staged == whole, graph == eager) and only
+# the loss with the fp32 engine.  Below, at the batch sizes where the tile planner, the XCD runs, the K slices of the dW group, the
+# macro-tile slices with their bias-only strips and adam_slabs ARE the product path, every gradient tensor and the parameters after
+# a step are compared with something that shares none of that code: the fp32 engine (f32 MFMA kernels, unsliced, stand-alone IEEE
+# Adam), the float64 oracle, and the same batch run as independent shards.
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4"])
+def test_full_size_bf16_gradients_and_update_track_the_fp32_engine(name):
+    """code/base_models.py:110 (tf.gradients of every trainable) + :102-110 (Adam), at 4096 / 16384 / 8192 rows.
+    (i) every gradient tensor of the bf16 backward (cfg3: dW in four K slices on the macro tile + bias-only strips + slab_reduce)
+        against the fp32 engine on the same batch and noise: Frobenius error <= 8e-2 per tensor (measured 2e-3 .. 4e-2);
+    (ii) the parameters after ONE fused bf16 step (cfg3: adam_slabs) against fp32 engine + IEEE Adam.  Step 1 of TF-Adam moves a
+        parameter by -lr g / (|g| + eps'), i.e. by +-lr wherever |g| >> 3e-7: the two runs agree to rounding where the bf16 and the
+        fp32 gradient have the same sign and differ by 2 lr where a gradient within bf16 error of zero changes sign.  Stated bound:
+        no element differs by more than 2 lr (1 + 1e-3), at most 6 % differ by more than lr / 10 (measured <= 3 %), and the pad
+        elements (zero gradient) do not move at all."""
+    kw, B, lr = FULL[name]
+    g = torch.Generator(device="cuda"); g.manual_seed(31)
+    X = torch.rand((B, 784), device="cuda", generator=g) * (torch.rand((B, 784), device="cuda", generator=g) < 0.19)
+    eps = torch.randn((B, kw["latent_dim"]), device="cuda", generator=g)
+    res = {}
+    for dt in ("fp32", "bf16"):
+        eng = make(kw, dt, B, seed=4, lr=lr)
+        p0 = eng.param.clone()
+        eng.load_batch(X, None, 0, B)
+        eng.forward_backward(B, eps)
+        torch.cuda.synchronize()
+        grads = {k: eng.grad_view(k).clone() for k in eng.tensors}
+        if dt == "fp32":
+            eng.update(1.0)
+        else:       # the product path: Adam fused into the dW launch (cfg3: slabs + adam_slabs)
+            eng.load_batch(X, None, 0, B)
+            eng.forward_backward_update(B, eps)
+        torch.cuda.synchronize()
+        res[dt] = (grads, eng.param - p0, eng.read_state().last_loss, (p0 == 0))
+        del eng
+        torch.cuda.empty_cache()
+    gf, gb = res["fp32"][0], res["bf16"][0]
+    worst = {}
+    for k in gf:
+        rel = (gb[k] - gf[k]).norm().item() / (gf[k].norm().item() + 1e-30)
+        worst[k] = rel
+        assert rel <= 8e-2, (name, k, rel)
+    assert abs(res["bf16"][2] - res["fp32"][2]) <= 2e-3 * abs(res["fp32"][2])
+    df, db = res["fp32"][1], res["bf16"][1]
+    diff = (db - df).abs()
+    assert diff.max().item() <= 2 * lr * (1 + 1e-3), diff.max().item()
+    frac = (diff > lr / 10).float().mean().item()
+    assert frac <= 0.06, (name, frac)
+    # elements that never receive a gradient (layout pads: zero parameter, zero gradient) stay put in both runs
+    still = (df == 0)
+    assert torch.equal(db[still & res["fp32"][3]], torch.zeros_like(db[still & res["fp32"][3]]))
+    print("%s: worst gradient Frobenius error %.3e (%s); parameters off by > lr/10: %.3f %%" %
+          (name, max(worst.values()), max(worst, key=worst.get), 100 * frac))
+
+
+def test_fp32_engine_at_the_full_cfg2_batch_matches_the_float64_oracle():
+    """The oracle comparisons elsewhere run at B <= 512.  Here: the fp32 engine at the metric's own batch, 4096 x 784 (the grids, supertile
+    heights and XCD runs of the full size), against the float64 oracle: loss <= 1e-3, every activation <= 3e-5, every gradient
+    tensor <= 1e-4 of its max (~0.1 TFLOP of float64 NumPy: seconds on the GPU box's host cores)."""
+    fp32_step_vs_oracle(CFG2, 4096, seed=5)
+
+
+def test_one_65536_row_step_equals_eight_8192_row_shards():
+    """`bench.py --config cfg4-strong` at N = 1: ONE 65 536-row batch on one GPU (dW in K slices on the macro tile, adam_slabs, the
+    MFMA form of the latent stage at 512 row blocks).  The loss terms are batch means of per-row quantities (base_models.py:74-79,
+    priors.py:145,199), so its gradients must equal the SUM of the gradients of the same rows run as eight independent 8192-row
+    shards at inv_B = 1 / 65536 (the data-parallel identity of SURVEY 8e, here as a full-size check of the 65 536-row launch
+    geometry).  Different summation orders over bf16 products: per-tensor Frobenius error <= 2e-3, loss <= 1e-5 relative."""
+    kw = CFG4
+    BIG, SH = 65536, 8192
+    g = torch.Generator(device="cuda"); g.manual_seed(41)
+    X = torch.rand((BIG, 784), device="cuda", generator=g) * (torch.rand((BIG, 784), device="cuda", generator=g) < 0.19)
+    eps = torch.randn((BIG, kw["latent_dim"]), device="cuda", generator=g)
+    big = make(kw, "bf16", BIG, seed=4)
+    big.load_batch(X, None, 0, BIG)
+    big.forward_backward(BIG, eps)
+    torch.cuda.synchronize()
+    gbig = {k: big.grad_view(k).clone() for k in big.tensors}
+    sb = big.read_state()
+    loss_big = (sb.last_loss, sb.last_recon, sb.last_klz, sb.last_klc)
+    del big
+    torch.cuda.empty_cache()
+    small = make(kw, "bf16", SH, seed=4)
+    acc = {k: torch.zeros_like(small.grad_view(k), dtype=torch.float64) for k in small.tensors}
+    loss = np.zeros(4)
+    for j in range(BIG // SH):
+        small.load_batch(X, None, j * SH, SH)
+        small.forward_backward(SH, eps[j * SH:(j + 1) * SH].contiguous(), None, 1.0 / BIG)
+        torch.cuda.synchronize()
+        for k in acc:
+            acc[k] += small.grad_view(k).double()
+        st = small.read_state()
+        loss += np.array([st.last_loss, st.last_recon, st.last_klz, st.last_klc])
+    for a, b in zip(loss_big, loss):
+        assert abs(a - b) <= 1e-5 * abs(b) + 1e-6, (loss_big, loss)
+    for k in acc:
+        rel = (gbig[k].double() - acc[k]).norm().item() / (acc[k].norm().item() + 1e-30)
+        assert rel <= 2e-3, (k, rel)
+
+
+def test_staged_backward_in_k_slices_leaves_earlier_buckets_alone():
+    """with the dW group in K slices (>= 16384 rows per GPU) the staged backward of the data-parallel path summed
+    the slabs over ONE range from the segment's first weight to its last bias -- every bias now lives in the arena tail, so that
+    range covered the weight buckets of EARLIER segments (whose reduce-scatter / all-reduce is already in flight under
+    _step_with_exchange) and the not-yet-written biases of later ones.  Here: cfg3's 16 384 rows, slices forced to 2 (small tiles)
+    and 4 (macro tile + bias-only strips); after every segment its bucket is cloned and then PERTURBED (as an in-place collective
+    would), the untouched tail biases carry a sentinel; later segments must leave all of that exactly as it was, and the
+    gradients must equal the whole (unstaged) backward."""
+    from dmvae_hip import _lib
+    kw, B, lr = FULL["cfg3"]
+    g = torch.Generator(device="cuda"); g.manual_seed(51)
+    X = torch.rand((B, 784), device="cuda", generator=g) * (torch.rand((B, 784), device="cuda", generator=g) < 0.19)
+    eps = torch.randn((B, kw["latent_dim"]), device="cuda", generator=g)
+    for slices in (2, 4):
+        try:
+            _lib.check(_lib.lib.dmvae_debug_set_knob(10, slices))
+            whole = make(kw, "bf16", B, seed=4, lr=lr)
+            whole.load_batch(X, None, 0, B)
+            whole.forward_backward(B, eps)
+            torch.cuda.synchronize()
+            ref = whole.grad.clone()
+            del whole
+            eng = make(kw, "bf16", B, seed=4, lr=lr)
+            buckets, (tlo, thi) = eng.grad_buckets()
+            eng.load_batch(X, None, 0, B)
+            SENT = 12345.0
+            eng.grad[tlo:thi] = SENT
+            bias_of = {0: ["b_dec0", "b_dec1", "b_dec2", "b_out"], 1: ["b_zh", "b_ch", "b_mean", "b_logvar", "b_logits"], 2: ["b_enc0", "b_enc1"]}
+            kept = []
+            for stage in range(3):
+                eng.forward_backward_stage(stage, B, eps)
+                torch.cuda.synchronize()
+                for lo, hi, want in kept:            # earlier buckets: exactly the perturbed values
+                    assert torch.equal(eng.grad[lo:hi], want), (slices, stage, lo, hi)
+                lo, hi = buckets[stage]
+                assert torch.equal(eng.grad[lo:hi], ref[lo:hi]), (slices, stage)
+                for later in range(stage + 1, 3):     # later segments' biases: not written yet
+                    for k in bias_of[later]:
+                        assert bool((eng.grad_view(k) == SENT).all()), (slices, stage, k)
+                for k in bias_of[stage]:
+                    assert torch.equal(eng.grad_view(k), eng._strided(ref, k)), (slices, stage, k)
+                eng.grad[lo:hi] += 1.0                # what an in-flight in-place collective would do to the bucket
+                kept.append((lo, hi, eng.grad[lo:hi].clone()))
+            del eng
+            torch.cuda.empty_cache()
+        finally:
+            _lib.check(_lib.lib.dmvae_debug_set_knob(10, 0))

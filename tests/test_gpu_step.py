@@ -247,6 +247,21 @@ def test_staged_backward_equals_whole_and_buckets_cover_the_arena(dtype):
             assert torch.equal(staged.grad[dlo:dhi], whole.grad[dlo:dhi]), (stage, dlo, dhi)
     assert torch.equal(staged.grad[tlo:thi], whole.grad[tlo:thi])               # the tail is complete behind the last segment
     assert staged.read_state().last_loss == whole.read_state().last_loss
+    # two weight-gradient launches instead of three (dmvae_plan_set_stage_groups(2), the two-bucket exchange): segment 0's problems go
+    # out with segment 1's, so decoder + heads are complete behind segment 1 -- and not a bit differs
+    two = make(kw, dtype, B, seed=2)
+    two.set_stage_groups(2)
+    two.load_batch(Xd, None, 0, B)
+    two.forward_backward_stage(0, B, ed)
+    two.forward_backward_stage(1, B, ed)
+    torch.cuda.synchronize()
+    lo, hi = buckets[1][0], buckets[0][1]
+    assert torch.equal(two.grad[lo:hi], whole.grad[lo:hi])
+    if dtype == "bf16":       # (bf16 queues the problems; the f32 path launches each GEMM where it is issued)
+        assert not torch.equal(two.grad[:lo], whole.grad[:lo])                  # the trunk is still to come
+    two.forward_backward_stage(2, B, ed)
+    torch.cuda.synchronize()
+    assert torch.equal(two.grad, whole.grad)
     whole.update(0.5)
     staged.update(0.5)
     torch.cuda.synchronize()
@@ -326,7 +341,7 @@ def _dp_rank(rank, world, port, overlap, out, mode="allreduce", dtype="fp32"):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      DMVAE_DP_OVERLAP="1" if overlap else "0", DMVAE_DP_MODE=mode)
+                      DMVAE_DP_OVERLAP="1" if overlap else "0", DMVAE_DP_MODE=mode, DMVAE_DP_BUCKETS="2" if overlap == 2 else "3")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import dmvae_oracle as Or
     from dmvae_hip import StepEngine, make_exchange, shard_range
@@ -337,7 +352,7 @@ def _dp_rank(rank, world, port, overlap, out, mode="allreduce", dtype="fp32"):
     eng = StepEngine(dtype=dtype, max_batch=hi - lo, mode="exact", **kw)
     eng.init_parameters(3)
     ex = make_exchange()
-    assert ex.enabled and ex.overlap == overlap and ex.sharded == (mode == "sharded")
+    assert ex.enabled and ex.overlap == bool(overlap) and ex.sharded == (mode == "sharded") and ex.n_buckets == (2 if overlap == 2 else 3)
     Xd = torch.as_tensor(X[lo:hi]).cuda()
     for step in range(2):
         eps = rng.randn(B, 64).astype(np.float32)
@@ -355,7 +370,7 @@ def _dp_rank(rank, world, port, overlap, out, mode="allreduce", dtype="fp32"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("overlap", [True, 2, False])      # three buckets / two buckets (decoder + heads | trunk) / one collective pair
 def test_sharded_exchange_equals_allreduce_bit_for_bit(overlap):
     """reduce-scatter -> Adam on the owned slice -> all-gather leaves, on every rank, exactly the parameters that
     all-reduce + replicated Adam leaves (two ranks: a + b is the same float either way); the Adam moments are
@@ -387,7 +402,7 @@ def test_sharded_exchange_equals_allreduce_bit_for_bit(overlap):
     assert (sh[0][3] != 0).sum() < 0.75 * (ar[0][3] != 0).sum()  # ... and a rank does not maintain the others' moments
 
 
-@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("overlap", [True, 2, False])      # three buckets / two buckets (decoder + heads | trunk) / one collective pair
 def test_sharded_exchange_gathers_the_bf16_shadow(overlap):
     """bf16 plans (VERDICT r2 next #5 iv): reduce-scatter -> Adam on the owned weight slice -> all-gather of the bf16
     SHADOW (2 B per parameter), the tail (biases, prior tables) all-reduced and updated on every rank.  After two steps on two ranks:
@@ -423,7 +438,7 @@ def test_sharded_exchange_gathers_the_bf16_shadow(overlap):
                                                                      # move nearly every real weight; pad elements stay 0 everywhere)
 
 
-@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("overlap", [True, 2, False])      # three buckets / two buckets (decoder + heads | trunk) / one collective pair
 def test_two_ranks_equal_one_rank_to_fp32_roundoff(overlap):
     """N ranks x B/N == 1 rank x B.  Two processes share the GPU (gloo carries the
     all-reduce here; RCCL on the multi-GPU box), each runs the real kernels on its half of the batch
@@ -468,7 +483,7 @@ def _rccl_rank(port, overlap, out, mode="allreduce"):
     if p not in sys.path:
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
-                      DMVAE_DP_FORCE="1", DMVAE_DP_OVERLAP="1" if overlap else "0", DMVAE_DP_MODE=mode)
+                      DMVAE_DP_FORCE="1", DMVAE_DP_OVERLAP="1" if overlap else "0", DMVAE_DP_MODE=mode, DMVAE_DP_BUCKETS="2" if overlap == 2 else "3")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     from dmvae_hip import StepEngine, make_exchange
@@ -477,7 +492,7 @@ def _rccl_rank(port, overlap, out, mode="allreduce"):
     data = torch.rand((4 * B, 784), device="cuda", generator=g)
     perm = torch.randperm(4 * B, device="cuda", generator=g).to(torch.int32)
     ex = make_exchange()
-    assert ex.enabled and ex.world == 1 and ex.overlap == overlap and ex.sharded == (mode == "sharded")
+    assert ex.enabled and ex.world == 1 and ex.overlap == bool(overlap) and ex.sharded == (mode == "sharded")
     res = []
     for sync in (ex, None):
         eng = StepEngine(dtype="bf16", max_batch=B, mode="exact", seed=77, **kw)
@@ -496,7 +511,7 @@ def _rccl_rank(port, overlap, out, mode="allreduce"):
 
 
 @pytest.mark.parametrize("mode", ["sharded", "allreduce"])
-@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("overlap", [True, 2, False])      # three buckets / two buckets (decoder + heads | trunk) / one collective pair
 def test_rccl_exchange_on_one_rank_is_the_identity(overlap, mode):
     """The N > 1 step sequence (staged backward, bucketed asynchronous collectives on RCCL's stream -- reduce-scatter /
     all-gather or all-reduce --, per-bucket Adam) with a one-rank communicator must reproduce the single-process

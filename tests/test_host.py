@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(_lib.lib, name), "libdmvae_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     m = re.search(r"#define DMVAE_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "dmvae_hip.h")).read())
-    assert _lib.lib.dmvae_abi_version() == int(m.group(1)) == _lib.ABI_VERSION == 2
+    assert _lib.lib.dmvae_abi_version() == int(m.group(1)) == _lib.ABI_VERSION == 3
 
 
 def test_ctypes_structs_match_header_layout():
@@ -492,6 +492,13 @@ def test_sharded_layout_of_the_baseline_plans(name, world):
             slo, shi = ex.owned(lo, hi)
             assert (hi - lo) % (64 * world) == 0 and (shi - slo) * world == hi - lo and slo % 4 == 0
             assert slo == lo + rank * (shi - slo)
+        # the TWO-bucket form (MNIST-sized arenas): decoder + heads as one bucket behind segment 1, the trunk behind segment 2
+        raw2 = [(raw[1][0], raw[0][1]), raw[2]]
+        b2 = ex.bucket_bounds(raw2, n)
+        assert len(b2) == 2 and None not in b2 and b2[0][1] == n and b2[1][0] == 0 and b2[0][0] == b2[1][1] and b2[0][0] >= raw2[0][0]
+        for lo, hi in b2:
+            slo, shi = ex.owned(lo, hi)
+            assert (hi - lo) % (64 * world) == 0 and (shi - slo) * world == hi - lo and slo % 4 == 0
     # a tiny model in a huge world: the middle bucket collapses and must come back as None, in place
     ex = ShardedExchange.__new__(ShardedExchange)
     ex.group, ex.enabled, ex.world, ex.rank, ex.align = None, False, 8, 0, 512
@@ -509,6 +516,7 @@ def _sharded_worker_n(rank, world, port, cases, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from dmvae_hip.parallel import make_exchange
     ok = []
+    cases = list(cases) + [(n_real, [(raw[1][0], raw[0][1]), raw[2]]) for n_real, raw in cases[:2]]      # ... and the two-bucket form of the MNIST-sized arenas
     for n_real, raw in cases:
         ex = make_exchange(param_bytes=4 * n_real)
         n = ex.padded(n_real)
@@ -551,3 +559,21 @@ def test_sharded_exchange_world4_world8_gloo(world):
         p.join(120)
         assert p.exitcode == 0
     assert [r[0] for r in res] == list(range(world)) and all(r[1] for r in res), res
+
+
+def test_exchange_policy_by_arena_size(monkeypatch):
+    """make_exchange: one collective pair below 8 MiB (latency-sized), the two-bucket overlapped form for the MNIST-sized arenas
+    (decoder + heads behind segment 1, trunk behind segment 2), three buckets from 64 MiB (the 4096-wide stack); the environment
+    switches override each choice."""
+    from dmvae_hip.parallel import make_exchange
+    for k in ("DMVAE_DP_OVERLAP", "DMVAE_DP_BUCKETS", "DMVAE_DP_MODE"):
+        monkeypatch.delenv(k, raising=False)
+    small, mnist, wide = make_exchange(4 * 2 ** 20), make_exchange(4 * 5955584), make_exchange(4 * 175 * 10 ** 6)
+    assert (small._overlap, mnist._overlap, wide._overlap) == (False, True, True)
+    assert (mnist.n_buckets, wide.n_buckets) == (2, 3) and mnist.sharded and wide.sharded
+    monkeypatch.setenv("DMVAE_DP_BUCKETS", "3")
+    assert make_exchange(4 * 5955584).n_buckets == 3
+    monkeypatch.setenv("DMVAE_DP_OVERLAP", "0")
+    assert make_exchange(4 * 175 * 10 ** 6)._overlap is False
+    monkeypatch.setenv("DMVAE_DP_MODE", "allreduce")
+    assert not make_exchange(4 * 5955584).sharded
