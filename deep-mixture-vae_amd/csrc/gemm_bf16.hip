@@ -914,12 +914,10 @@ int gemm_bf16_grouped_dw_adam(hipStream_t s, const GemmArgs* probs, int nprob, c
 static int g_force_tile = 0;   // debug override (dmvae_debug_set_tile): BM*1000+BN, 0 = heuristic
 void gemm_bf16_force_tile(int t) { g_force_tile = t; }
 static int g_nw8 = 1;          // tuning knob (dmvae_debug_set_knob 1): 8-wave workgroups for the 128-row tiles
-static int g_deep = 0;         // tuning knob (dmvae_debug_set_knob 3): -1 deep ring when <= 1 workgroup/CU, 0 never, 1 always
 void gemm_bf16_set_knob(int which, int v) {
     if (which == 0) g_group_m = v < 0 ? 0 : v;
     if (which == 1) g_nw8 = v;
     if (which == 2) g_grouped_mixed = v;
-    if (which == 3) g_deep = v;
     if (which == 4) g_grouped_cls = v;
     if (which == 5) g_conv_short = v;
     if (which == 6) gemm_bf16_256_set_policy(v);
@@ -1001,16 +999,15 @@ static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split) {
         a.group_m = gemm_auto_group_m(a.M / 64, a.N / 64, 64, 64);
         return launch<64, 64, LAYOUT, EPI, 2>(s, a, split);
     }
-    const long wgs = (long)(a.M / (t / 1000)) * (a.N / (t % 1000)) * split;
-    // one workgroup per CU at most -> a single deep ring (more bytes in flight); else two shallow ones
-    const bool deep = g_deep < 0 ? wgs <= 320 : g_deep == 1;
+    // (A single DEEP ring for launches of at most one workgroup per CU -- 4 x 32 KiB for 128x128, 6 x 24 KiB for 128x64, i.e. one
+    //  workgroup per CU by LDS -- was knob 3 until round 4: 0.2926 vs 0.2860 ms per step at cfg2; the K loop of a 4096x512x512 layer
+    //  took 2.92 vs 2.96 us and its first tile landed 0.5 us later.  Removed with its 18 instantiations, which also could not meet
+    //  the two-workgroups-per-CU register bound of the kernel template.)
     switch (t) {
         case 128128:
-            if (deep) return launch<128, 128, LAYOUT, EPI, 4, 8>(s, a, split);
             return g_nw8 ? launch<128, 128, LAYOUT, EPI, 2, 8>(s, a, split) : launch<128, 128, LAYOUT, EPI, 2>(s, a, split);
         case 128064:
             // (three workgroups per CU on a 2-slot 48 KiB ring: 0.331 vs 0.300 ms/step -- the long-K layers need the third slot)
-            if (deep) return launch<128, 64, LAYOUT, EPI, 6, 8>(s, a, split);
             return g_nw8 ? launch<128, 64, LAYOUT, EPI, 3, 8>(s, a, split) : launch<128, 64, LAYOUT, EPI, 3>(s, a, split);
         case 64128: return launch<64, 128, LAYOUT, EPI, 3>(s, a, split);
         default: return launch<64, 64, LAYOUT, EPI, 4>(s, a, split);

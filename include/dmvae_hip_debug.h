@@ -49,7 +49,8 @@ int dmvae_debug_set_tile(int bm, int bn);
 /* tuning aid: knob 0 = supertile height (tile rows) of the L2-friendly tile order,
  *             knob 1 = 8-wave workgroups for the 128-row tiles (0|1),
  *             knob 2 = per-problem tile shapes in the grouped dW grid (0 = all 64x64, 1 = planned, 2 = largest),
- *             knob 3 = ring depth policy (-1 deep ring when <= 1 workgroup per CU, 0 never, 1 always),
+ *             (knob 3, the deep-ring policy, was removed in round 4 with its instantiations: measured slower, see csrc/gemm_bf16.hip;
+ *              setting it is refused),
  *             knob 4 = XCD runs of a grouped grid cut per tile-shape class (1) or per problem (0),
  *             knob 5 = conv-mode tiles: >= 1 short-K tiles as 4-wave / 2-slot workgroups (three per CU),
  *                      2 also 3-slot rings for the 64x64 weight-gradient tiles,
