@@ -50,19 +50,9 @@
 #include <vector>
 
 #include "gemm_tile.h"
+#include "measure.h"      // MEAS_*: stamps and ablation switches of the measurement builds; all of it empty / false in the product build
 
-__device__ unsigned long long g_mid[2048];           // DMVAE_ABLATE == 6 builds only: end of each workgroup's K loop
-__device__ unsigned long long g_anat[2048 * 8];      // DMVAE_ABLATE == 6: per workgroup {entry, first tile landed, K loop done, epilogue issued, stores acknowledged, HW_ID|XCC} (tools/anatomy.py)
-#if DMVAE_ABLATE == 6
-#define ANAT(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_anat[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define ANAT(i) do { } while (0)
-#endif
-// Measurement-only builds (tools/ablate.sh -> a separately named .so, never the product library):
-// 1 = no MFMA, 2 = no LDS fragment reads, 3 = no global->LDS loads in the K loop, 4 = 1 + 2.
-#ifndef DMVAE_ABLATE
-#define DMVAE_ABLATE 0
-#endif
+MEAS_TABLES_BF16
 
 namespace dmvae {
 
@@ -88,7 +78,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     static_assert(NSTAGE >= 2 && NSTAGE <= 8 && LOADS * (NSTAGE - 1) <= 63, "ring depth / vmcnt range");
     // smem: NSTAGE * STAGE elements, the kernel's ONLY LDS object (owned by the __global__ wrapper)
 
-    ANAT(0);
+    MEAS_ANAT(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -208,40 +198,38 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     auto rd = [&](int slot, int ks, bf16x8 (&af)[TM], bf16x8 (&bfr)[TN]) {
         const bf16_t* As = smem + slot * STAGE;
         const bf16_t* Bs = As + A_ELEMS;
-#if DMVAE_ABLATE == 2 || DMVAE_ABLATE == 4      // tools/ablate.sh: no LDS reads
+        if constexpr (MEAS_NO_LDS_READ) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = ones;
+            for (int i = 0; i < TM; ++i) af[i] = ones;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[j] = ones;
-#else
-        if constexpr (!BONLY) {
+            for (int j = 0; j < TN; ++j) bfr[j] = ones;
+        } else {
+            if constexpr (!BONLY) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = read_frag<A_KC>(As, foA[ks][i][0], foA[ks][i][1]);
+                for (int i = 0; i < TM; ++i) af[i] = read_frag<A_KC>(As, foA[ks][i][0], foA[ks][i][1]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j] = read_frag<B_KC>(Bs, foB[ks][j][0], foB[ks][j][1]);
         }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[j] = read_frag<B_KC>(Bs, foB[ks][j][0], foB[ks][j][1]);
-#endif
     };
     auto mma = [&](const bf16x8 (&af)[TM], const bf16x8 (&bfr)[TN]) {
-#if DMVAE_ABLATE == 1 || DMVAE_ABLATE == 4      // no MFMA (fragments still read)
+        if constexpr (MEAS_NO_MFMA) {      // (fragments still read: kept live)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[i]));
+            for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[i]));
 #pragma unroll
-        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bfr[j]));
-#else
-        // the wave that has its fragments goes first: two waves share a SIMD, the other one is waiting on
-        // LDS or the barrier anyway (measured on the step, tools/ab_libs.sh: 0.3136 -> 0.3110 ms)
-        if constexpr (!BONLY) {
-        __builtin_amdgcn_s_setprio(1);
+            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bfr[j]));
+        } else if constexpr (!BONLY) {
+            // the wave that has its fragments goes first: two waves share a SIMD, the other one is waiting on
+            // LDS or the barrier anyway (measured on the step, tools/ab_libs.sh: 0.3136 -> 0.3110 ms)
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                // operands swapped: D[row = n][col = m] -> each lane owns 4 consecutive n of one m
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+                for (int j = 0; j < TN; ++j)
+                    // operands swapped: D[row = n][col = m] -> each lane owns 4 consecutive n of one m
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
-#endif
         if constexpr (DW) {
             if (do_bias) {
 #pragma unroll
@@ -317,11 +305,8 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
         for (int q = 0; q < NQ; ++q) {
             const int idx = q * (64 * NW) + tid;
             const int ml = idx / (BN / 4), c = idx % (BN / 4);
-#if DMVAE_ABLATE == 8      // (tools/ablate.sh 8: no mask read -- the upper bound of what a 1-bit mask could save)
-            gate[q] = make_uint2(0x3f803f80u, 0x3f803f80u); (void)ml; (void)c;
-#else
-            gate[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.epi.aux0) + (int64_t)(m0 + ml) * a.epi.ld0 + n0 + c * 4);
-#endif
+            if constexpr (MEAS_NO_MASK_READ) gate[q] = make_uint2(0x3f803f80u, 0x3f803f80u);
+            else gate[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.epi.aux0) + (int64_t)(m0 + ml) * a.epi.ld0 + n0 + c * 4);
         }
     }
     // Only real tiles are issued.  (Round 1 clamped tile ids past the K range to the last tile to keep every vmcnt count a
@@ -333,7 +318,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     if (nk >= NSTAGE) wait_vmcnt<LOADS*(NSTAGE - 1)>();        // tile 0 has landed (this wave's share)
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    ANAT(1);
+    MEAS_ANAT(1);
     rd(0, 0, f0a, f0b);
     for (int kt = 0; kt < nk; kt += NSTAGE) {
 #pragma unroll
@@ -345,9 +330,9 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
                 if (kt + s + NSTAGE <= nk) wait_vmcnt<LOADS*(NSTAGE - 2)>();   // tile kt+s+1 has landed (this wave's share)
                 else wait_vmcnt<0>();                                          // K tail: fewer tiles in flight than the constant assumes
                 __builtin_amdgcn_s_barrier();
-#if DMVAE_ABLATE != 3                            // (tools/ablate.sh 3: no global loads in the K loop)
-                if (kt + s + NSTAGE < nk) issue(kt + s + NSTAGE, s);
-#endif
+                if constexpr (!MEAS_NO_KLOOP_LOADS) {
+                    if (kt + s + NSTAGE < nk) issue(kt + s + NSTAGE, s);
+                }
                 if (kt + s + 1 < nk) rd((s + 1) % NSTAGE, 0, f0a, f0b);
                 mma(f1a, f1b);
             }
@@ -355,10 +340,8 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     }
     wait_vmcnt<0>();                                            // (nothing is in flight any more)
     __builtin_amdgcn_s_barrier();
-#if DMVAE_ABLATE == 6     // tools/stamps.py: when the K loop of this workgroup ended
-    if (threadIdx.x == 0 && blockIdx.x < 2048) g_mid[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-#endif
-    ANAT(2);
+    MEAS_KLOOP_END();
+    MEAS_ANAT(2);
 
     // Epilogue through LDS.  The MFMA result map gives a lane 4 consecutive n of ONE row and its 15
     // neighbours 15 OTHER rows: stored straight from the accumulators a wave instruction touches
@@ -381,8 +364,12 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
         if (epi_s.out2) epi_s.out2 = reinterpret_cast<float*>(epi_s.out2) + (int64_t)ys * a.slab_stride2;
     }
     float* ct = reinterpret_cast<float*>(smem);
-#if DMVAE_ABLATE != 5
-    if constexpr (!BONLY) {
+    if constexpr (MEAS_NO_EPILOGUE) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else if constexpr (!BONLY) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -446,12 +433,6 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
         }
     }
     }
-#else
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
-#endif
     if constexpr (DW) {
         if (do_bias && wm == 0 && li == 0) {      // D[row = n][col = any m]: column 0 of the wm == 0 waves writes
             float* db = reinterpret_cast<float*>(epi_s.out2);
@@ -485,13 +466,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
         constexpr int CM = BM / 64, CN = BN / 64;
         if (tid < CM * CN) a.epi.partials[(tm * CM + tid / CN) * (a.N / 64) + tn * CN + tid % CN] = tid == 0 ? t : 0.f;
     }
-#if DMVAE_ABLATE == 6
-    ANAT(3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ANAT(4);
-    if (threadIdx.x == 0 && blockIdx.x < 2048)
-        g_anat[blockIdx.x * 8 + 5] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);
-#endif
+    MEAS_ANAT_DRAIN();
 }
 
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW>
@@ -525,15 +500,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_bf16_conv_kernel(GemmArg
 // grid (the nine dW = X^T dY products of a training step: each alone fills a fraction of the 256
 // CUs, together they keep every CU at two resident workgroups).  Problem i owns the workgroups
 // [start[i], start[i+1]).
-__device__ unsigned long long g_stamps[2048 * 4];   // written by DMVAE_ABLATE == 6 builds only
-void* gemm_bf16_anatomy() {
-    void* p = nullptr;
-    return hipGetSymbolAddress(&p, HIP_SYMBOL(g_anat)) == hipSuccess ? p : nullptr;
-}
-void* gemm_bf16_stamps() {
-    void* p = nullptr;
-    return hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps)) == hipSuccess ? p : nullptr;
-}
+void* gemm_bf16_anatomy() { return MEAS_SYMBOL(g_anat); }      // (nullptr in the product build: no stamp tables, measure.h)
+void* gemm_bf16_stamps() { return MEAS_SYMBOL(g_stamps); }
 struct GroupedArgs {
     int nprob;
     int kind[DMVAE_MAX_GROUP];
@@ -599,9 +567,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_bf16_grouped_ke
         ksl = bid / tiles_i;
         bid -= ksl * tiles_i;
     }
-#if DMVAE_ABLATE == 6     // placement / timeline stamps of every workgroup (tools/stamps.py)
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-#endif
+    MEAS_WG_BEGIN();
     // (a 4-slot ring of K depth 32 in the same 64 KiB was measured for the 128x128 dW tiles: no gain)
     if constexpr (SHORTK) {
         gemm_bf16_body<64, 64, LAYOUT, EPI, 2, NW>(g.p[i], bid, gs, cnt, smem, ac, ksl);
@@ -614,15 +580,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_bf16_grouped_ke
         }
         else gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW>(g.p[i], bid, gs, cnt, smem, ac, ksl);
     }
-#if DMVAE_ABLATE == 6
-    if (threadIdx.x == 0 && blockIdx.x < 2048) {
-        unsigned long long* st = g_stamps + 4 * blockIdx.x;
-        st[0] = t0;
-        st[1] = __builtin_amdgcn_s_memrealtime();
-        st[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_ID | XCC_ID
-        st[3] = ((g_mid[blockIdx.x] - t0) << 16) | ((unsigned long long)LAYOUT << 8) | (unsigned)kind;   // K-loop ticks | layout | kind
-    }
-#endif
+    MEAS_WG_END(LAYOUT, kind);
 }
 
 // ---------------------------------------------------------------- host side

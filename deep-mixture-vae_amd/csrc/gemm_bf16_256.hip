@@ -43,22 +43,12 @@
 #include <vector>
 
 #include "gemm_tile.h"
+#include "measure.h"      // MEAS_*: empty in the product build
 
 namespace dmvae {
 
-#ifndef DMVAE_ABLATE
-#define DMVAE_ABLATE 0
-#endif
-#if DMVAE_ABLATE == 6      // tools/anatomy256.py, tools/clock256.py: per workgroup {entry, K loop done, epilogue done (100 MHz ticks, s_memrealtime),
-                           // HW_ID << 32 | XCC_ID, entry, K loop done (shader cycles, s_memtime), 0, 0}: the clock the chip holds in the K loop is
-                           // (slot 5 - slot 4) / (slot 1 - slot 0) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).  The stamps go to this
-                           // table only; no output is computed from them; the product build executes none of them.
-__device__ unsigned long long g_anat256[4096 * 8];
-#define ANAT256(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) { g_anat256[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
-                        if ((i) < 2) g_anat256[blockIdx.x * 8 + 4 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
-#else
-#define ANAT256(i) do { } while (0)
-#endif
+// (tools/anatomy256.py, tools/clock256.py -- measure.h: the clock the chip holds in the K loop is (slot 5 - slot 4) / (slot 1 - slot 0) x 100 MHz)
+MEAS_TABLES_256
 constexpr int HALF_ELEMS = 128 * BK;     // one half-tile: 128 rows (or columns) x 64 k of bf16 = 16 KiB
 constexpr int LOOKAHEAD = 6;             // half-tiles issued ahead of the phase that consumes them
 constexpr int ADAM_NB = 4;               // quads per batch of the dW + Adam epilogue; two batches of parameter / m / v loads in flight (adam_pipelined)
@@ -147,7 +137,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& a, const dmvae_adam
     }
     constexpr bool A_KC = (LAYOUT != DMVAE_GEMM_DW);
     constexpr bool B_KC = (LAYOUT == DMVAE_GEMM_DX);
-    ANAT256(0);
+    MEAS_ANAT256(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -269,7 +259,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& a, const dmvae_adam
     if (wr == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier
     wait_vmcnt<0>();                                 // the trailing re-loads: every DMA write has landed ...
     __builtin_amdgcn_s_barrier();                    // ... for every wave, before LDS is reused
-    ANAT256(1);
+    MEAS_ANAT256(1);
 
     // ---- epilogue: two 64 x 64 fp32 blocks per wave through the wave's private 16 KiB
     float loss = 0.f;
@@ -359,13 +349,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& a, const dmvae_adam
         const float t = block_sum_waves<8>(loss, red);
         if (tid < 16) a.epi.partials[(tm * 4 + tid / 4) * (a.N / 64) + tn * 4 + tid % 4] = tid == 0 ? t : 0.f;   // 64x64 cell grid, see gemm_bf16.hip
     }
-#if DMVAE_ABLATE == 6
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    ANAT256(2);
-    if (threadIdx.x == 0 && blockIdx.x < 4096)
-        g_anat256[blockIdx.x * 8 + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);
-#endif
+    MEAS_ANAT256_DRAIN();
 }
 
 template <int LAYOUT, int EPI>
@@ -423,14 +407,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_dw_multi_kernel(Multi256
 }
 
 // ---------------------------------------------------------------- host side
-void* gemm_bf16_256_anatomy() {
-#if DMVAE_ABLATE == 6
-    void* p = nullptr;
-    return hipGetSymbolAddress(&p, HIP_SYMBOL(g_anat256)) == hipSuccess ? p : nullptr;
-#else
-    return nullptr;
-#endif
-}
+void* gemm_bf16_256_anatomy() { return MEAS_SYMBOL(g_anat256); }
 static int g_policy256 = 1;     // tuning knob (dmvae_debug_set_knob 6): 0 never, 1 when the grid fills the chip, 2 whenever the shape divides
 void gemm_bf16_256_set_policy(int v) { g_policy256 = v; }
 

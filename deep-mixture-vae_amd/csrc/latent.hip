@@ -53,19 +53,12 @@ __device__ __forceinline__ float row_max16(float v) {
     return v;
 }
 
-#ifndef DMVAE_ABLATE
-#define DMVAE_ABLATE 0
-#endif
-#if DMVAE_ABLATE == 7   // tools/latent_time.py --stamps: phase timeline of block 0 behind the loss partials (100 MHz ticks)
-#define LAT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(L.a.loss_partials + 2 * gridDim.x)[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define LAT_STAMP(i) do { } while (0)
-#endif
+#include "measure.h"      // MEAS_LAT_STAMP: phase stamps of block 0 in the abl7 measurement build (tools/latent_time.py); empty in the product build
 
 template <int MODE, int DSL>   // MODE 0 exact, 1 relaxed; DSL = columns per lane per chunk (DC = 16*DSL)
 __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
     const dmvae_latent_args& a = L.a;
-    LAT_STAMP(0);
+    MEAS_LAT_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int K = a.K, D = a.D, RB = L.RB;
     constexpr int DC = 16 * DSL, DCP = DC + 1;   // +1: rows of one column land on distinct banks (phase 1b / 2)
@@ -124,7 +117,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
         }
     }
 
-    LAT_STAMP(1);
+    MEAS_LAT_STAMP(1);
     // ---- prologue: c_k, tables of chunk 0 into LDS, per-row softmax / zeta, KL_C ----
     for (int k = tid >> 4; k < K; k += 16) {
         float s = 0.f;
@@ -215,7 +208,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
         }
     }
     lds_barrier();
-    LAT_STAMP(2);
+    MEAS_LAT_STAMP(2);
 
     // ---- D-chunk loop ----
     for (int c = 0; c < L.nchunks; ++c) {
@@ -251,7 +244,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                     for (int u = 0; u < 4; ++u) nz[4 * j + u] = q4[u];
                 }
             }
-            LAT_STAMP(7);
+            MEAS_LAT_STAMP(7);
 #pragma unroll
             for (int i = 0; i < DSL; ++i) {
                 const int d = lr + 16 * i;
@@ -276,7 +269,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                     a.clv[(int64_t)b * a.ld_g + dg] = cl;
                 }
             }
-            LAT_STAMP(8);
+            MEAS_LAT_STAMP(8);
             if (MODE == 0) {
                 float gm[DSL], A[DSL];
 #pragma unroll
@@ -297,7 +290,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                         A[i] += wk * ipk;
                     }
                 }
-                LAT_STAMP(9);
+                MEAS_LAT_STAMP(9);
                 lvsum = row_sum16(lvsum);
                 if (lr == 0) rowlv[r] += lvsum;
 #pragma unroll
@@ -348,9 +341,9 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                 if (lr == 0) rowlv[r] += integ;
             }
         }
-        LAT_STAMP(10);
+        MEAS_LAT_STAMP(10);
         lds_barrier();
-        LAT_STAMP(3);
+        MEAS_LAT_STAMP(3);
 
         // phase 1b: sixteen lanes per row, cluster k = lr + 16*j; sums over d in private accumulators
         for (int r = rsub; r < RB; r += 16) {
@@ -384,7 +377,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
             }
         }
 
-        LAT_STAMP(4);
+        MEAS_LAT_STAMP(4);
         // phase 2: prior-table gradient partials of this block, threads over (k, d)
         for (int idx = tid; idx < K * dc; idx += 256) {
             const int k = idx / dc, d = idx - k * dc;
@@ -413,7 +406,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
             o[(int64_t)K * D + (int64_t)k * D + d0 + d] = a2;
         }
         lds_barrier();
-        LAT_STAMP(5);
+        MEAS_LAT_STAMP(5);
     }
 
     // ---- finalize rows: KL_Z, dlogits ----
@@ -467,7 +460,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
         a.loss_partials[2 * blockIdx.x + 0] = z;
         a.loss_partials[2 * blockIdx.x + 1] = c;
     }
-    LAT_STAMP(6);
+    MEAS_LAT_STAMP(6);
 }
 
 static void latent_geometry(int B_pad, int D, int K, int& RB, int& DC, int& nchunks, size_t& lds_bytes) {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds measurement variants of the bf16 GEMM (DMVAE_ABLATE=1..4, see gemm_bf16.hip) into
+# Builds measurement variants of the kernels (DMVAE_ABLATE=1..8: csrc/measure.h lists them) into
 # deep-mixture-vae_amd/build/libdmvae_hip_abl<N>.so (git-ignored; select with DMVAE_HIP_LIB).
 # Results of an ablated library are WRONG by construction: timing only.
 set -e
