@@ -28,9 +28,9 @@ behind its segment) or as one collective after the whole backward.  Three bucket
 (a collective behind each of decoder / heads / trunk) pay three smaller dW grids +
 host hand-overs per step: chosen from 64 MiB (the 4096-wide configuration).  Two
 buckets (decoder + heads behind segment 1 as ONE weight-gradient launch, the trunk
-behind segment 2) pay one grid more than the single-process step: the MNIST-sized
-arenas (19-24 MB), where one exposed reduce-scatter / all-gather pair is ~15 % of
-the step at 8 ranks.  Below 8 MiB: one pair after the backward.
+behind segment 2) exist and are tested, but priced with a one-rank RCCL
+communicator they cost more than they can hide at the MNIST sizes (the table at
+make_exchange), so smaller arenas issue one pair after the backward.
 DMVAE_DP_OVERLAP=0|1 and DMVAE_DP_BUCKETS=2|3 override (make_exchange).
 """
 import os
@@ -209,12 +209,22 @@ def make_exchange(param_bytes=0, group=None):
     ov = os.environ.get("DMVAE_DP_OVERLAP")
     ex._overlap = (param_bytes >= OVERLAP_MIN_BYTES) if ov is None else ov != "0"
     nb = os.environ.get("DMVAE_DP_BUCKETS")
-    ex.n_buckets = int(nb) if nb in ("2", "3") else (3 if param_bytes >= 64 * 2 ** 20 else 2)
+    ex.n_buckets = int(nb) if nb in ("2", "3") else 3
     return ex
 
 
-# Arena size from which the exchange is cut into buckets that overlap the backward pass.  >= 64 MiB (the 4096-wide stack: 702 MB):
-# three buckets, the exchange must hide.  MNIST-sized arenas (19-24 MB): TWO buckets -- one weight-gradient launch more than the
-# single-process step instead of two more; measured with a one-rank RCCL communicator it costs less than the
-# wire time it takes off the critical path at 8 ranks.  Below 8 MiB a collective is latency, not bytes: one pair after the backward.
-OVERLAP_MIN_BYTES = 8 * 2 ** 20
+# Arena size from which the exchange is cut into buckets that overlap the backward pass: 64 MiB, i.e. the 4096-wide stack (702 MB of
+# gradients: the exchange must hide).  The MNIST-sized arenas (19-24 MB) keep ONE reduce-scatter / all-gather pair after the backward.
+# MEASURED, round 4, one MI355X, a ONE-RANK RCCL communicator (DMVAE_DP_FORCE=1: every collective is the library call, an identity --
+# this prices host issue, stream hand-overs, the extra weight-gradient grids and the stand-alone Adam launches, NOT wire time), ms per
+# step (profiles/r04_dp_pricing.txt):
+#                      fused single process | one pair | two buckets | three buckets
+#     cfg2 (4096 rows)        0.2793        |  0.3241  |   0.3878    |    0.4372
+#     cfg4 (8192 rows)        0.6213        |  0.6599  |   0.7274    |    0.8236
+# The two-bucket form (decoder + heads behind segment 1 as one weight-gradient launch, the trunk behind segment 2) costs
+# +67 us per step over one pair at cfg4; what it can take off the critical path at 8 ranks is the decoder + heads reduce-scatter,
+# estimated at ~45 us (17 us of wire at 153 GB/s per link + one collective latency) -- on this evidence it does not
+# pay at these sizes, so it is NOT the default.  It stays selectable (DMVAE_DP_OVERLAP=1 DMVAE_DP_BUCKETS=2), is bit-identical to the
+# other forms (tests/test_gpu_step.py, the [2] cases) and bench.py prints exchange.exposed_us, so the first real multi-rank run can
+# overturn this with a measurement.
+OVERLAP_MIN_BYTES = 64 * 2 ** 20

@@ -52,7 +52,17 @@ __global__ void lds_kernel(int reps, unsigned long long* out, float* sink) {
     float acc = 0.f;          // consume every destination AFTER the final wait (keeps them live across the loop)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc += q[i][0] + q[i][3] + h[i][0] + h[i][1] + w[i];
-    if (tid == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = r1 - r0; }
+    // the workgroup's span: earliest wave start -> latest wave end (with two waves per SIMD the arbiter favours the older wave, which
+    // then finishes early: ONE wave's elapsed time against ALL waves' bytes over-reads the rate -- the first round-4 run did that)
+    __shared__ unsigned long long span[4];
+    if (tid == 0) { span[0] = ~0ull; span[1] = 0; span[2] = ~0ull; span[3] = 0; }
+    __syncthreads();
+    if (lane == 0) {
+        atomicMin(&span[0], c0); atomicMax(&span[1], c1);
+        atomicMin(&span[2], r0); atomicMax(&span[3], r1);
+    }
+    __syncthreads();
+    if (tid == 0) { out[2 * blockIdx.x] = span[1] - span[0]; out[2 * blockIdx.x + 1] = span[3] - span[2]; }
     if (acc == 123.456f) sink[0] = acc;
 }
 
