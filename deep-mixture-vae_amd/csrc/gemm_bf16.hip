@@ -803,7 +803,21 @@ int gemm_bf16_grouped(hipStream_t s, int layout, const GemmArgs* probs, int npro
     if (layout == DMVAE_GEMM_DW && epi == DMVAE_EPI_STORE_F32) return grouped_launch<DMVAE_GEMM_DW, DMVAE_EPI_STORE_F32>(s, probs, nprob);
     if (layout == DMVAE_GEMM_FWD && epi == DMVAE_EPI_BIAS_F32) return grouped_launch<DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_F32>(s, probs, nprob);
     if (fin && !(layout == DMVAE_GEMM_DX && epi == DMVAE_EPI_RELU_MASK)) { set_error("dmvae_gemm_grouped: step_finalize rides on DX / RELU_MASK groups only"); return DMVAE_EINVAL; }
-    if (layout == DMVAE_GEMM_DX && epi == DMVAE_EPI_RELU_MASK) return grouped_launch<DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK>(s, probs, nprob, nullptr, fin);
+    if (layout == DMVAE_GEMM_DX && epi == DMVAE_EPI_RELU_MASK) {
+        // the tiny-K problems (the dX of the two head layers: K = 2 D | the padded class count) stream through heads_dx.hip; the step_finalize
+        // riders go with them; what does not qualify (K = 512 at D = 256) stays on the grouped tiles
+        bool taken[DMVAE_MAX_GROUP];
+        const int rc = heads_dx_stream_launch(s, probs, nprob, fin, taken);
+        if (rc) return rc;
+        GemmArgs rest[DMVAE_MAX_GROUP];
+        int nrest = 0, ntaken = 0;
+        for (int i = 0; i < nprob; ++i) {
+            if (taken[i]) ++ntaken;
+            else rest[nrest++] = probs[i];
+        }
+        if (nrest == 0) return 0;
+        return grouped_launch<DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK>(s, rest, nrest, nullptr, ntaken ? nullptr : fin);
+    }
     set_error("dmvae_gemm_grouped: layout %d with epilogue %d is not instantiated", layout, epi);
     return DMVAE_EUNSUPPORTED;
 }

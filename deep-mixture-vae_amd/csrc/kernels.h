@@ -31,6 +31,10 @@ void gemm_bf16_256_set_stagger(int v);
 bool gemm_bf16_256_slice_ok(int M, int N, int k_split);   // may K slices of this dW problem run on the macro tile (into slabs)?
 bool gemm_bf16_256_rides();      // policy: may sub-chip problems ride in the merged dW grid (knob 6 >= 1, merging on)
 int gemm_bf16_256_dw_all(hipStream_t s, const GemmArgs* probs, int n, const dmvae_adam_ctx* ctx);
+// streaming form of the dX of the two head layers (heads_dx.hip): takes the problems of a grouped DX / RELU_MASK launch with K = 64 / 128 / 256
+// (taken[i]) as one launch, the riding step_finalize blocks with them; the caller launches whatever is left as before
+int heads_dx_stream_launch(hipStream_t s, const GemmArgs* probs, int nprob, const dmvae_finalize_args* fin, bool* taken);
+void heads_dx_stream_set(int v);
 void gemm_bf16_force_tile(int t);
 void gemm_bf16_set_knob(int which, int v);
 int gemm_f32_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split);

@@ -568,3 +568,65 @@ def test_philox_noise_moments_and_cast(hip):
     d = torch.zeros(n, device="cuda")
     L.check(L.lib.dmvae_cast_bf16_to_f32(stream(), L.ptr(c), L.ptr(d), n))
     assert torch.equal(d, c.float())
+
+
+# ---------------------------------------------------------------- streaming dX of the two head layers (csrc/heads_dx.hip, round 4)
+def _heads_dx_case(L, M, Ks, N, seed, reps=1):
+    """the grouped DX / RELU_MASK launch of len(Ks) sibling problems writing side-by-side column ranges of one [M, len(Ks) * N] output
+    (the layout of d[hz | hc], code/base_models.py:229-248), on the grouped tiles (knob 13 = 0) and on the streaming kernel (1)"""
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    P = len(Ks)
+    dY = [torch.randn(M, K, device="cuda", generator=g).bfloat16() for K in Ks]
+    W = [(torch.randn(N, K, device="cuda", generator=g) * 0.25).bfloat16() for K in Ks]       # [in = N][out = K]: contraction-contiguous for dX
+    gate = torch.relu(torch.randn(M, P * N, device="cuda", generator=g)).bfloat16()           # ~half of the units closed
+    SENT = 7.0
+    outs = []
+    for knob in (0, 1):
+        L.check(L.lib.dmvae_debug_set_knob(13, knob))
+        try:
+            res = []
+            for _ in range(reps):
+                out = torch.full((M + 64, P * N + 64), SENT, device="cuda", dtype=torch.bfloat16)    # a guard band of rows and columns around the output
+                probs = (L.GemmProblem * P)()
+                for i in range(P):
+                    p = probs[i]
+                    p.M, p.N, p.K = M, N, Ks[i]
+                    p.A, p.lda, p.B, p.ldb = dY[i].data_ptr(), Ks[i], W[i].data_ptr(), Ks[i]
+                    p.epi.kind = L.EPI_RELU_MASK
+                    p.epi.out = out.data_ptr() + i * N * 2; p.epi.ldo = P * N + 64
+                    p.epi.aux0 = gate.data_ptr() + i * N * 2; p.epi.ld0 = P * N
+                L.check(L.lib.dmvae_gemm_grouped(stream(), L.BF16, L.GEMM_DX, probs, P))
+                torch.cuda.synchronize()
+                res.append(out)
+            outs.append(res)
+        finally:
+            L.check(L.lib.dmvae_debug_set_knob(13, 1))
+    for r in range(reps):
+        a, b = outs[0][r], outs[1][r]
+        assert bool((b[M:] == SENT).all()) and bool((b[:, P * N:] == SENT).all()), "stray store outside the output"
+        assert torch.equal(a, b), (M, Ks, N, r, int((a != b).sum().item()))
+    # and against the definition (fp32 accumulate over bf16 products, gate, one rounding to bf16)
+    b = outs[1][0]
+    for i in range(P):
+        ref = (dY[i].float() @ W[i].float().t()) * (gate[:, i * N:(i + 1) * N].float() > 0)
+        got = b[:M, i * N:(i + 1) * N].float()
+        assert torch.allclose(got, ref, rtol=2e-2, atol=2e-2 * float(ref.abs().max()) / 8), (M, Ks[i])
+        assert bool(((got == 0) | (gate[:, i * N:(i + 1) * N].float() > 0)).all())      # closed units are exact zeros
+
+
+# M chosen so that the walk of a workgroup has 1, 2, 3, 4, 5, 6 and 11 steps (every branch of the step dispatcher: single step, first + last,
+# the two-steps-per-iteration loop once and twice, both tails), and cases whose last row chunk is ragged (a workgroup with a single
+# step inside a multi-step launch); K = 64 / 128 / 256 are the kernel's three bodies, K = 512 stays on the grouped tiles
+@pytest.mark.parametrize("M,Ks,N", [(64, (128, 64), 2048), (128, (128, 64), 2048), (3072, (128, 64), 2048), (4096, (128, 64), 2048),
+                                    (5120, (128, 64), 2048), (6144, (128, 64), 2048), (7168, (256, 64), 2048), (3392, (128, 64), 2048), (192, (64,), 128),
+                                    (1024, (256,), 256), (2048, (512, 64), 2048), (640, (128, 128), 384)])
+def test_heads_dx_stream_equals_the_grouped_kernel(hip, M, Ks, N):
+    """csrc/heads_dx.hip against gemm_bf16_grouped_kernel on the same operands: bit-identical (the same MFMA chain per output
+    element, k ascending), nothing written outside the output, closed ReLU units exact zeros."""
+    _heads_dx_case(hip, M, Ks, N, seed=M + sum(Ks))
+
+
+def test_heads_dx_stream_repeated_launches_stay_identical(hip):
+    """a synchronisation fault (a slot reused before every wave has read it, a gate consumed before it landed) shows as rare
+    mismatches that come and go: the same launch 25 times at the metric's shape, every result compared with the grouped kernel's"""
+    _heads_dx_case(hip, 4096, (128, 64), 2048, seed=99, reps=25)
