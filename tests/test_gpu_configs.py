@@ -365,7 +365,8 @@ def test_full_size_bf16_gradients_and_update_track_the_fp32_engine(name):
     (ii) the parameters after ONE fused bf16 step (cfg3: adam_slabs) against fp32 engine + IEEE Adam.  Step 1 of TF-Adam moves a
         parameter by -lr g / (|g| + eps'), i.e. by +-lr wherever |g| >> 3e-7: the two runs agree to rounding where the bf16 and the
         fp32 gradient have the same sign and differ by 2 lr where a gradient within bf16 error of zero changes sign.  Stated bound:
-        no element differs by more than 2 lr (1 + 1e-3), at most 6 % differ by more than lr / 10 (printed), and the pad
+        no element differs by more than 2 lr (1 + 1e-3), at most 1 % differ by more than lr / 10 (measured 0.21 / 0.17 / 0.25 % at
+        cfg2 / cfg3 / cfg4, worst gradient Frobenius error 2.0e-2 / 1.4e-2 / 2.2e-2: profiles/r04_fullsize_parity.txt), and the pad
         elements (zero gradient) do not move at all."""
     kw, B, lr = FULL[name]
     g = torch.Generator(device="cuda"); g.manual_seed(31)
@@ -410,7 +411,7 @@ def test_full_size_bf16_gradients_and_update_track_the_fp32_engine(name):
     diff = (db - df).abs()
     assert diff.max().item() <= 2 * lr * (1 + 1e-3), diff.max().item()
     frac = (diff > lr / 10).float().mean().item()
-    assert frac <= 0.06, (name, frac)
+    assert frac <= 0.01, (name, frac)
     # elements that never receive a gradient (layout pads: zero parameter, zero gradient) stay put in both runs
     still = (df == 0)
     assert torch.equal(db[still & res["fp32"][3]], torch.zeros_like(db[still & res["fp32"][3]]))

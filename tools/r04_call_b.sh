@@ -1,10 +1,9 @@
 #!/bin/bash
-# round 4, GPU call B: the streaming heads-dX kernel -- what is wrong with the first form (knob 13 = 2: waits that credit stores), is the
-# store-agnostic form (knob 13 = 1) right, then -- only if its tests pass -- timings
+# round 4, GPU call B: the streaming heads-dX kernel (second form): tests, the classification diagnostic, then -- only if the tests pass -- timings
 set -o pipefail
 mkdir -p gpurun_out
 O=gpurun_out
-timeout -k 10 120 python tools/heads_dx_diag.py 2 4096 2>&1 | tee $O/r04_hdx_diag_knob2.txt | cut -c1-420
+
 timeout -k 10 120 python tools/heads_dx_diag.py 1 4096 2>&1 | tee $O/r04_hdx_diag_knob1.txt | cut -c1-420
 timeout -k 10 300 python -m pytest tests/test_gpu_kernels.py -m gpu -q -k "heads_dx" > $O/r04_hdx_tests.log 2>&1
 rc=$?; tail -3 $O/r04_hdx_tests.log
