@@ -22,10 +22,13 @@
 // (tools/heads_dx_diag.py; found by tests/test_gpu_kernels.py, proven in the ISA).  Now a step's gate registers are local to that
 // branch-free step: loaded at its top (for the NEXT tile), and at its end waited for and written to thread-private LDS slots, from
 // which the next step's epilogue reads them; the prologue does the same for tile 0.
-// MEASURED (round 4): the pair alone 20.4 -> 17.4 us at cfg2 (3.3 -> 3.9 TB/s of mask + output), 80.3 -> 76.8 us at cfg3; in the step
-// 0.2752 -> 0.2736 ms (cfg2).  It does NOT reach the memory system's rate (VERDICT r3 asked >= 5 TB/s): a step takes ~4 us, one HBM
-// round trip -- the next tile's gates are requested ONE step ahead and the step ends waiting for them.  Two or three tiles of gates in
-// flight (by LDS-DMA into a ring, no register destination, hence no hazard below) is what the numbers call for; not built.
+// MEASURED (round 4, profiles/r04_heads_dx_stream.txt).  The pair alone, interleaved graph replays on shared buffers, two runs: 20.4 -> 17.4 and
+// 20.3 -> 17.6 us at cfg2 (3.3 -> 3.8-3.9 TB/s of mask + output; a plain copy of the same bytes: 6.3 TB/s), 80.3 -> 76.8 and 78.8 -> 75.7 us at
+// cfg3 (copy: 7.0 TB/s).  In the STEP (tools/knob_step.py <cfg> 13 0 1 1 0: one engine, graphs on the same buffers, same-value spread 0.15 %):
+// cfg2 0.2758 vs 0.2757 ms -- nothing; cfg3 0.9383 -> 0.9327 ms (-0.6 %); cfg4 does not take this kernel.  It does NOT reach the memory
+// system's rate (VERDICT r3 asked >= 5 TB/s): a step of the walk takes ~4 us, one HBM round trip -- the next tile's gates are requested
+// ONE step ahead and the step ends waiting for them.  Two or three tiles of gates in flight (by LDS-DMA into a ring: no register
+// destination, hence no hazard below) is what the numbers call for; not built.
 // Arithmetic: the same v_mfma_f32_16x16x32_bf16 chain per output element, k ascending, as gemm_bf16_body -- bit-identical results
 // (tests/test_gpu_kernels.py::test_heads_dx_stream_equals_the_grouped_kernel, and every step test runs through it).
 #include <algorithm>
@@ -253,10 +256,9 @@ int heads_dx_stream_launch(hipStream_t s, const GemmArgs* probs, int nprob, cons
     HeadsDxArgs h{};
     int n = 0;
     double flops = 0.0, bytes = 0.0;
-    // ALL problems of the group or none.  MEASURED (round 4, tools/heads_dx_ab.py + tools/knob_step.py, interleaved on one box): with K = 2 D = 512
-    // (cfg4) only the class-logits problem qualifies; streaming it and leaving the other on the grouped tiles makes two launches out of one
-    // grid: 48.9 vs 44.1 us for the pair, 0.6268 vs 0.6208 ms per step.  Where both qualify: cfg2 17.35 vs 20.40 us (step 0.2736 vs 0.2752 ms),
-    // cfg3 76.8 vs 80.3 us (step 0.9372 vs 0.9385 ms).
+    // ALL problems of the group or none.  MEASURED (round 4, tools/heads_dx_ab.py, the pair alone, interleaved on shared buffers): with
+    // K = 2 D = 512 (cfg4) only the class-logits problem qualifies; streaming it and leaving the other on the grouped tiles makes two launches
+    // out of one grid: 48.9 vs 44.1 us for the pair.
     if (nprob > 2) return 0;
     for (int i = 0; i < nprob; ++i)
         if (heads_dx_kind(probs[i]) < 0) return 0;
