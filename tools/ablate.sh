@@ -13,6 +13,6 @@ done
 wait
 for n in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libdmvae_hip_abl$n.so build/gemm_bf16_abl$n.o build/latent_abl$n.o \
-      build/gemm_bf16_256_abl$n.o build/gemm_f32.o build/latent_mfma.o build/latent_vade.o build/elementwise.o build/conv.o build/api.o
+      build/gemm_bf16_256_abl$n.o build/gemm_f32.o build/latent_mfma.o build/latent_vade.o build/elementwise.o build/conv.o build/heads_dx.o build/api.o
   echo build/libdmvae_hip_abl$n.so
 done
