@@ -171,7 +171,8 @@ struct dmvae_plan {
     std::vector<int64_t> o_enc, o_dec, o_denc, o_ddec;
     int64_t o_rpart, o_lpart, o_dprior, o_cs, o_lws = 0;
     int64_t lws_bytes = 0;            // scratch of the MFMA form of the latent contractions (0: the one-kernel form)
-    int n_rpart, n_lblk, n_pblk;      // loss-partial blocks of the latent kernel; rows of its prior-table gradient partials
+    int n_rpart, n_lblk, n_pblk;      // loss-partial blocks of the latent kernel; rows of its prior-table gradient partials (as of plan creation)
+    int n_lblk_cap = 0;               // rows the partial-sum buffers hold
     int64_t cs_elems;
     int64_t work_bytes;
     dmvae_buffers buf;
@@ -385,10 +386,14 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
     p->n_rpart = gemm_partials(c->dtype, p->Bp, p->Ip);
     p->o_rpart = take((int64_t)p->n_rpart * 4);
     p->n_lblk = p->vade ? latent_vade_nblocks(p->Bp) : latent_nblocks(p->Bp, c->latent_dim, c->n_classes);
-    p->o_lpart = take((int64_t)p->n_lblk * 2 * 4);
+    // The block count of the latent kernel follows a tuning knob (14) that may change after the plan exists: the partial-sum buffers are
+    // sized for the LARGEST count any setting can produce (16 rows per block), the count in use is taken at enqueue time
+    // (latent_blocks_now) and checked against this capacity.
+    p->n_lblk_cap = std::max(p->n_lblk, (p->Bp + 15) / 16);
+    p->o_lpart = take((int64_t)p->n_lblk_cap * 2 * 4);
     p->lws_bytes = (!p->vade && latent_mfma_applies(c->latent_dim, c->n_classes, c->mode)) ? latent_mfma_ws_bytes(p->Bp, c->latent_dim, c->n_classes) : 0;
     p->n_pblk = p->lws_bytes ? 1 : p->n_lblk;          // the MFMA form delivers the prior-table gradient complete, in one row
-    p->o_dprior = take((int64_t)p->n_pblk * 2 * KD * 4);
+    p->o_dprior = take((int64_t)(p->lws_bytes ? 1 : p->n_lblk_cap) * 2 * KD * 4);
     if (p->lws_bytes) p->o_lws = take(p->lws_bytes);
     int maxN = std::max(std::max(2 * p->Hp, p->Ip), p->flat);
     for (auto& L : p->enc) maxN = std::max(maxN, L.out_pad);
@@ -851,9 +856,12 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     // launch of their own, here.  MEASURED earlier: as a side BRANCH of the graph (fork / join events) the step
     // took 0.344 ms against 0.326 ms -- a second branch costs more than the launch it hides.
     const int KD2 = 2 * c.n_classes * c.latent_dim;
+    const int n_lblk = p->vade ? p->n_lblk : latent_nblocks(p->Bp, c.latent_dim, c.n_classes);      // under the knob's CURRENT value: what latent_launch will use
+    const int n_pblk = p->lws_bytes ? 1 : n_lblk;
+    DMVAE_REQUIRE(n_lblk <= p->n_lblk_cap, "dmvae_plan_forward_backward: the latent kernel would run %d blocks, the plan's partial-sum buffers hold %d", n_lblk, p->n_lblk_cap);
     const dmvae_finalize_args fin = step_finalize_args(reinterpret_cast<float*>(WS(p, p->o_rpart)), p->n_rpart, reinterpret_cast<float*>(WS(p, p->o_lpart)),
-                                                       p->n_lblk, inv_B, p->buf.state, 1, c.beta1, c.beta2,
-                                                       reinterpret_cast<float*>(WS(p, p->o_dprior)), p->n_pblk, KD2, p->buf.grad + p->prior_off);
+                                                       n_lblk, inv_B, p->buf.state, 1, c.beta1, c.beta2,
+                                                       reinterpret_cast<float*>(WS(p, p->o_dprior)), n_pblk, KD2, p->buf.grad + p->prior_off);
     // (wide heads -- the 4096-wide configuration -- take the 256x256 macro-tile kernel one by one instead of the grouped grid)
     const bool heads_big = dt == DMVAE_BF16 && gemm_bf16_256_ok(DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK, p->Bp, p->Hp, 2 * p->Dp, false) &&
                            gemm_bf16_256_ok(DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK, p->Bp, p->Hp, p->Kp, false);
@@ -1261,7 +1269,8 @@ extern "C" int dmvae_debug_set_knob(int which, int value) {
     if (which == 11) { g_dw_macro = value; return 0; }
     if (which == 12) { g_heads_dx_form = value; return 0; }
     if (which == 13) { heads_dx_stream_set(value); return 0; }
-    DMVAE_REQUIRE(which >= 0 && which <= 9 && which != 3, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, (3: removed, the deep-ring policy), 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy, 7 = short-K workgroups, 8 = first-tile stagger of the merged dW grid, 9 = waves per workgroup of a grouped dX launch; 10 / 11 = K slices of the dW groups, 12 = heads dX as one or two launches, 13 = heads dX on the streaming kernel (1) or the grouped tiles (0)");
+    if (which == 14) { latent_set_blocks_target(value); return 0; }      // (changes latent_nblocks: set it BEFORE the plan is created)
+    DMVAE_REQUIRE(which >= 0 && which <= 9 && which != 3, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, (3: removed, the deep-ring policy), 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy, 7 = short-K workgroups, 8 = first-tile stagger of the merged dW grid, 9 = waves per workgroup of a grouped dX launch; 10 / 11 = K slices of the dW groups, 12 = heads dX as one or two launches, 13 = heads dX on the streaming kernel (1) or the grouped tiles (0), 14 = blocks the latent kernel's geometry aims at (512)");
     gemm_bf16_set_knob(which, value);
     return 0;
 }

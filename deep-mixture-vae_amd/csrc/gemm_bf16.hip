@@ -123,7 +123,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     // fragment against an all-ones A operand (exact: products with 1.0, fp32 accumulate), in
     // the workgroups of the first tile row only -- no separate column-sum pass over dY.
     constexpr bool DW = (LAYOUT == DMVAE_GEMM_DW);
-    const bool do_bias = DW && a.epi.out2 != nullptr && (tm == 0 || BONLY);
+    const bool do_bias = DW && !MEAS_NO_BIAS_MFMA && a.epi.out2 != nullptr && (tm == 0 || BONLY);
     f32x4 bacc[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) bacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};

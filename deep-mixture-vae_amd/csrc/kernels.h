@@ -42,6 +42,7 @@ int gemm_f32_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split);
 int gemm_f32_trio(hipStream_t s, const GemmArgs& g1, int split1, const GemmArgs& g2, int split2, const GemmArgs& g3, int split3);
 int latent_nblocks(int B_pad, int D, int K);
 int latent_launch(hipStream_t s, const dmvae_latent_args* a);
+void latent_set_blocks_target(int v);
 // VaDE's latent stage (latent_vade.hip): mode 2
 int latent_vade_nblocks(int B_pad);
 int latent_vade_launch(hipStream_t s, const dmvae_latent_args* a);

@@ -463,8 +463,10 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
     MEAS_LAT_STAMP(6);
 }
 
+static int g_latent_blocks = 512;          // tuning knob (dmvae_debug_set_knob 14): blocks the geometry aims at (rows per block = 16 .. 64, a power of two)
+void latent_set_blocks_target(int v) { g_latent_blocks = v < 64 ? 512 : v; }
 static void latent_geometry(int B_pad, int D, int K, int& RB, int& DC, int& nchunks, size_t& lds_bytes) {
-    const int want = (B_pad + 511) / 512;      // aim at >= 256..512 blocks
+    const int want = (B_pad + g_latent_blocks - 1) / g_latent_blocks;      // aim at >= 256..512 blocks
     RB = 16;                                    // power of two in [16, 64]: divides B_pad (multiple of 64)
     while (RB < want && RB < 64) RB *= 2;
     DC = 256;

@@ -10,6 +10,7 @@
 //      of a small GEMM), tools/anatomy256.py / tools/clock256.py (merged macro-tile dW grid; the clock held inside its K loop)
 //   7  phase timeline of block 0 of the latent kernel (tools/latent_time.py)
 //   8  no ReLU-mask read in the dX epilogue (the upper bound of what a 1-bit mask could save)
+//   9  no bias-gradient MFMAs in the first tile row of the weight-gradient tiles (the upper bound of moving that work elsewhere; bias gradients are then zero)
 // Stamp values go to tables of their own (or, build 7, behind the loss partials in the caller's buffer); no output is computed
 // from them (MI355X_MICROARCH.md, DVFS give-back item 6).
 #pragma once
@@ -24,6 +25,7 @@ constexpr bool MEAS_NO_LDS_READ = DMVAE_ABLATE == 2 || DMVAE_ABLATE == 4;
 constexpr bool MEAS_NO_KLOOP_LOADS = DMVAE_ABLATE == 3;
 constexpr bool MEAS_NO_EPILOGUE = DMVAE_ABLATE == 5;
 constexpr bool MEAS_NO_MASK_READ = DMVAE_ABLATE == 8;
+constexpr bool MEAS_NO_BIAS_MFMA = DMVAE_ABLATE == 9;
 constexpr bool MEAS_STAMPS = DMVAE_ABLATE == 6;
 }  // namespace dmvae
 
