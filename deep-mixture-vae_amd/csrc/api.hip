@@ -1269,9 +1269,8 @@ extern "C" int dmvae_debug_set_knob(int which, int value) {
     if (which == 11) { g_dw_macro = value; return 0; }
     if (which == 12) { g_heads_dx_form = value; return 0; }
     if (which == 13) { heads_dx_stream_set(value); return 0; }
-    if (which == 14) { latent_set_blocks_target(value); return 0; }
-    if (which == 15) { gemm_bf16_256_set_two_wg(value); return 0; }      // (changes latent_nblocks: set it BEFORE the plan is created)
-    DMVAE_REQUIRE(which >= 0 && which <= 9 && which != 3, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, (3: removed, the deep-ring policy), 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy, 7 = short-K workgroups, 8 = first-tile stagger of the merged dW grid, 9 = waves per workgroup of a grouped dX launch; 10 / 11 = K slices of the dW groups, 12 = heads dX as one or two launches, 13 = heads dX on the streaming kernel (1) or the grouped tiles (0), 14 = blocks the latent kernel's geometry aims at (512), 15 = the merged macro-tile dW grid as 256 x 128 tiles with two workgroups per CU (1) or 256 x 256 with one (0)");
+    if (which == 14) { latent_set_blocks_target(value); return 0; }      // (the block count in use is taken at enqueue time and checked against the plan's capacity)
+    DMVAE_REQUIRE(which >= 0 && which <= 9 && which != 3, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, (3: removed, the deep-ring policy), 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy, 7 = short-K workgroups, 8 = first-tile stagger of the merged dW grid, 9 = waves per workgroup of a grouped dX launch; 10 / 11 = K slices of the dW groups, 12 = heads dX as one or two launches, 13 = heads dX on the streaming kernel (1) or the grouped tiles (0), 14 = blocks the latent kernel's geometry aims at (512)");
     gemm_bf16_set_knob(which, value);
     return 0;
 }

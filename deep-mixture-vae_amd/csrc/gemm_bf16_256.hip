@@ -406,220 +406,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_dw_multi_kernel(Multi256
     gemm256_tile<DMVAE_GEMM_DW, EPI>(m.p[i], m.ac, item, smem, ksl);
 }
 
-// ---------------------------------------------------------------- 256 x 128 weight-gradient tile, TWO workgroups per CU (round 4)
-// The merged dW + Adam grid above runs ONE 8-wave workgroup per CU: a 50 us Adam epilogue (1.7 MB of p / m / v per 256 x 256 tile, latency bound)
-// sits serial behind every 184 us K loop with the matrix cores idle (0.4-0.5 ms of the 6.5 ms cfg5 step).  Here the tile is 256 x 128 on FOUR
-// waves (one per SIMD) with an 80 KiB ring, so that two workgroups share a CU (2 x 80 KiB = the CU's LDS; <= 256 VGPRs at two waves per SIMD):
-// one workgroup's epilogue runs under the other's K loop.  Price: 96 instead of 128 flop per byte taken into LDS, and the two partners of a SIMD
-// alternate by themselves instead of by the barrier stagger of the 8-wave tile.
-//   * waves = 2 (M) x 2 (N); wave (wr, wc) owns rows {ai * 128 + wr * 64 + 0..63 : ai = 0, 1} x cols wc * 64 + 0..63: the 8-wave tile's wave tile
-//     (32 accumulator tiles), the same four quadrant phases per K tile (p0: A-lo x b0, p1: A-lo x b1, p2: A-hi x b1, p3: A-hi x b0).
-//   * a K tile = THREE half-tiles of 16 KiB in stream order A-lo, B, A-hi; ring of FIVE buffers, half-tile s in buffer s % 5.  A-lo(t) is last
-//     read in phase 4t, B(t) in 4t + 1, A-hi(t) in 4t + 2; buffer of s is refilled with s + 5: phase 4t + 1 issues A-hi(t + 1), 4t + 2 issues
-//     A-lo(t + 2), 4t + 3 issues B(t + 2) -- each five or six phases ahead of its first read.
-//   * one phase = [fragment reads] [one half-tile of LDS-DMA: 4 instructions per wave] [counted vmcnt in phases 1 and 3] lgkmcnt(0) s_barrier [16 MFMAs].
-//     RAW: the data phase q + 1 reads was retired by every wave's vmcnt BEFORE the barrier of phase q.  WAR: a buffer is refilled by a DMA
-//     issued in phase >= r + 1, behind the barrier of phase r in which every wave completed (lgkmcnt(0)) its last reads of it.
-//     vmcnt(12): behind the half-tile(s) the next phase needs, three younger half-tiles stay in flight (48 KiB per workgroup).
-template <int EPI>
-__device__ __forceinline__ void gemm256x128_dw_tile(const GemmArgs& a, const dmvae_adam_ctx& ac, const int bid, bf16_t* smem, const int kslice = -1) {
-    static_assert(EPI == DMVAE_EPI_ADAM || EPI == DMVAE_EPI_STORE_F32, "weight-gradient epilogues");
-    int kdim = a.K;
-    int64_t koffA = 0, koffB = 0, slab_off = 0;
-    if constexpr (EPI == DMVAE_EPI_STORE_F32) {
-        if (kslice >= 0) {
-            kdim = a.k_split;
-            koffA = (int64_t)kslice * a.k_split * a.lda;
-            koffB = (int64_t)kslice * a.k_split * a.ldb;
-            slab_off = (int64_t)kslice * a.slab_stride;
-        }
-    }
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int tiles_n = a.N / 128, tiles_m = a.M / 256;
-    int tm, tn;
-    {
-        const int gm_max = a.group_m;
-        const int gsz = gm_max * tiles_n, grp = bid / gsz, first = grp * gm_max;
-        const int gm = min(tiles_m - first, gm_max), in = bid - grp * gsz;
-        tm = first + in % gm;
-        tn = in / gm;
-    }
-    const int m0 = tm * 256, n0 = tn * 128;
-    const int nk = kdim / BK;
-    // DW layout: A = X [K][M] m-contiguous, B = dY [K][N] n-contiguous
-    const bf16_t* Ag = reinterpret_cast<const bf16_t*>(a.A) + koffA + m0;
-    const bf16_t* Bg = reinterpret_cast<const bf16_t*>(a.B) + koffB + n0;
-    const int64_t stepA = (int64_t)BK * a.lda, stepB = (int64_t)BK * a.ldb;
-    unsigned goA[4], goB[4];
-    stage_offsets<128, false, 4, BK>(a.lda, wave, lane, goA);
-    stage_offsets<128, false, 4, BK>(a.ldb, wave, lane, goB);
-    unsigned foA[4], foB[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        unsigned short lo, hi;
-        frag_offsets<128, false>(wr * 64 + i * 16, 0, lane, lo, hi);
-        foA[i] = lo;
-        frag_offsets<128, false>(wc * 64 + i * 16, 0, lane, lo, hi);
-        foB[i] = lo;
-    }
-    const unsigned lds_w = __builtin_amdgcn_readfirstlane(
-        (unsigned)(size_t)((__attribute__((address_space(3))) bf16_t*)smem) + 1024u * (unsigned)wave);
-
-    f32x4 acc[2][4][4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // LDS-DMA of half-tile J (0 A-lo, 1 B, 2 A-hi) of K tile ts into ring buffer BUF (compile time)
-    auto issue = [&](auto Jc, auto BUFc, int ts) {
-        constexpr int J = decltype(Jc)::value, BUF = decltype(BUFc)::value;
-        const int tc = ts < nk ? ts : nk - 1;               // past the K range: re-load the last K tile into a buffer nobody reads (uniform vmcnt)
-        constexpr unsigned buf = 2u * (unsigned)(BUF * HALF_ELEMS);
-        if constexpr (J == 0) glds_tile(Ag + tc * stepA, goA, lds_w + buf, 4096u);
-        else if constexpr (J == 2) glds_tile(Ag + 128 + tc * stepA, goA, lds_w + buf, 4096u);
-        else glds_tile(Bg + tc * stepB, goB, lds_w + buf, 4096u);
-    };
-    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
-    // one phase of K tile t.  S0 = (3 t) % 5: ring position of the tile's first half-tile (compile time: the loop is unrolled over five K tiles)
-    auto phase = [&](auto Pc, auto S0c, int t) {
-        constexpr int P = decltype(Pc)::value, S0 = decltype(S0c)::value;
-        const bf16_t* Alo = smem + ((S0 + 0) % 5) * HALF_ELEMS;
-        const bf16_t* Bt = smem + ((S0 + 1) % 5) * HALF_ELEMS;
-        const bf16_t* Ahi = smem + ((S0 + 2) % 5) * HALF_ELEMS;
-        if constexpr (P == 0) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                { fb0[j][0] = read_frag_ks<128, false, 0>(Bt, foB[j]); fb0[j][1] = read_frag_ks<128, false, 1>(Bt, foB[j]); }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                { fa[i][0] = read_frag_ks<128, false, 0>(Alo, foA[i]); fa[i][1] = read_frag_ks<128, false, 1>(Alo, foA[i]); }
-        }
-        if constexpr (P == 1) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                { fb1[j][0] = read_frag_ks<128, false, 0>(Bt, foB[2 + j]); fb1[j][1] = read_frag_ks<128, false, 1>(Bt, foB[2 + j]); }
-        }
-        if constexpr (P == 2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                { fa[i][0] = read_frag_ks<128, false, 0>(Ahi, foA[i]); fa[i][1] = read_frag_ks<128, false, 1>(Ahi, foA[i]); }
-        }
-        // refills (buffer of s + 5 = buffer of s): p1 -> A-hi(t + 1) into A-lo(t)'s buffer, p2 -> A-lo(t + 2) into B(t)'s, p3 -> B(t + 2) into A-hi(t)'s
-        if constexpr (P == 1) issue(IC<2>{}, IC<(S0 + 0) % 5>{}, t + 1);
-        if constexpr (P == 2) issue(IC<0>{}, IC<(S0 + 1) % 5>{}, t + 2);
-        if constexpr (P == 3) issue(IC<1>{}, IC<(S0 + 2) % 5>{}, t + 2);
-        if constexpr (P == 1 || P == 3) wait_vmcnt<12>();   // p1: A-hi(t) has landed; p3: A-lo(t + 1), B(t + 1) have landed (this wave's share)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);
-        constexpr int AI = P >= 2 ? 1 : 0;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if constexpr (P == 0 || P == 3)
-                        acc[AI][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[AI][i][j], 0, 0, 0);
-                    else
-                        acc[AI][i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[AI][i][2 + j], 0, 0, 0);
-                }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto ktile = [&](auto S0c, int t) { phase(IC<0>{}, S0c, t); phase(IC<1>{}, S0c, t); phase(IC<2>{}, S0c, t); phase(IC<3>{}, S0c, t); };
-
-    // prologue: half-tiles 0..4 = A-lo(0), B(0), A-hi(0), A-lo(1), B(1); A-lo(0) and B(0) landed (three younger half-tiles stay in flight)
-    issue(IC<0>{}, IC<0>{}, 0); issue(IC<1>{}, IC<1>{}, 0); issue(IC<2>{}, IC<2>{}, 0); issue(IC<0>{}, IC<3>{}, 1); issue(IC<1>{}, IC<4>{}, 1);
-    wait_vmcnt<12>();
-    __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < nk; t += 5) {                    // ring position of K tile t + u: (3 u) % 5 for t a multiple of 5
-        ktile(IC<0>{}, t);
-        if (t + 1 < nk) ktile(IC<3>{}, t + 1);
-        if (t + 2 < nk) ktile(IC<1>{}, t + 2);
-        if (t + 3 < nk) ktile(IC<4>{}, t + 3);
-        if (t + 4 < nk) ktile(IC<2>{}, t + 4);
-    }
-    wait_vmcnt<0>();                                     // the trailing re-loads have landed ...
-    __builtin_amdgcn_s_barrier();                        // ... for every wave, before the ring becomes the epilogue's staging area
-
-    // ---- epilogue: two 64 x 64 fp32 blocks per wave through the wave's private 16 KiB (4 x 16 KiB of the idle 80 KiB ring)
-    float* st = reinterpret_cast<float*>(smem) + wave * 4096;
-    const int li = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = i * 16 + li, c = j * 4 + g;
-                *reinterpret_cast<f32x4*>(st + r * 64 + ((c ^ (r & 7)) << 2)) = acc[h][i][j];
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (EPI == DMVAE_EPI_ADAM) {
-            const unsigned base = (unsigned)((reinterpret_cast<const float*>(a.epi.out) - ac.grad) + (int64_t)(m0 + h * 128 + wr * 64) * a.epi.ldo + n0 + wc * 64 + li * 4);
-            adam_pipelined<ADAM_NB, 16 / ADAM_NB>(ac,
-                [&](int i, int b) { return base + (unsigned)((i * ADAM_NB + b) * 4 + g) * (unsigned)a.epi.ldo; },
-                [&](int i, int b, float (&gv)[4]) {
-                    const int r = (i * ADAM_NB + b) * 4 + g;
-                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(st + r * 64 + ((li ^ (r & 7)) << 2));
-                    gv[0] = t4[0]; gv[1] = t4[1]; gv[2] = t4[2]; gv[3] = t4[3];
-                });
-        } else {
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int r = it * 4 + g;
-                const f32x4 t4 = *reinterpret_cast<const f32x4*>(st + r * 64 + ((li ^ (r & 7)) << 2));
-                float v[4] = {t4[0], t4[1], t4[2], t4[3]};
-                ActIO<float>::store4(reinterpret_cast<float*>(a.epi.out) + slab_off, (int64_t)(m0 + h * 128 + wr * 64 + r) * a.epi.ldo + n0 + wc * 64 + li * 4, v);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-}
-
-// the merged grid of the 256 x 128 tiles: same Multi256 argument block (start[] counts 256 x 128 tiles x K slices), bias-gradient workgroups behind
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_256x128_dw_multi_kernel(Multi256 m) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[5 * HALF_ELEMS];       // 80 KiB: two workgroups per CU
-    const int b = (int)blockIdx.x, ntile = m.start[m.nprob];
-    if (b >= ntile) {
-        int j = 0;
-        while (j + 1 < m.nprob && b - ntile >= m.extra[j + 1]) ++j;
-        // (bias_seg_block strides by 512 threads per workgroup: here 256 threads, so twice the workgroups of the 8-wave grid cover it)
-        const int e = b - ntile - m.extra[j], ne = m.extra[j + 1] - m.extra[j];
-        const BiasSeg& bs = m.bs[j];
-        for (int q = e * 256 + (int)threadIdx.x; q < bs.n / 4; q += ne * 256) {
-            float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int sl = 0; sl < bs.nslab; ++sl) {                      // ascending order: the bits of bias_seg_block
-                const float4 p4 = *reinterpret_cast<const float4*>(bs.part + (int64_t)sl * bs.n + 4 * q);
-                g4.x += p4.x; g4.y += p4.y; g4.z += p4.z; g4.w += p4.w;
-            }
-            if constexpr (EPI == DMVAE_EPI_ADAM) {
-                const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
-                adam_quad(m.ac, (bs.out - m.ac.grad) + 4 * q, gv);
-            } else {
-                *reinterpret_cast<float4*>(bs.out + 4 * q) = g4;
-            }
-        }
-        return;
-    }
-    int i = 0;
-    while (i + 1 < m.nprob && b >= m.start[i + 1]) ++i;
-    int item = xcd_run_index(b, m.start[i], m.start[i + 1]), ksl = -1;
-    if (m.nsl[i] > 1) {
-        const int tiles_i = (m.start[i + 1] - m.start[i]) / m.nsl[i];
-        ksl = item / tiles_i;
-        item -= ksl * tiles_i;
-    }
-    gemm256x128_dw_tile<EPI>(m.p[i], m.ac, item, smem, ksl);
-}
+// (A 256 x 128 weight-gradient tile on FOUR waves with an 80 KiB five-buffer half-tile ring -- TWO workgroups per CU, so that one's Adam epilogue runs
+//  under the other's K loop: VERDICT r3 #1, the form DESIGN had proposed since round 2 -- was built in round 4, correct (bit-identical to this tile), and
+//  21.7 % slower on the cfg5 step: 6.425 -> 7.819 ms, the launch 2.57 -> 3.69 ms = 0.78 PFLOP/s.  Without the barrier stagger of the two wave groups
+//  below a wave's [fragment reads -> drain -> barrier -> 16 MFMAs] is serial and the two workgroups of a SIMD do not alternate by themselves.  Removed;
+//  git history at commit aa6b3aa, numbers in profiles/r04_two_wg_dw_tile.txt, DESIGN_LOG.md R4.2.)
 
 // ---------------------------------------------------------------- host side
 void* gemm_bf16_256_anatomy() { return MEAS_SYMBOL(g_anat256); }
@@ -704,8 +495,6 @@ static int launch256(hipStream_t s, const GemmArgs& a0, const dmvae_adam_ctx* ct
     }
 }
 
-static int g_dw_two_wg = 0;     // tuning knob (dmvae_debug_set_knob 15): the merged dW grid on 256 x 128 tiles, two workgroups per CU (1) or 256 x 256, one (0)
-void gemm_bf16_256_set_two_wg(int v) { g_dw_two_wg = v; }
 static int g_stagger = 0;       // tuning knob (dmvae_debug_set_knob 8): first-tile delay of the merged dW grid, units of 3.4 us spread over the 256 CUs.
                                 // MEASURED at cfg5 (tools/knob_cfg5.py 8 -1 0 12 24 48): one launch per problem 7.07 ms; merged, no delay 6.89;
                                 // delays 12 / 24 / 48 units 7.01 / 7.01 / 7.11 -- the tiles drift apart by themselves, a forced stagger only costs
@@ -720,16 +509,14 @@ static int launch256_dw_multi(hipStream_t s, const GemmArgs* probs, int n, const
     if (ctx) m.ac = *ctx;
     int total = 0, extra = 0;
     double flops = 0.0, bytes = 0.0;
-    const bool two = g_dw_two_wg != 0;          // 256 x 128 tiles, two 4-wave workgroups per CU (gemm256x128_dw_tile)
     for (int i = 0; i < n; ++i) {
         GemmArgs a = probs[i];
-        const int tiles = (a.M / 256) * (a.N / (two ? 128 : 256));
+        const int tiles = (a.M / 256) * (a.N / 256);
         const int nsl = (a.k_split > 0 && a.k_split < a.K) ? a.K / a.k_split : 1;
         if (nsl > 1 && (EPI != DMVAE_EPI_STORE_F32 || !a.slab_stride || a.epi.out2 || a.k_split % BK)) {
             set_error("gemm_bf16_256 (merged dW): K slices need the STORE_F32 epilogue into slabs and no fused bias gradient"); return DMVAE_EINVAL;
         }
-        a.group_m = two ? gemm_auto_group_m(a.M / 256, a.N / 128, 256, 128, std::max(1.0, std::min(tiles, 512) / 8.0))
-                        : gemm_auto_group_m(a.M / 256, a.N / 256, 256, 256, std::max(1.0, std::min(tiles, 256) / 8.0));
+        a.group_m = gemm_auto_group_m(a.M / 256, a.N / 256, 256, 256, std::max(1.0, std::min(tiles, 256) / 8.0));
         m.p[i] = a;
         m.nsl[i] = nsl;
         m.start[i] = total; total += tiles * nsl;
@@ -737,7 +524,7 @@ static int launch256_dw_multi(hipStream_t s, const GemmArgs* probs, int n, const
         if (a.epi.out2) {
             if (!a.csum_in || a.csum_ld != a.N) { set_error("gemm_bf16_256 (merged dW): a problem with a bias gradient needs its column-sum partials"); return DMVAE_EINVAL; }
             m.bs[i].part = a.csum_in; m.bs[i].nslab = a.csum_rows; m.bs[i].n = a.N; m.bs[i].out = reinterpret_cast<float*>(a.epi.out2);
-            extra += two ? std::min(16, (a.N / 4 + 255) / 256) : std::min(8, (a.N / 4 + 511) / 512);
+            extra += std::min(8, (a.N / 4 + 511) / 512);
         }
         flops += 2.0 * a.M * a.N * (double)a.K;
         bytes += 2.0 * ((double)a.M * a.K + (double)a.K * a.N);
@@ -747,10 +534,8 @@ static int launch256_dw_multi(hipStream_t s, const GemmArgs* probs, int n, const
     for (int i = n; i <= MULTI_MAX; ++i) { m.start[i] = total; m.extra[i] = extra; }
     for (int i = n; i < MULTI_MAX; ++i) m.nsl[i] = 1;
     static const std::string nm = std::string("gemm_bf16_256_dw_multi_kernel<") + std::to_string(EPI) + ">";
-    static const std::string nm2 = std::string("gemm_bf16_256x128_dw_multi_kernel<") + std::to_string(EPI) + ">";
-    ProfScope ps(s, two ? nm2.c_str() : nm.c_str(), flops, bytes);
-    if (two) DMVAE_LAUNCH((gemm_bf16_256x128_dw_multi_kernel<EPI>), dim3(total + extra), dim3(256), 0, s, m);
-    else DMVAE_LAUNCH((gemm_bf16_256_dw_multi_kernel<EPI>), dim3(total + extra), dim3(512), 0, s, m);
+    ProfScope ps(s, nm.c_str(), flops, bytes);
+    DMVAE_LAUNCH((gemm_bf16_256_dw_multi_kernel<EPI>), dim3(total + extra), dim3(512), 0, s, m);
     return check_launch("gemm_bf16_256_dw_multi");
 }
 bool gemm_bf16_256_rides() { return g_policy256 >= 1 && g_stagger >= 0; }

@@ -28,7 +28,6 @@ bool gemm_bf16_256_ok(int layout, int epi, int M, int N, int K, bool conv);
 int gemm_bf16_256_launch(hipStream_t s, int layout, const GemmArgs& a, const dmvae_adam_ctx* ctx = nullptr);
 void gemm_bf16_256_set_policy(int v);
 void gemm_bf16_256_set_stagger(int v);
-void gemm_bf16_256_set_two_wg(int v);
 bool gemm_bf16_256_slice_ok(int M, int N, int k_split);   // may K slices of this dW problem run on the macro tile (into slabs)?
 bool gemm_bf16_256_rides();      // policy: may sub-chip problems ride in the merged dW grid (knob 6 >= 1, merging on)
 int gemm_bf16_256_dw_all(hipStream_t s, const GemmArgs* probs, int n, const dmvae_adam_ctx* ctx);

@@ -160,19 +160,6 @@ def test_gemm256_weight_gradient_group_with_bias_and_fused_adam(hip256):
     _dw_group_case(hip256, 512)
 
 
-@pytest.mark.parametrize("K", [64, 128, 192, 320, 384, 512, 704, 2048])
-def test_gemm256x128_two_workgroup_tile_weight_gradient_group(hip256, K):
-    """the same on the 256 x 128 tile with two workgroups per CU (knob 15; csrc/gemm_bf16_256.hip gemm256x128_dw_tile): 1 .. 32 K tiles
-    through its five-buffer half-tile ring -- one K tile, fewer than a ring's worth, whole and partial passes of the five-fold
-    unrolled loop, the dummy refills past the K range -- with the bias-gradient workgroups and the fused Adam."""
-    L = hip256
-    L.check(L.lib.dmvae_debug_set_knob(15, 1))
-    try:
-        _dw_group_case(L, K)
-    finally:
-        L.check(L.lib.dmvae_debug_set_knob(15, 0))
-
-
 def _dw_group_case(L, K):
     shapes = [(512, 768), (256, 256), (192, 256), (512, 64), (1024, 512)]
     rng = np.random.RandomState(9)
