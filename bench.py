@@ -381,6 +381,11 @@ def main():
     rows = []
     if args.profile_steps > 0:
         torch.cuda.synchronize()
+        if sync is not None and getattr(sync, "enabled", False):
+            # the eager steps below are FUSED single-process steps (Adam over the whole arena): after sharded data-parallel steps a rank's
+            # fp32 master is current on its own slice only, and the engine refuses to update stale weights -- bring it up to date first
+            # (a collective: every rank runs this leg)
+            eng.sync_master(ex)
         prof_enable(True)
         import ctypes
         for _ in range(args.profile_steps):

@@ -589,6 +589,10 @@ class StepEngine:
         torch.cuda.synchronize(self.device)
         self.param.copy_(saved[0]); self.m.copy_(saved[1]); self.v.copy_(saved[2]); self.state_t.copy_(saved[3])
         self.grad.zero_()
+        # the whole fp32 arena has just been restored: whatever the sharded warm-up steps left stale outside this rank's slice is gone
+        # (without this the guard of refresh_shadow refused -- every multi-rank bench.py / train_op run failed here: found by the
+        # two-rank rehearsal, now tests/test_gpu_step.py::test_captured_step_under_the_sharded_exchange_two_ranks)
+        self._master_stale = False
         self.refresh_shadow()
         torch.cuda.synchronize(self.device)
         if grad_sync is None:

@@ -560,3 +560,65 @@ def test_deep_stack_more_than_sixteen_weight_gradients():
     torch.cuda.synchronize()
     for name in ("param", "m", "v", "param_bf16"):
         assert torch.equal(getattr(plain, name), getattr(fused, name)), name
+
+
+def _captured_dp_rank(rank, world, port, out):
+    """bench.py's and train_op's multi-rank form: capture_step (warm-up steps, state restored, then the eager data-parallel step callable)
+    under the sharded bf16 exchange, device noise, batch cursor in the device state"""
+    import torch.distributed as dist
+    for p in (os.path.join(ROOT, "deep-mixture-vae_amd"), os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), DMVAE_DP_MODE="sharded", DMVAE_DP_OVERLAP="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dmvae_hip import StepEngine, make_exchange
+    kw, B = dict(input_dim=784, latent_dim=64, n_classes=10), 256
+    g = torch.Generator(device="cuda"); g.manual_seed(5 + rank)
+    data = torch.rand((4 * B, 784), device="cuda", generator=g)
+    perm = torch.randperm(4 * B, device="cuda", generator=g).to(torch.int32)
+    eng = StepEngine(dtype="bf16", max_batch=B, mode="exact", seed=77 + rank, **kw)
+    eng.init_parameters(3)
+    ex = make_exchange(4 * eng.param.numel())
+    assert ex.enabled and ex.sharded and ex.world == world
+    p0 = eng.param.clone()
+    eng.reset_epoch(4, kl_ratio=1.0)
+    step = eng.capture_step(data, perm, grad_sync=ex, grad_scale=ex.grad_scale)      # (raised in refresh_shadow before the fix)
+    assert torch.equal(eng.param, p0) and not eng._master_stale                           # the warm-up steps left no trace
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    stale = bool(eng._master_stale)
+    refused = False
+    try:
+        eng.get_parameters()
+    except RuntimeError:
+        refused = True
+    eng.sync_master(ex)                        # collective
+    params = eng.get_parameters()
+    out.put((rank, stale, refused, eng.param.cpu().numpy(), eng.param_bf16.float().cpu().numpy(), eng.read_state().adam_t,
+             bool(all(np.isfinite(v).all() for v in params.values()))))
+    dist.destroy_process_group()
+
+
+def test_captured_step_under_the_sharded_exchange_two_ranks():
+    """capture_step + sharded bf16 exchange + world 2 -- the path `bench.py --gpus N` and `train_op` take on a node.  Round 4's stale-master
+    guard made capture_step's own refresh_shadow refuse after its warm-up steps, so every multi-rank run died before its
+    first step; no test took this path (the one-rank RCCL test has nothing stale, the two-rank tests step without capture).  Here: it
+    captures, three steps run, the replicas agree in every bit a step reads and -- after sync_master -- in the fp32 master; before the
+    sync the master IS stale and get_parameters refuses."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_captured_dp_rank, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[1] and r[2] and r[5] == 3 and r[6], r[:3] + r[5:]      # stale before the sync, get_parameters refused, three Adam steps, finite
+    np.testing.assert_array_equal(res[0][4], res[1][4])                  # the bf16 shadow: identical on both ranks
+    np.testing.assert_array_equal(res[0][3], res[1][3])                  # the fp32 master after sync_master
