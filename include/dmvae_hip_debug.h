@@ -66,7 +66,11 @@ int dmvae_debug_set_tile(int bm, int bn);
  *             knob 11 = with K slices: the 256-divisible layers' slices on the 256x256 macro tile (1, default) or everything on the small tiles (0)
  *             knob 9  = waves per workgroup of a grouped dX launch (0 / 4 = four, 8 = eight at <= 128 VGPRs; tools/heads_dx_probe.py, tools/knob_step.py:
  *                       85.6 vs 90.0 us alone at 16384 rows, 0.9785 vs 0.9651 ms in the step -- four)
- *             knob 12 = the dX of the two head layers as one grouped launch (0 / 1, default) or as two launches (2: 0.9424 vs 0.9366 ms at 16384 rows) */
+ *             knob 12 = the dX of the two head layers as one grouped launch (0 / 1, default) or as two launches (2: 0.9424 vs 0.9366 ms at 16384 rows),
+ *             knob 13 = that dX on the streaming kernel (csrc/heads_dx.hip; 1, default, when every problem of the group has K = 64 / 128 / 256) or
+ *                       on the grouped tiles (0): the pair alone 20.4 -> 17.4 us at 4096 rows, 80.3 -> 76.8 us at 16384; step -0.6 % at 16384 rows,
+ *             knob 14 = blocks the latent kernel's geometry aims at (512; rows per block = 16 .. 64).  The plan sizes its partial sums for the largest
+ *                       count and takes the count at enqueue time, so it may change while a plan exists.  1024 at 16384 rows: 0.9500 vs 0.9493 ms */
 int dmvae_debug_set_knob(int which, int value);
 
 #ifdef __cplusplus
