@@ -123,6 +123,8 @@ static int g_dw_slices = 0;
 // tuning knob (dmvae_debug_set_knob 11): with K slices, the layers whose shape divides by 256 on the macro tile (1, default) or every
 // layer on the small tiles (0)
 static int g_dw_macro = 1;
+static int g_fin_rides = 1;                 // tuning knob (dmvae_debug_set_knob 16): the step_finalize blocks ride in the dZ GEMM where it has the room, else in the heads' dX launch
+                                            // (1, default); always in the heads' dX launch (2); a launch of their own (0)
 static int g_heads_dx_form = 0;             // tuning knob (dmvae_debug_set_knob 12): the dX of the two head layers as one grouped launch (0 / 1) or as two launches (2)
 
 // ====================================================================== plan
@@ -865,7 +867,16 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     // (wide heads -- the 4096-wide configuration -- take the 256x256 macro-tile kernel one by one instead of the grouped grid)
     const bool heads_big = dt == DMVAE_BF16 && gemm_bf16_256_ok(DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK, p->Bp, p->Hp, 2 * p->Dp, false) &&
                            gemm_bf16_256_ok(DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK, p->Bp, p->Hp, p->Kp, false);
-    const bool fin_rides = all && dt == DMVAE_BF16 && !heads_big && !p->vade;
+    const bool fin_rides = all && dt == DMVAE_BF16 && !heads_big && !p->vade && g_fin_rides;
+    // ... and WHERE they ride.  In the heads' dX launch (every slot of the chip taken by a real workgroup) they cost that launch 2.2 us at 4096 rows
+    // (MEASURED, knob 16: 19.4 us with them, 17.2 without; as a launch of their own +4.3 us per step).  The dZ GEMM two launches earlier has
+    // their inputs too (it runs behind the reconstruction layer) and, while tiles + riders <= 256, leaves every rider a CU of its own.
+    bool fin_in_dz = false;
+    if (fin_rides && g_fin_rides == 1) {
+        const int t = gemm_bf16_tile_m(p->Bp, p->Dp, 1);
+        const int lead = (fin.nblocks + 7) & ~7;
+        fin_in_dz = (p->Bp / (t / 1000)) * (p->Dp / (t % 1000)) + lead <= 256;
+    }
   if (all || stage == 0) {
     p->dw_queue.clear();
     p->csum_of.clear();
@@ -943,6 +954,11 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
             memset(&e, 0, sizeof(e));
             e.kind = DMVAE_EPI_LATENT; e.out = WS(p, p->o_dmv); e.ldo = 2 * p->Dp; e.d_off = p->Dp;
             e.aux0 = la.gmu; e.ld0 = p->Dp; e.aux1 = la.glv; e.ld1 = p->Dp; e.aux2 = la.clv; e.ld2 = p->Dp;
+            if (fin_in_dz) {      // the step_finalize blocks ride here (see fin_in_dz above)
+                GemmArgs ga;
+                TRY(gemm_checked(s, dt, DMVAE_GEMM_DX, p->Bp, p->Dp, L.out_pad, WS(p, p->o_ddec[0]), L.out_pad, Wp(p, L.w_off), L.ldw, &e, 1, &ga));
+                TRY(gemm_bf16_dispatch(s, DMVAE_GEMM_DX, ga, 1, &fin));
+            } else
             TRY(gemm_checked(s, dt, DMVAE_GEMM_DX, p->Bp, p->Dp, L.out_pad, WS(p, p->o_ddec[0]), L.out_pad, Wp(p, L.w_off), L.ldw, &e, 1));
         }
     }
@@ -967,9 +983,9 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
                      const_cast<void*>(act_off(p, p->o_dhzc, p->Hp)), 2 * p->Hp, grp ? &q[1] : nullptr, WS(p, p->o_dhzc), p->o_cs_dhzc, 2 * p->Hp, p->Hp));
         if (grp && g_heads_dx_form == 2) {       // z-hidden as its own launch, c-hidden (and the riding finalize blocks) as a group of one
             TRY(gemm_bf16_dispatch(s, DMVAE_GEMM_DX, q[0], 1));
-            TRY(gemm_bf16_grouped(s, DMVAE_GEMM_DX, q + 1, 1, fin_rides ? &fin : nullptr));
+            TRY(gemm_bf16_grouped(s, DMVAE_GEMM_DX, q + 1, 1, (fin_rides && !fin_in_dz) ? &fin : nullptr));
         } else
-        if (grp) TRY(gemm_bf16_grouped(s, DMVAE_GEMM_DX, q, 2, fin_rides ? &fin : nullptr));
+        if (grp) TRY(gemm_bf16_grouped(s, DMVAE_GEMM_DX, q, 2, (fin_rides && !fin_in_dz) ? &fin : nullptr));
     }
     // ---- backward: trunk
     TRY(grad_dense(p, s, WS(p, p->o_enc[ne - 1]), p->Tp, p->Tp, WS(p, p->o_dhzc), 2 * p->Hp, 2 * p->Hp, p->zc.w_off, p->zc.ldw, p->zc.b_off));
@@ -1269,6 +1285,7 @@ extern "C" int dmvae_debug_set_knob(int which, int value) {
     if (which == 11) { g_dw_macro = value; return 0; }
     if (which == 12) { g_heads_dx_form = value; return 0; }
     if (which == 13) { heads_dx_stream_set(value); return 0; }
+    if (which == 16) { g_fin_rides = value; return 0; }
     if (which == 14) { latent_set_blocks_target(value); return 0; }      // (the block count in use is taken at enqueue time and checked against the plan's capacity)
     DMVAE_REQUIRE(which >= 0 && which <= 9 && which != 3, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, (3: removed, the deep-ring policy), 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy, 7 = short-K workgroups, 8 = first-tile stagger of the merged dW grid, 9 = waves per workgroup of a grouped dX launch; 10 / 11 = K slices of the dW groups, 12 = heads dX as one or two launches, 13 = heads dX on the streaming kernel (1) or the grouped tiles (0), 14 = blocks the latent kernel's geometry aims at (512)");
     gemm_bf16_set_knob(which, value);

@@ -478,6 +478,21 @@ __global__ __launch_bounds__(64 * NW, (EPI == DMVAE_EPI_BIAS_RECON ? 1 : NW / 2)
     gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW>(a, blockIdx.x, 0, gridDim.x, smem);
 }
 
+// The dZ GEMM (DX layout, LATENT epilogue) carrying the step_finalize blocks (common.h) as RIDERS: `lead` (a multiple of 8, so that id % 8 -- the
+// XCD a workgroup lands on -- stays what the tile mapping assumes) extra workgroups hold the first ids of the grid, the first fin.nblocks of them run
+// step_finalize_block.  At 4096 rows this launch is 64 workgroups on a 256-CU chip: every rider gets a CU of its own -- in the heads' dX launch, which
+// fills every slot of the chip, the same riders cost that launch 2.2 us (MEASURED round 4, knob 16).  Same tile code, same bits.
+template <int BM, int BN, int NSTAGE, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_bf16_dz_riders_kernel(GemmArgs a, dmvae_finalize_args fin, int lead) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * (BM + BN) * BK];
+    if ((int)blockIdx.x < lead) {
+        if (NW > 4 && threadIdx.x >= 256) return;          // (step_finalize_block is written for four waves; a finished wave leaves the barrier count)
+        if ((int)blockIdx.x < fin.nblocks) step_finalize_block((int)blockIdx.x, fin, reinterpret_cast<float(*)[17]>(smem));
+        return;
+    }
+    gemm_bf16_body<BM, BN, DMVAE_GEMM_DX, DMVAE_EPI_LATENT, NSTAGE, NW>(a, (int)blockIdx.x - lead, lead, (int)gridDim.x - lead, smem);
+}
+
 // The same tile in conv mode (implicit 3x3 convolution, csrc/conv.hip): its own kernel, so the dense
 // instantiations above are bit-for-bit what they were (a run-time flag in their K loop cost 1.6 % of the step).
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW>
@@ -629,9 +644,17 @@ static double gemm_bytes(const GemmArgs& a, int layout = DMVAE_GEMM_FWD) {    //
 }
 
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4>
-static int launch(hipStream_t s, const GemmArgs& a, int split) {
+static int launch(hipStream_t s, const GemmArgs& a, int split, const dmvae_finalize_args* riders = nullptr) {
     dim3 grid((a.M / BM) * (a.N / BN), split);
     ProfScope ps(s, kernel_name<BM, BN, LAYOUT, EPI, NSTAGE, NW>(false), 2.0 * a.M * a.N * (double)a.K, gemm_bytes(a));
+    if constexpr (LAYOUT == DMVAE_GEMM_DX && EPI == DMVAE_EPI_LATENT) {
+        if (riders && split == 1) {      // the step_finalize blocks ride in the first ids of this grid (gemm_bf16_dz_riders_kernel)
+            const int lead = (riders->nblocks + 7) & ~7;
+            DMVAE_LAUNCH((gemm_bf16_dz_riders_kernel<BM, BN, NSTAGE, NW>), dim3(grid.x + lead), dim3(64 * NW), 0, s, a, *riders, lead);
+            return check_launch("gemm_bf16 (dZ + riders)");
+        }
+    }
+    if (riders) { set_error("gemm_bf16: step_finalize riders are carried by the DX / LATENT launch only"); return DMVAE_EINVAL; }
     DMVAE_LAUNCH((gemm_bf16_kernel<BM, BN, LAYOUT, EPI, NSTAGE, NW>), grid, dim3(64 * NW), 0, s, a);
     return check_launch("gemm_bf16");
 }
@@ -930,7 +953,7 @@ int gemm_bf16_tile_m(int M, int N, int split) {
 // one wave per SIMD; a second resident workgroup fills the gaps):
 //   128x128: 2 x 32 KiB, 128x64 / 64x128: 3 x 24 KiB, 64x64: 4 x 16 KiB  (<= 72 KiB -> 2 blocks/CU)
 template <int LAYOUT, int EPI>
-static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split) {
+static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split, const dmvae_finalize_args* riders = nullptr) {
     GemmArgs a = a0;
     int t = gemm_bf16_tile_m(a.M, a.N, split);
     if (a.conv_c) {          // conv mode (csrc/conv.hip): the three (layout, epilogue) pairs a convolution layer uses
@@ -964,12 +987,13 @@ static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split) {
     //  17.1 vs 19.0 us; whole step at B = 16384: 1.0753 vs 1.0706 ms, at B = 8192 / D 256 / K 50: 0.8079 vs
     //  0.7922 ms.  Two resident workgroups overlapping their load / compute / store phases beat the
     //  smaller intake of one.)
+    if (riders && (a.conv_c || !(LAYOUT == DMVAE_GEMM_DX && EPI == DMVAE_EPI_LATENT))) { set_error("gemm_bf16: step_finalize riders are carried by the dense DX / LATENT launch only"); return DMVAE_EINVAL; }
     if (split == 1 && gemm_bf16_256_ok(LAYOUT, EPI, a.M, a.N, a.K, false)) return gemm_bf16_256_launch(s, LAYOUT, a);
     a.group_m = gemm_auto_group_m(a.M / (t / 1000), a.N / (t % 1000), t / 1000, t % 1000);
     if (g_shortk && a.K <= 128 && split == 1 && LAYOUT != DMVAE_GEMM_DW && EPI != DMVAE_EPI_BIAS_RECON) {
         // one or two K tiles: the workgroup is prologue + epilogue; small LDS footprint -> more workgroups per CU
         a.group_m = gemm_auto_group_m(a.M / 64, a.N / 64, 64, 64);
-        return launch<64, 64, LAYOUT, EPI, 2>(s, a, split);
+        return launch<64, 64, LAYOUT, EPI, 2>(s, a, split, riders);
     }
     // (A single DEEP ring for launches of at most one workgroup per CU -- 4 x 32 KiB for 128x128, 6 x 24 KiB for 128x64, i.e. one
     //  workgroup per CU by LDS -- was knob 3 until round 4: 0.2926 vs 0.2860 ms per step at cfg2; the K loop of a 4096x512x512 layer
@@ -977,19 +1001,19 @@ static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split) {
     //  the two-workgroups-per-CU register bound of the kernel template.)
     switch (t) {
         case 128128:
-            return g_nw8 ? launch<128, 128, LAYOUT, EPI, 2, 8>(s, a, split) : launch<128, 128, LAYOUT, EPI, 2>(s, a, split);
+            return g_nw8 ? launch<128, 128, LAYOUT, EPI, 2, 8>(s, a, split, riders) : launch<128, 128, LAYOUT, EPI, 2>(s, a, split, riders);
         case 128064:
             // (three workgroups per CU on a 2-slot 48 KiB ring: 0.331 vs 0.300 ms/step -- the long-K layers need the third slot)
-            return g_nw8 ? launch<128, 64, LAYOUT, EPI, 3, 8>(s, a, split) : launch<128, 64, LAYOUT, EPI, 3>(s, a, split);
-        case 64128: return launch<64, 128, LAYOUT, EPI, 3>(s, a, split);
-        default: return launch<64, 64, LAYOUT, EPI, 4>(s, a, split);
+            return g_nw8 ? launch<128, 64, LAYOUT, EPI, 3, 8>(s, a, split, riders) : launch<128, 64, LAYOUT, EPI, 3>(s, a, split, riders);
+        case 64128: return launch<64, 128, LAYOUT, EPI, 3>(s, a, split, riders);
+        default: return launch<64, 64, LAYOUT, EPI, 4>(s, a, split, riders);
     }
 }
 
-int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split) {
+int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split, const dmvae_finalize_args* riders) {
     const int epi = a.epi.kind;
 #define CASE(L, E) \
-    if (layout == L && epi == E) return launch_tiled<L, E>(s, a, split);
+    if (layout == L && epi == E) return launch_tiled<L, E>(s, a, split, riders);
     CASE(DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_RELU)
     CASE(DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_F32)
     CASE(DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_RECON)

@@ -15,7 +15,8 @@ struct AdamArgs {
 };
 
 #define DMVAE_MAX_GROUP 16
-int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split);
+// riders: the step_finalize blocks as extra workgroups of this launch (the dense DX / LATENT GEMM only: gemm_bf16_dz_riders_kernel)
+int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split, const dmvae_finalize_args* riders = nullptr);
 int gemm_bf16_grouped_dw(hipStream_t s, const GemmArgs* probs, int nprob);
 // fin: the step_finalize blocks ride as extra workgroups of this launch (DX / RELU_MASK groups only)
 int gemm_bf16_grouped(hipStream_t s, int layout, const GemmArgs* probs, int nprob, const dmvae_finalize_args* fin = nullptr);

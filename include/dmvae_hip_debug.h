@@ -70,7 +70,9 @@ int dmvae_debug_set_tile(int bm, int bn);
  *             knob 13 = that dX on the streaming kernel (csrc/heads_dx.hip; 1, default, when every problem of the group has K = 64 / 128 / 256) or
  *                       on the grouped tiles (0): the pair alone 20.4 -> 17.4 us at 4096 rows, 80.3 -> 76.8 us at 16384; step -0.6 % at 16384 rows,
  *             knob 14 = blocks the latent kernel's geometry aims at (512; rows per block = 16 .. 64).  The plan sizes its partial sums for the largest
- *                       count and takes the count at enqueue time, so it may change while a plan exists.  1024 at 16384 rows: 0.9500 vs 0.9493 ms */
+ *                       count and takes the count at enqueue time, so it may change while a plan exists.  1024 at 16384 rows: 0.9500 vs 0.9493 ms,
+ *             knob 16 = where the step_finalize blocks run: 1 (default) as riders of the dZ GEMM while tiles + riders <= 256 (4096 rows), else of the
+ *                       heads' dX launch; 2 always the heads' dX launch; 0 a launch of their own (0.2796 vs 0.2753 ms at 4096 rows) */
 int dmvae_debug_set_knob(int which, int value);
 
 #ifdef __cplusplus
