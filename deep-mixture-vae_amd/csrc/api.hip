@@ -1209,6 +1209,7 @@ extern "C" int dmvae_debug_spin(void* stream, int microseconds) { return spin_la
 extern "C" int dmvae_debug_stamps(void** device_ptr) {
     if (!device_ptr) return DMVAE_EINVAL;
     *device_ptr = gemm_bf16_stamps();
+    if (!*device_ptr) *device_ptr = heads_dx_phase_table();      // measurement build 10: the phase table of heads_dx.hip (measure.h)
     return *device_ptr ? 0 : DMVAE_ESTATE;
 }
 

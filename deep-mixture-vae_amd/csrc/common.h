@@ -22,8 +22,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 __device__ __forceinline__ float bf2f(bf16_t h) {
     return __uint_as_float(((unsigned int)h) << 16);
 }
+// both halves in ONE v_cvt_pk_bf16_f32 (two scalar converts cost a convert each and an or / sdwa to join them; same rounding)
 __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
-    return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const bf16x2_ h = __builtin_convertvector(f32x2_{lo, hi}, bf16x2_);
+    return __builtin_bit_cast(unsigned int, h);
 }
 
 // TF-1.x Adam (base_models.py:95-110), shared by the stand-alone kernel and the dW-epilogue form so

@@ -27,8 +27,12 @@
 // cfg3 (copy: 7.0 TB/s).  In the STEP (tools/knob_step.py <cfg> 13 0 1 1 0: one engine, graphs on the same buffers, same-value spread 0.15 %):
 // cfg2 0.2758 vs 0.2757 ms -- nothing; cfg3 0.9383 -> 0.9327 ms (-0.6 %); cfg4 does not take this kernel.  It does NOT reach the memory
 // system's rate (VERDICT r3 asked >= 5 TB/s): a step of the walk takes ~4 us, one HBM round trip -- the next tile's gates are requested
-// ONE step ahead and the step ends waiting for them.  Two or three tiles of gates in flight (by LDS-DMA into a ring: no register
-// destination, hence no hazard below) is what the numbers call for; not built.
+// ONE step ahead and the step ends waiting for them.  THAT READING WAS WRONG, and the two forms it called for were built and lose
+// (DESIGN_LOG.md R4.2, profiles/r04_heads_dx_phases.txt): per-workgroup phase sums (measurement build 10, tools/heads_dx_phases.py)
+// show a step waiting 0.08 us for its operands; with the gates three tiles ahead by LDS-DMA the rate did not move, and with the park
+// removed as well (columns of W permuted so that a lane stores 16 B straight from its accumulators, 16 rows x 64 B per wave
+// instruction; half the VALU work, one barrier per step instead of three) it FELL: 17.8 vs 17.2 us at cfg2, 79.7 vs 71.3 at cfg3 -- the
+// vector-memory path of a CU is what is busy, it serves requests in order, and it prefers this form's 4 rows x 256 B per instruction.
 // Arithmetic: the same v_mfma_f32_16x16x32_bf16 chain per output element, k ascending, as gemm_bf16_body -- bit-identical results
 // (tests/test_gpu_kernels.py::test_heads_dx_stream_equals_the_grouped_kernel, and every step test runs through it).
 #include <algorithm>
@@ -36,8 +40,11 @@
 #include <type_traits>
 
 #include "gemm_tile.h"
+#include "measure.h"
 
 namespace dmvae {
+MEAS_TABLES_HDX
+void* heads_dx_phase_table() { return MEAS_SYMBOL_HDX(g_hdx); }      // (nullptr in the product build, measure.h)
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -111,6 +118,7 @@ __device__ __forceinline__ void heads_dx_body(const GemmArgs& a, const int slice
     };
 
     // ---- prologue (branch-free).  Issue order:  W slice | gates of tile 0 | dY block 0
+    MEAS_HDX_BEGIN();
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) glds_tile(Wg + kt * 64, goW, lds_x + 2u * (unsigned)(kt * CW * 64), 4096u);
     bf16x8 wf[CB][KS];                                   // this wave's W fragments: resident for the whole walk
@@ -120,6 +128,7 @@ __device__ __forceinline__ void heads_dx_body(const GemmArgs& a, const int slice
         issue_a(0);
         wait_vmcnt<NQ + NAG>();                          // the W slice has landed (this wave's share)
         __builtin_amdgcn_s_barrier();
+        MEAS_HDX_MARK(1);
 #pragma unroll
         for (int j = 0; j < CB; ++j)
 #pragma unroll
@@ -141,13 +150,16 @@ __device__ __forceinline__ void heads_dx_body(const GemmArgs& a, const int slice
     __builtin_amdgcn_s_barrier();                        // every wave has its W fragments: X is free for the park
 
     float* ct = reinterpret_cast<float*>(Xs);
+    MEAS_HDX_MARK(2);
     // One step, branch-free.  Issue order per wave:  ... || step s: dY block s + 1, gates(s + 1), stores(s) || step s + 1: ...
     auto step = [&](auto firstc, auto lastc, int s) {
         constexpr bool FIRST = decltype(firstc)::value, LAST = decltype(lastc)::value;
         // dY block s has landed (this wave's share): the first step waits for it here (nothing younger is outstanding); later steps
         // retired it with the wait for gates(s) at the end of step s - 1 (the block is older than those gates)
         if constexpr (FIRST) wait_vmcnt<0>();
+        MEAS_HDX_ACC(5);
         __builtin_amdgcn_s_barrier();
+        MEAS_HDX_ACC(6);
         bf16x8 af[2][KS];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -185,6 +197,7 @@ __device__ __forceinline__ void heads_dx_body(const GemmArgs& a, const int slice
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // the fp32 tile is parked
+        MEAS_HDX_ACC(7);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int ml = ml0 + q * RQ;
@@ -199,20 +212,24 @@ __device__ __forceinline__ void heads_dx_body(const GemmArgs& a, const int slice
             o[1] = pack2bf(v2, v3);
             gst2(out_p + ((int64_t)s * 64 + q * RQ) * a.epi.ldo, o);
         }
+        MEAS_HDX_ACC(8);
         if constexpr (!LAST) {
             wait_gates<NQ, NQ>(gn);                      // gates(s + 1) -- and the older dY block s + 1 -- have landed; younger: this tile's stores only
             park_gates(gn);                              // (this thread read its slots above: same thread, program order)
         }
+        MEAS_HDX_ACC(9);
         // (no barrier here: a wave writes the next park only behind the two barriers at the top of the next step, which it
         //  passes after every wave has finished its reads of this one)
     };
     using T = std::true_type; using F = std::false_type;
-    if (steps == 1) { step(T{}, T{}, 0); return; }
+    if (steps == 1) { step(T{}, T{}, 0); MEAS_HDX_END(steps); return; }
     step(T{}, F{}, 0);
     int s = 1;
     for (; s + 1 < steps; ++s) step(F{}, F{}, s);
     step(F{}, T{}, s);
+    MEAS_HDX_END(steps);
 }
+
 
 __global__ __launch_bounds__(256, 2) void heads_dx_stream_kernel(HeadsDxArgs h) {
     // 80 KiB: X (32 KiB) | dY slot (up to 64 x 256 bf16 = 32 KiB) | gate slots (16 KiB) -> two workgroups per CU (2 x 81920 B = the CU's 160 KiB)
@@ -244,7 +261,8 @@ void heads_dx_stream_set(int v) { g_heads_dx_stream = v; }
 
 static int heads_dx_kind(const GemmArgs& p) {
     if (p.conv_c || p.M % 64 || p.N % 128 || p.k_split != p.K || p.epi.kind != DMVAE_EPI_RELU_MASK || !p.epi.aux0 || !p.epi.out) return -1;
-    if ((p.lda * 2) % 16 || (p.ldb * 2) % 16 || p.epi.ld0 % 4 || p.epi.ldo % 4) return -1;
+    if ((p.lda * 2) % 16 || (p.ldb * 2) % 16 || p.epi.ld0 % 8 || p.epi.ldo % 8) return -1;
+    if (((uintptr_t)p.epi.aux0 | (uintptr_t)p.epi.out | (uintptr_t)p.A | (uintptr_t)p.B) % 16) return -1;      // 16-byte units: LDS-DMA of the gates, dwordx4 stores
     return p.K == 64 ? 0 : p.K == 128 ? 1 : p.K == 256 ? 2 : -1;
 }
 
@@ -269,20 +287,45 @@ int heads_dx_stream_launch(hipStream_t s, const GemmArgs* probs, int nprob, cons
         ++n;
     }
     if (n == 0) return 0;
-    int total_slices = 0;
-    for (int i = 0; i < n; ++i) total_slices += h.p[i].N / (h.kind[i] == 2 ? 64 : 128);
+    // Row chunks per problem.  ONE round of the chip (two resident workgroups per CU = 512 slots) where the batch allows -- never more than 512
+    // workgroups: rounding the chunk count to nearest gave 528 at 16 384 rows with D = 128, and the 16 workgroups of the second round started when
+    // the first ones ended (launch span 72 us for walks of 45-56 us) -- and at least two steps each.  With two problems the slots are shared so
+    // that the walks END together: a step costs 2.1-2.2 us on a 128-column slice, 1.9 on a 64-column one (measurement build 10,
+    // profiles/r04_heads_dx_phases.txt: with equal step counts the 128-column workgroups of cfg3 ran 60 us, the others 52).
+    auto step_cost = [](int kind) { return kind == 2 ? 1.93 : kind == 1 ? 2.10 : 2.20; };
+    auto shape = [&](int i, int want, int& chunks, int& steps) {
+        const int tiles = h.p[i].M / 64;
+        chunks = std::max(1, std::min(tiles, want));
+        steps = (tiles + chunks - 1) / chunks;
+        if (steps < 2 && tiles >= 2) steps = 2;
+        chunks = (tiles + steps - 1) / steps;
+    };
+    int nsl[2] = {0, 0};
+    for (int i = 0; i < n; ++i) nsl[i] = h.p[i].N / (h.kind[i] == 2 ? 64 : 128);
+    if (n == 1) {
+        shape(0, 512 / nsl[0], h.chunks[0], h.steps[0]);
+    } else {
+        double best = 1e30;
+        for (int c0 = 1; c0 * nsl[0] < 512; ++c0) {
+            const int c1 = (512 - c0 * nsl[0]) / nsl[1];
+            if (c1 < 1) break;
+            int ch0, st0, ch1, st1;
+            shape(0, c0, ch0, st0);
+            shape(1, c1, ch1, st1);
+            if (ch0 * nsl[0] + ch1 * nsl[1] > 512) continue;
+            const double t = std::max(st0 * step_cost(h.kind[0]), st1 * step_cost(h.kind[1]));
+            if (t < best) { best = t; h.chunks[0] = ch0; h.steps[0] = st0; h.chunks[1] = ch1; h.steps[1] = st1; }
+        }
+        if (best == 1e30) {                // (cannot happen for the shapes heads_dx_kind admits; the caller then launches the grouped tiles)
+            for (int i = 0; i < nprob; ++i) taken[i] = false;
+            return 0;
+        }
+    }
     int total = 0;
     for (int i = 0; i < n; ++i) {
         const GemmArgs& p = h.p[i];
-        const int nsl = p.N / (h.kind[i] == 2 ? 64 : 128), tiles = p.M / 64;
-        // ONE round of the chip (two resident workgroups per CU = 512 slots) where the batch allows, and at least two steps each
-        int chunks = std::max(1, std::min(tiles, (512 + total_slices / 2) / total_slices));
-        int steps = (tiles + chunks - 1) / chunks;
-        if (steps < 2 && tiles >= 2) steps = 2;
-        chunks = (tiles + steps - 1) / steps;
-        h.chunks[i] = chunks; h.steps[i] = steps;
         h.start[i] = total;
-        total += chunks * nsl;
+        total += h.chunks[i] * nsl[i];
         flops += 2.0 * p.M * p.N * (double)p.K;
         bytes += 2.0 * ((double)p.M * p.K + (double)p.K * p.N) + 2.0 * p.M * p.N;
     }

@@ -34,6 +34,7 @@ bool gemm_bf16_256_rides();      // policy: may sub-chip problems ride in the me
 int gemm_bf16_256_dw_all(hipStream_t s, const GemmArgs* probs, int n, const dmvae_adam_ctx* ctx);
 // streaming form of the dX of the two head layers (heads_dx.hip): takes the problems of a grouped DX / RELU_MASK launch with K = 64 / 128 / 256
 // (taken[i]) as one launch, the riding step_finalize blocks with them; the caller launches whatever is left as before
+void* heads_dx_phase_table();      // measurement build 10 only (measure.h); nullptr otherwise
 int heads_dx_stream_launch(hipStream_t s, const GemmArgs* probs, int nprob, const dmvae_finalize_args* fin, bool* taken);
 void heads_dx_stream_set(int v);
 void gemm_bf16_force_tile(int t);

@@ -11,6 +11,8 @@
 //   7  phase timeline of block 0 of the latent kernel (tools/latent_time.py)
 //   8  no ReLU-mask read in the dX epilogue (the upper bound of what a 1-bit mask could save)
 //   9  no bias-gradient MFMAs in the first tile row of the weight-gradient tiles (the upper bound of moving that work elsewhere; bias gradients are then zero)
+//  10  phase split of every workgroup of heads_dx.hip (tools/heads_dx_phases.py): shader-clock sums per phase, kept in registers
+//      until the workgroup ends (a stamp STORE inside the walk would count in the walk's own vmcnt arithmetic)
 // Stamp values go to tables of their own (or, build 7, behind the loss partials in the caller's buffer); no output is computed
 // from them (MI355X_MICROARCH.md, DVFS give-back item 6).
 #pragma once
@@ -86,6 +88,35 @@ constexpr bool MEAS_STAMPS = DMVAE_ABLATE == 6;
 #define MEAS_ANAT256(i) do { } while (0)
 #define MEAS_ANAT256_DRAIN() do { } while (0)
 #define MEAS_SYMBOL(sym) (static_cast<void*>(nullptr))      // the product build has no stamp tables: dmvae_debug_* report DMVAE_ESTATE
+#endif
+
+#if DMVAE_ABLATE == 10  // heads_dx.hip: g_hdx[wg][16] = {entry, W landed, W fragments read + tile 0's gates parked, end of walk, stores acknowledged (s_memtime cycles),
+                       //   sums over the steps: [5] wait for dY (first step only), [6] barrier behind it, [7] fragments .. park barrier, [8] epilogue (stores issued),
+                       //   [9] wait for the next tile's gates + their park; [10], [11] entry and end in 100 MHz ticks, [12] HW_ID << 32 | XCC_ID, [13] steps}
+#define MEAS_TABLES_HDX __device__ unsigned long long g_hdx[1024 * 16];
+#define MEAS_HDX_BEGIN() unsigned long long hx_[12] = {}; unsigned long long hx_last_; hx_[0] = __builtin_amdgcn_s_memtime(); hx_[10] = __builtin_amdgcn_s_memrealtime()
+#define MEAS_HDX_MARK(i) do { hx_last_ = __builtin_amdgcn_s_memtime(); hx_[i] = hx_last_; } while (0)
+#define MEAS_HDX_ACC(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); hx_[i] += t_ - hx_last_; hx_last_ = t_; } while (0)
+#define MEAS_HDX_END(steps)                                                                                                        \
+    do {                                                                                                                           \
+        MEAS_HDX_MARK(3);                                                                                                          \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                           \
+        MEAS_HDX_MARK(4);                                                                                                          \
+        hx_[11] = __builtin_amdgcn_s_memrealtime();                                                                                \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                                               \
+            for (int i_ = 0; i_ < 12; ++i_) g_hdx[blockIdx.x * 16 + i_] = hx_[i_];                                                 \
+            g_hdx[blockIdx.x * 16 + 13] = (unsigned long long)(steps);                                                             \
+            g_hdx[blockIdx.x * 16 + 12] = (((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20)); \
+        }                                                                                                                          \
+    } while (0)
+#define MEAS_SYMBOL_HDX(sym) ([] { void* p_ = nullptr; return hipGetSymbolAddress(&p_, HIP_SYMBOL(sym)) == hipSuccess ? p_ : nullptr; }())
+#else
+#define MEAS_TABLES_HDX
+#define MEAS_HDX_BEGIN() do { } while (0)
+#define MEAS_HDX_MARK(i) do { } while (0)
+#define MEAS_HDX_ACC(i) do { } while (0)
+#define MEAS_HDX_END(steps) do { } while (0)
+#define MEAS_SYMBOL_HDX(sym) (static_cast<void*>(nullptr))
 #endif
 
 #if DMVAE_ABLATE == 7   // latent.hip: phase timeline of block 0, behind the loss partials (100 MHz ticks)
