@@ -22,9 +22,10 @@ for M, N, K, lay in shapes:
     bias = torch.zeros(N, device="cuda"); junk = torch.empty(64 << 20, device="cuda")
     e = L.Epilogue(); e.kind = L.EPI_BIAS_RELU if lay == 0 else L.EPI_RELU_MASK
     e.out, e.ldo, e.bias, e.aux0, e.ld0 = out.data_ptr(), N, bias.data_ptr(), Y.data_ptr(), N
-    for mode in ("hot",):
+    for mode in os.environ.get("ANATOMY_MODES", "hot").split(","):      # hot | mall (48 MB written between launches: out of the L2s, still in the Infinity Cache) | cold (256 MB)
         for _ in range(3):
             if mode == "cold": junk.fill_(1.0)          # evict L2 / Infinity Cache between launches
+            if mode == "mall": junk[:12 << 20].fill_(1.0)
             t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
             t0.record()
             L.check(L.lib.dmvae_gemm(st, 1, lay, M, N, K, L.ptr(A), K, L.ptr(B), N if lay == 0 else K, C.byref(e), 1))
