@@ -124,6 +124,7 @@ static int g_dw_slices = 0;
 // tuning knob (dmvae_debug_set_knob 11): with K slices, the layers whose shape divides by 256 on the macro tile (1, default) or every
 // layer on the small tiles (0)
 static int g_dw_macro = 1;
+static int g_pf_rides = 1;                  // tuning knob (dmvae_debug_set_knob 17): a prefetched batch's gather rides in the dZ GEMM where it has the room (1), or is a launch of its own (0)
 static int g_fin_rides = 1;                 // tuning knob (dmvae_debug_set_knob 16): the step_finalize blocks ride in the dZ GEMM where it has the room, else in the heads' dX launch
                                             // (1, default); always in the heads' dX launch (2); a launch of their own (0)
 static int g_heads_dx_form = 0;             // tuning knob (dmvae_debug_set_knob 12): the dX of the two head layers as one grouped launch (0 / 1) or as two launches (2)
@@ -203,6 +204,12 @@ struct dmvae_plan {
     bool tsrc_used = false;           // a forward pass has consumed that batch: the device cursor has moved on (step_finalize), so a second
                                       // pass without a reload would pair the old bf16 batch with the NEXT batch's targets -- refused
     bool tgt_gather = false;          // the plan is eligible
+    // dmvae_plan_prefetch_batch: the NEXT batch is assembled while this step runs -- by workgroups riding in the trunk's dX launch where that
+    // launch leaves them CUs of their own (forward_backward_impl), else by a gather launch of its own -- into the OTHER of two bf16 batch
+    // buffers; dmvae_plan_swap_batch then makes it the current one.  The step itself no longer starts with a gather.
+    int64_t o_x2 = -1;                // the second bf16 batch buffer (bf16 dense plans)
+    int xsel = 0;                     // the current one
+    struct { const float* data; int64_t n_rows; const int32_t* perm; int64_t first; int n_valid; const void* st; bool armed, done; dmvae_gather_args gat; } pf{};
     bool vade = false;                // cfg.model == DMVAE_MODEL_VADE: no head hidden layers, no logits; latent mode 2
     // bias gradients of the macro-tile path: the GEMM that PRODUCES a dY (256x256 kernel, ReLU-gate / recon epilogue) leaves
     // its column sums per 256-row tile, [Bp/256][width] floats per dY tensor; the dW problem of that layer picks them up
@@ -333,6 +340,7 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
     const int64_t Bp = p->Bp, es = p->es;
     p->o_xf = take(Bp * p->Ip * 4);
     p->o_x = (c->dtype == DMVAE_F32) ? p->o_xf : take(Bp * p->Ip * es);
+    if (c->dtype == DMVAE_BF16 && p->conv.empty()) p->o_x2 = take(Bp * p->Ip * es);
     {
         int64_t wmax = 0;
         for (size_t i = 0; i < p->conv.size(); ++i) {
@@ -478,14 +486,16 @@ static inline const void* Wp(const dmvae_plan* p, int64_t off) {
                                       : (const void*)(p->buf.param + off);
 }
 static inline const void* act_off(const dmvae_plan* p, int64_t base, int64_t elems) { return WS(p, base) + elems * p->es; }
+static inline char* XB(const dmvae_plan* p, int other = 0) { return WS(p, ((p->xsel ^ other) && p->o_x2 >= 0) ? p->o_x2 : p->o_x); }      // the current (other = 1: the next) act copy of the batch
 
 extern "C" int dmvae_plan_load_batch(dmvae_plan* p, void* stream, const float* data, int64_t n_rows, const int32_t* perm,
                                      int64_t first, int n_valid, int use_state_cursor) {
     DMVAE_REQUIRE(p && p->bound && data, "dmvae_plan_load_batch: plan not bound / null data");
     DMVAE_REQUIRE(n_valid >= 0 && n_valid <= p->cfg.max_batch, "dmvae_plan_load_batch: n_valid=%d exceeds max_batch=%d", n_valid, p->cfg.max_batch);
     hipStream_t s = (hipStream_t)stream;
-    void* xa = p->cfg.dtype == DMVAE_BF16 ? (void*)WS(p, p->o_x) : nullptr;
+    void* xa = p->cfg.dtype == DMVAE_BF16 ? (void*)XB(p) : nullptr;
     p->tsrc_valid = false;
+    p->pf.armed = p->pf.done = false;
     return gather_launch(s, p->cfg.dtype, data, n_rows, p->cfg.input_dim, perm, first, p->cfg.max_batch, n_valid, p->Bp, xa, p->Ip,
                          reinterpret_cast<float*>(WS(p, p->o_xf)), p->Ip, p->Ip, use_state_cursor ? p->buf.state : nullptr);
 }
@@ -504,12 +514,39 @@ extern "C" int dmvae_plan_load_batch_step(dmvae_plan* p, void* stream, const flo
     p->tsrc.st = use_state_cursor ? p->buf.state : nullptr;
     p->tsrc_valid = true;
     p->tsrc_used = false;
+    p->pf.armed = p->pf.done = false;
     if constexpr (MEAS_NO_STEP_GATHER) {      // measurement build 11 only (measure.h): timing of a step without its gather
         static int calls = 0;
         if (++calls > 2) return 0;
     }
     return gather_launch((hipStream_t)stream, DMVAE_BF16, data, n_rows, p->cfg.input_dim, perm, first, p->cfg.max_batch, n_valid, p->Bp,
-                         WS(p, p->o_x), p->Ip, nullptr, p->Ip, p->Ip, use_state_cursor ? p->buf.state : nullptr);
+                         XB(p), p->Ip, nullptr, p->Ip, p->Ip, use_state_cursor ? p->buf.state : nullptr);
+}
+
+// Arms the assembly of the NEXT batch inside the next forward + backward pass (see dmvae_plan::pf); with use_state_cursor the rows are those
+// of the device cursor AFTER that pass's step_finalize has advanced it.  Needs a current batch assembled by dmvae_plan_load_batch_step (or
+// made current by dmvae_plan_swap_batch) on an eligible plan; `data` / `perm` must stay alive and unchanged until the step AFTER next has run.
+extern "C" int dmvae_plan_prefetch_batch(dmvae_plan* p, const float* data, int64_t n_rows, const int32_t* perm, int64_t first, int n_valid,
+                                         int use_state_cursor) {
+    DMVAE_REQUIRE(p && p->bound && data, "dmvae_plan_prefetch_batch: plan not bound / null data");
+    DMVAE_REQUIRE(n_valid >= 0 && n_valid <= p->cfg.max_batch, "dmvae_plan_prefetch_batch: n_valid=%d exceeds max_batch=%d", n_valid, p->cfg.max_batch);
+    if (!p->tgt_gather || p->o_x2 < 0) { set_error("dmvae_plan_prefetch_batch: this plan assembles its batches with dmvae_plan_load_batch (f32, conv trunk, or an output layer on the macro tile)"); return DMVAE_EUNSUPPORTED; }
+    DMVAE_REQUIRE(p->tsrc_valid && !p->tsrc_used, "dmvae_plan_prefetch_batch: no current batch (dmvae_plan_load_batch_step or dmvae_plan_swap_batch first)");
+    p->pf.data = data; p->pf.n_rows = n_rows; p->pf.perm = perm; p->pf.first = first; p->pf.n_valid = n_valid;
+    p->pf.st = use_state_cursor ? p->buf.state : nullptr;
+    p->pf.armed = true; p->pf.done = false;
+    return 0;
+}
+// Makes the batch a pass has prefetched the current one (host state only: the other batch buffer and its target source).
+extern "C" int dmvae_plan_swap_batch(dmvae_plan* p) {
+    DMVAE_REQUIRE(p && p->bound, "dmvae_plan_swap_batch: plan not bound");
+    DMVAE_REQUIRE(p->pf.done, "dmvae_plan_swap_batch: no pass has run since dmvae_plan_prefetch_batch");
+    p->xsel ^= 1;
+    p->tsrc.data = p->pf.data; p->tsrc.n_rows = p->pf.n_rows; p->tsrc.perm = p->pf.perm; p->tsrc.first = p->pf.first; p->tsrc.n_valid = p->pf.n_valid;
+    p->tsrc.st = p->pf.st;
+    p->tsrc_valid = true; p->tsrc_used = false;
+    p->pf.armed = p->pf.done = false;
+    return 0;
 }
 
 static int fwd_dense(dmvae_plan* p, hipStream_t s, const void* A, int64_t lda, int Kdim, const PLayer& L, int N, int64_t w_col,
@@ -632,7 +669,7 @@ static int conv_trunk_backward(dmvae_plan* p, hipStream_t s) {
 }
 
 static int encode_impl(dmvae_plan* p, hipStream_t s) {
-    const void* in = WS(p, p->o_x);
+    const void* in = p->conv.empty() ? XB(p) : WS(p, p->o_x);
     int64_t ld = p->Ip;
     int kd = p->Ip;
     if (!p->conv.empty()) {
@@ -811,10 +848,15 @@ static int launch_dw_queue(dmvae_plan* p, hipStream_t target, bool with_prior) {
 // cs_key (the dY tensor's base pointer) for the weight-gradient problem of that layer
 static int dx_dense(dmvae_plan* p, hipStream_t s, const void* dY, int64_t ldy, int Kdim, int64_t w_off, int64_t ldw, int N,
                     const void* Yfwd, int64_t ldyf, void* out, int64_t ldo, GemmArgs* deferred = nullptr,
-                    const void* cs_key = nullptr, int64_t cs_off = -1, int64_t cs_ld = 0, int64_t cs_col = 0) {
+                    const void* cs_key = nullptr, int64_t cs_off = -1, int64_t cs_ld = 0, int64_t cs_col = 0, const GemmRiders* riders = nullptr) {
     dmvae_epilogue e;
     memset(&e, 0, sizeof(e));
     e.kind = DMVAE_EPI_RELU_MASK; e.out = out; e.ldo = ldo; e.aux0 = Yfwd; e.ld0 = ldyf;
+    if (riders) {       // (the caller has asked gemm_bf16_riders_room: a small-tile launch)
+        GemmArgs a;
+        TRY(gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_DX, p->Bp, N, Kdim, dY, ldy, Wp(p, w_off), ldw, &e, 1, &a));
+        return gemm_bf16_dispatch(s, DMVAE_GEMM_DX, a, 1, riders);
+    }
     if (!deferred && cs_off >= 0 && p->cfg.dtype == DMVAE_BF16 && gemm_bf16_256_ok(DMVAE_GEMM_DX, DMVAE_EPI_RELU_MASK, p->Bp, N, Kdim, false)) {
         GemmArgs a;
         TRY(gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_DX, p->Bp, N, Kdim, dY, ldy, Wp(p, w_off), ldw, &e, 1, &a));
@@ -876,12 +918,30 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     // ... and WHERE they ride.  In the heads' dX launch (every slot of the chip taken by a real workgroup) they cost that launch 2.2 us at 4096 rows
     // (MEASURED, knob 16: 19.4 us with them, 17.2 without; as a launch of their own +4.3 us per step).  The dZ GEMM two launches earlier has
     // their inputs too (it runs behind the reconstruction layer) and, while tiles + riders <= 256, leaves every rider a CU of its own.
-    bool fin_in_dz = false;
-    if (fin_rides && g_fin_rides == 1) {
-        const int t = gemm_bf16_tile_m(p->Bp, p->Dp, 1);
-        const int lead = (fin.nblocks + 7) & ~7;
-        fin_in_dz = (p->Bp / (t / 1000)) * (p->Dp / (t % 1000)) + lead <= 256;
+    bool fin_in_dz = false, fin_in_out = false;
+    const int fin_lead = (fin.nblocks + 7) & ~7;
+    GemmArgs dz_shape{}, out_shape{};           // (shapes only: what gemm_bf16_riders_room looks at)
+    dz_shape.M = p->Bp; dz_shape.N = p->Dp; dz_shape.K = p->dec.empty() ? 64 : p->dec[0].out_pad; dz_shape.epi.kind = DMVAE_EPI_LATENT;
+    out_shape.M = p->Bp; out_shape.N = p->dec.empty() ? 64 : p->dec.back().out_pad; out_shape.K = p->Ip; out_shape.epi.kind = DMVAE_EPI_RELU_MASK;
+    const int dz_room = (dt == DMVAE_BF16 && !p->dec.empty()) ? gemm_bf16_riders_room(dz_shape, true) : -1;
+    if (fin_rides && g_fin_rides == 1) fin_in_dz = dz_room >= fin_lead;
+    // A prefetched batch (dmvae_plan_prefetch_batch): its gather takes the idle CUs of the dZ launch -- behind step_finalize, which has moved the
+    // batch cursor on: those blocks then ride one launch EARLIER, as second workgroups of the output layer's dX launch (their inputs, the loss
+    // partials, are complete behind the output layer's forward GEMM).  Without the room for both: step_finalize where it was, the gather as a
+    // launch of its own in front of the trunk's backward pass.
+    GemmRiders rid_dz, rid_out;
+    if (p->pf.armed && (all || stage == 0)) {
+        p->pf.gat = gather_args(DMVAE_BF16, p->pf.data, p->pf.n_rows, c.input_dim, p->pf.perm, p->pf.first, c.max_batch, p->pf.n_valid, p->Bp, XB(p, 1), p->Ip,
+                                nullptr, p->Ip, p->Ip, p->pf.st);
+        if (fin_rides && g_fin_rides == 1 && g_pf_rides && dz_room >= 64 && gemm_bf16_riders_room(out_shape, false) >= fin_lead) {
+            fin_in_dz = false; fin_in_out = true;
+            rid_out.fin = fin; rid_out.nfin = fin_lead;
+            rid_dz.gat = p->pf.gat;
+            rid_dz.gat_last = g_pf_rides != 2;           // behind the tiles: the tiles then get CUs of their own first
+            rid_dz.ngat = (g_pf_rides == 3 ? std::min(2 * dz_room, 512) : std::min(dz_room, 256)) & ~7;
+        }
     }
+    if (fin_in_dz) { rid_dz.fin = fin; rid_dz.nfin = fin_lead; }
   if (all || stage == 0) {
     p->dw_queue.clear();
     p->csum_of.clear();
@@ -944,7 +1004,7 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
                    p->out.w_off, p->out.ldw, p->out.b_off));
     TRY(dx_dense(p, s, WS(p, p->o_dl), p->Ip, p->Ip, p->out.w_off, p->out.ldw, p->dec[nd - 1].out_pad,
                  WS(p, p->o_dec[nd - 1]), p->dec[nd - 1].out_pad, WS(p, p->o_ddec[nd - 1]), p->dec[nd - 1].out_pad, nullptr,
-                 WS(p, p->o_ddec[nd - 1]), cso(p->o_cs_ddec, nd - 1), p->dec[nd - 1].out_pad));
+                 WS(p, p->o_ddec[nd - 1]), cso(p->o_cs_ddec, nd - 1), p->dec[nd - 1].out_pad, 0, fin_in_out ? &rid_out : nullptr));
     for (int i = nd - 1; i >= 0; --i) {
         const PLayer& L = p->dec[i];
         const void* xin = i > 0 ? WS(p, p->o_dec[i - 1]) : WS(p, p->o_Z);
@@ -959,10 +1019,11 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
             memset(&e, 0, sizeof(e));
             e.kind = DMVAE_EPI_LATENT; e.out = WS(p, p->o_dmv); e.ldo = 2 * p->Dp; e.d_off = p->Dp;
             e.aux0 = la.gmu; e.ld0 = p->Dp; e.aux1 = la.glv; e.ld1 = p->Dp; e.aux2 = la.clv; e.ld2 = p->Dp;
-            if (fin_in_dz) {      // the step_finalize blocks ride here (see fin_in_dz above)
+            if (rid_dz.nfin || rid_dz.ngat) {      // the step_finalize blocks, or the next batch's gather, ride here (see above)
                 GemmArgs ga;
                 TRY(gemm_checked(s, dt, DMVAE_GEMM_DX, p->Bp, p->Dp, L.out_pad, WS(p, p->o_ddec[0]), L.out_pad, Wp(p, L.w_off), L.ldw, &e, 1, &ga));
-                TRY(gemm_bf16_dispatch(s, DMVAE_GEMM_DX, ga, 1, &fin));
+                TRY(gemm_bf16_dispatch(s, DMVAE_GEMM_DX, ga, 1, &rid_dz));
+                if (rid_dz.ngat) { p->pf.armed = false; p->pf.done = true; }
             } else
             TRY(gemm_checked(s, dt, DMVAE_GEMM_DX, p->Bp, p->Dp, L.out_pad, WS(p, p->o_ddec[0]), L.out_pad, Wp(p, L.w_off), L.ldw, &e, 1));
         }
@@ -988,15 +1049,22 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
                      const_cast<void*>(act_off(p, p->o_dhzc, p->Hp)), 2 * p->Hp, grp ? &q[1] : nullptr, WS(p, p->o_dhzc), p->o_cs_dhzc, 2 * p->Hp, p->Hp));
         if (grp && g_heads_dx_form == 2) {       // z-hidden as its own launch, c-hidden (and the riding finalize blocks) as a group of one
             TRY(gemm_bf16_dispatch(s, DMVAE_GEMM_DX, q[0], 1));
-            TRY(gemm_bf16_grouped(s, DMVAE_GEMM_DX, q + 1, 1, (fin_rides && !fin_in_dz) ? &fin : nullptr));
+            TRY(gemm_bf16_grouped(s, DMVAE_GEMM_DX, q + 1, 1, (fin_rides && !fin_in_dz && !fin_in_out) ? &fin : nullptr));
         } else
-        if (grp) TRY(gemm_bf16_grouped(s, DMVAE_GEMM_DX, q, 2, (fin_rides && !fin_in_dz) ? &fin : nullptr));
+        if (grp) TRY(gemm_bf16_grouped(s, DMVAE_GEMM_DX, q, 2, (fin_rides && !fin_in_dz && !fin_in_out) ? &fin : nullptr));
     }
     // ---- backward: trunk
     TRY(grad_dense(p, s, WS(p, p->o_enc[ne - 1]), p->Tp, p->Tp, WS(p, p->o_dhzc), 2 * p->Hp, 2 * p->Hp, p->zc.w_off, p->zc.ldw, p->zc.b_off));
     TRY(flush_dw(p, s, 1));      // heads dW group ([mean|log_var], logits, [zh|ch]): launched here when staged
   }
   if (all || stage == 2) {
+    // a prefetched batch that did not ride in the dZ launch: a gather of its own, here -- step_finalize has run (in every placement it has, an
+    // earlier launch of this stream), so the device cursor is the next batch's
+    if (p->pf.armed) {
+        const dmvae_gather_args& g = p->pf.gat;
+        TRY(gather_launch(s, DMVAE_BF16, g.data, g.n_rows, g.dim, g.perm, g.first, g.batch, g.n_valid, g.B_pad, g.out_act, g.ld_act, nullptr, g.ld_f32, g.cols_pad, g.st));
+        p->pf.armed = false; p->pf.done = true;
+    }
     if (!p->vade) {
         TRY(dx_dense(p, s, WS(p, p->o_dhzc), 2 * p->Hp, 2 * p->Hp, p->zc.w_off, p->zc.ldw, p->Tp, WS(p, p->o_enc[ne - 1]), p->Tp,
                      WS(p, p->o_denc[ne - 1]), p->Tp, nullptr, WS(p, p->o_denc[ne - 1]), cso(p->o_cs_denc, ne - 1), p->Tp));
@@ -1005,7 +1073,7 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
         const PLayer& L = p->enc[i];
         const bool cnn = !p->conv.empty();
         const void* flat = cnn ? (p->conv.back().pool ? WS(p, p->conv.back().o_pool) : WS(p, p->conv.back().o_act)) : nullptr;
-        const void* xin = i > 0 ? WS(p, p->o_enc[i - 1]) : (cnn ? flat : WS(p, p->o_x));
+        const void* xin = i > 0 ? WS(p, p->o_enc[i - 1]) : (cnn ? flat : XB(p));
         const int64_t ldx = i > 0 ? p->enc[i - 1].out_pad : (cnn ? p->flat : p->Ip);
         TRY(grad_dense(p, s, xin, ldx, L.in_pad, WS(p, p->o_denc[i]), L.out_pad, L.out_pad, L.w_off, L.ldw, L.b_off));
         if (i > 0)
@@ -1292,6 +1360,7 @@ extern "C" int dmvae_debug_set_knob(int which, int value) {
     if (which == 12) { g_heads_dx_form = value; return 0; }
     if (which == 13) { heads_dx_stream_set(value); return 0; }
     if (which == 16) { g_fin_rides = value; return 0; }
+    if (which == 17) { g_pf_rides = value; return 0; }
     if (which == 14) { latent_set_blocks_target(value); return 0; }      // (the block count in use is taken at enqueue time and checked against the plan's capacity)
     DMVAE_REQUIRE(which >= 0 && which <= 9 && which != 3, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, (3: removed, the deep-ring policy), 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy, 7 = short-K workgroups, 8 = first-tile stagger of the merged dW grid, 9 = waves per workgroup of a grouped dX launch; 10 / 11 = K slices of the dW groups, 12 = heads dX as one or two launches, 13 = heads dX on the streaming kernel (1) or the grouped tiles (0), 14 = blocks the latent kernel's geometry aims at (512)");
     gemm_bf16_set_knob(which, value);

@@ -319,51 +319,26 @@ int step_finalize_launch(hipStream_t s, const float* rp, int nr, const float* lp
 }
 
 // ---------------------------------------------------------------- batch assembly
-// Dataset.get_batches (includes/utils.py:449-463): row r <- data[perm[first+r]].
-// One 64-lane group per row; 16-B loads of the f32 source row; writes the act copy
-// (bf16: 8-B stores) and the f32 copy; pad rows / pad columns are zero.
+// Dataset.get_batches (includes/utils.py:449-463): row r <- data[perm[first+r]] -- gather_rows_block (gemm_epilogue.h) over a grid of its own.
 template <typename ACT>
-__global__ __launch_bounds__(256) void gather_kernel(const float* data, int64_t n_rows, int dim, const int32_t* perm,
-                                                     int64_t first, int batch, int n_valid, int B_pad,
-                                                     ACT* out_act, int64_t ld_act, float* out_f32, int64_t ld_f32,
-                                                     int cols_pad, const dmvae_state* st) {
-    if (st) first = (int64_t)st->batch_cursor * batch;
-    const int quads = cols_pad >> 2;
-    const int64_t total = (int64_t)B_pad * quads;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int r = (int)(i / quads), c = (int)(i % quads) * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (r < n_valid) {
-            int64_t src = first + r;
-            if (perm) src = perm[src];
-            if (src < n_rows) {
-                const float* p = data + src * dim + c;
-                if (c + 3 < dim && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-                    const float4 q = *reinterpret_cast<const float4*>(p);
-                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = (c + j < dim) ? p[j] : 0.f;
-                }
-            }
-        }
-        if (out_act) ActIO<ACT>::store4(out_act, (int64_t)r * ld_act + c, v);
-        if (out_f32) ActIO<float>::store4(out_f32, (int64_t)r * ld_f32 + c, v);
-    }
+__global__ __launch_bounds__(256) void gather_kernel(dmvae_gather_args g) { gather_rows_block<ACT, 4>((int)blockIdx.x, 256, g); }
+dmvae_gather_args gather_args(int act_dtype, const float* data, int64_t n_rows, int dim, const int32_t* perm, int64_t first, int batch, int n_valid,
+                              int B_pad, void* out_act, int64_t ld_act, float* out_f32, int64_t ld_f32, int cols_pad, const void* st) {
+    dmvae_gather_args g;
+    g.data = data; g.n_rows = n_rows; g.dim = dim; g.perm = perm; g.first = first; g.batch = batch; g.n_valid = n_valid; g.B_pad = B_pad;
+    g.out_act = out_act; g.ld_act = ld_act; g.out_f32 = out_f32; g.ld_f32 = ld_f32; g.cols_pad = cols_pad; g.st = (const dmvae_state*)st;
+    const int64_t q = (int64_t)B_pad * (cols_pad / 4);
+    g.nblocks = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (q + 1023) / 1024));      // four quads per thread and pass
+    return g;
 }
 int gather_launch(hipStream_t s, int act_dtype, const float* data, int64_t n_rows, int dim, const int32_t* perm,
                   int64_t first, int batch, int n_valid, int B_pad, void* out_act, int64_t ld_act,
                   float* out_f32, int64_t ld_f32, int cols_pad, const void* st) {
-    int64_t q = (int64_t)B_pad * (cols_pad / 4);
-    int nb = (int)((q + 255) / 256);
-    if (nb > 2048) nb = 2048;
+    const dmvae_gather_args g = gather_args(act_dtype, data, n_rows, dim, perm, first, batch, n_valid, B_pad, out_act, ld_act, out_f32, ld_f32, cols_pad, st);
+    if ((int64_t)B_pad * (cols_pad / 4) >= (int64_t(1) << 31) - int64_t(2048) * 256 * 8) { set_error("dmvae_gather_rows: batch x columns too large for 32-bit quad indices"); return DMVAE_EINVAL; }
     ProfScope ps(s, "gather_rows", 0.0, (double)n_valid * dim * (4 + 4 + (act_dtype == DMVAE_BF16 ? 2 : 4)));
-    if (act_dtype == DMVAE_BF16)
-        DMVAE_LAUNCH(gather_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, data, n_rows, dim, perm, first, batch, n_valid, B_pad,
-                           (bf16_t*)out_act, ld_act, out_f32, ld_f32, cols_pad, (const dmvae_state*)st);
-    else
-        DMVAE_LAUNCH(gather_kernel<float>, dim3(nb), dim3(256), 0, s, data, n_rows, dim, perm, first, batch, n_valid, B_pad,
-                           (float*)out_act, ld_act, out_f32, ld_f32, cols_pad, (const dmvae_state*)st);
+    if (act_dtype == DMVAE_BF16) DMVAE_LAUNCH(gather_kernel<bf16_t>, dim3(g.nblocks), dim3(256), 0, s, g);
+    else DMVAE_LAUNCH(gather_kernel<float>, dim3(g.nblocks), dim3(256), 0, s, g);
     return check_launch("gather_rows");
 }
 

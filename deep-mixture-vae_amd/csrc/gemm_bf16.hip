@@ -478,19 +478,35 @@ __global__ __launch_bounds__(64 * NW, (EPI == DMVAE_EPI_BIAS_RECON ? 1 : NW / 2)
     gemm_bf16_body<BM, BN, LAYOUT, EPI, NSTAGE, NW>(a, blockIdx.x, 0, gridDim.x, smem);
 }
 
-// The dZ GEMM (DX layout, LATENT epilogue) carrying the step_finalize blocks (common.h) as RIDERS: `lead` (a multiple of 8, so that id % 8 -- the
-// XCD a workgroup lands on -- stays what the tile mapping assumes) extra workgroups hold the first ids of the grid, the first fin.nblocks of them run
-// step_finalize_block.  At 4096 rows this launch is 64 workgroups on a 256-CU chip: every rider gets a CU of its own -- in the heads' dX launch, which
-// fills every slot of the chip, the same riders cost that launch 2.2 us (MEASURED round 4, knob 16).  Same tile code, same bits.
-template <int BM, int BN, int NSTAGE, int NW>
-__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_bf16_dz_riders_kernel(GemmArgs a, dmvae_finalize_args fin, int lead) {
+// A dX GEMM (DX layout; LATENT epilogue = the dZ GEMM, RELU_MASK = a layer's dX) carrying RIDERS in the first ids of its grid (GemmRiders,
+// gemm_epilogue.h): the step_finalize blocks (common.h) and / or the gather of the NEXT batch (gather_rows_block).  Where they ride (api.hip):
+//   * step_finalize in the dZ GEMM at 4096 rows (64 tiles on 256 CUs: every rider a CU of its own) -- in the heads' dX launch, which fills every
+//     slot of the chip, the same riders cost that launch 2.2 us (MEASURED round 4, knob 16);
+//   * with a prefetched batch (dmvae_plan_prefetch_batch): the gather in the dZ GEMM -- memory work on the ~190 CUs that launch leaves idle -- and
+//     step_finalize one launch earlier, in the output layer's dX (one 8-wave tile per CU: the riders are second workgroups).  The gather as
+//     second workgroups of the TRUNK's dX (one tile per CU, K = 4096) was measured first and gives nothing: 0.2700 vs 0.2694 ms -- a CU's
+//     vector-memory path is what its K loop is bound by, and the riders share it.
+// Same tile code, same bits.
+template <int BM, int BN, int EPI, int NSTAGE, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_bf16_dx_riders_kernel(GemmArgs a, GemmRiders r) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * (BM + BN) * BK];
-    if ((int)blockIdx.x < lead) {
-        if (NW > 4 && threadIdx.x >= 256) return;          // (step_finalize_block is written for four waves; a finished wave leaves the barrier count)
-        if ((int)blockIdx.x < fin.nblocks) step_finalize_block((int)blockIdx.x, fin, reinterpret_cast<float(*)[17]>(smem));
+    const int lead = r.nfin + (r.gat_last ? 0 : r.ngat);
+    if (r.gat_last && (int)blockIdx.x >= (int)gridDim.x - r.ngat) {
+        if constexpr (MEAS_EMPTY_GATHER_RIDERS) return;
+        gather_rows_block<bf16_t, 16>((int)blockIdx.x - ((int)gridDim.x - r.ngat), 64 * NW, r.gat);
         return;
     }
-    gemm_bf16_body<BM, BN, DMVAE_GEMM_DX, DMVAE_EPI_LATENT, NSTAGE, NW>(a, (int)blockIdx.x - lead, lead, (int)gridDim.x - lead, smem);
+    if ((int)blockIdx.x < r.nfin) {
+        if (NW > 4 && threadIdx.x >= 256) return;          // (step_finalize_block is written for four waves; a finished wave leaves the barrier count)
+        if ((int)blockIdx.x < r.fin.nblocks) step_finalize_block((int)blockIdx.x, r.fin, reinterpret_cast<float(*)[17]>(smem));
+        return;
+    }
+    if ((int)blockIdx.x < lead) {
+        if constexpr (MEAS_EMPTY_GATHER_RIDERS) return;
+        gather_rows_block<bf16_t, 16>((int)blockIdx.x - r.nfin, 64 * NW, r.gat);      // (two rider blocks per idle CU, 16 quads in flight per thread: one pass at 4096 rows)
+        return;
+    }
+    gemm_bf16_body<BM, BN, DMVAE_GEMM_DX, EPI, NSTAGE, NW>(a, (int)blockIdx.x - lead, lead, (int)gridDim.x - lead - (r.gat_last ? r.ngat : 0), smem);
 }
 
 // The same tile in conv mode (implicit 3x3 convolution, csrc/conv.hip): its own kernel, so the dense
@@ -644,17 +660,20 @@ static double gemm_bytes(const GemmArgs& a, int layout = DMVAE_GEMM_FWD) {    //
 }
 
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4>
-static int launch(hipStream_t s, const GemmArgs& a, int split, const dmvae_finalize_args* riders = nullptr) {
+static int launch(hipStream_t s, const GemmArgs& a, int split, const GemmRiders* riders = nullptr) {
     dim3 grid((a.M / BM) * (a.N / BN), split);
-    ProfScope ps(s, kernel_name<BM, BN, LAYOUT, EPI, NSTAGE, NW>(false), 2.0 * a.M * a.N * (double)a.K, gemm_bytes(a));
-    if constexpr (LAYOUT == DMVAE_GEMM_DX && EPI == DMVAE_EPI_LATENT) {
-        if (riders && split == 1) {      // the step_finalize blocks ride in the first ids of this grid (gemm_bf16_dz_riders_kernel)
-            const int lead = (riders->nblocks + 7) & ~7;
-            DMVAE_LAUNCH((gemm_bf16_dz_riders_kernel<BM, BN, NSTAGE, NW>), dim3(grid.x + lead), dim3(64 * NW), 0, s, a, *riders, lead);
-            return check_launch("gemm_bf16 (dZ + riders)");
+    if constexpr (LAYOUT == DMVAE_GEMM_DX && (EPI == DMVAE_EPI_LATENT || EPI == DMVAE_EPI_RELU_MASK)) {
+        if (riders && split == 1) {      // riders in the first ids of this grid (gemm_bf16_dx_riders_kernel)
+            GemmRiders r = *riders;
+            double rbytes = 0.0;
+            if (r.ngat) { r.gat.nblocks = r.ngat; rbytes = (double)r.gat.n_valid * r.gat.dim * (4 + 2); }
+            ProfScope ps(s, kernel_name<BM, BN, LAYOUT, EPI, NSTAGE, NW>(false), 2.0 * a.M * a.N * (double)a.K, gemm_bytes(a) + rbytes);
+            DMVAE_LAUNCH((gemm_bf16_dx_riders_kernel<BM, BN, EPI, NSTAGE, NW>), dim3(grid.x + r.nfin + r.ngat), dim3(64 * NW), 0, s, a, r);
+            return check_launch("gemm_bf16 (dX + riders)");
         }
     }
-    if (riders) { set_error("gemm_bf16: step_finalize riders are carried by the DX / LATENT launch only"); return DMVAE_EINVAL; }
+    if (riders) { set_error("gemm_bf16: riders are carried by the dense DX launches with the LATENT or RELU_MASK epilogue only"); return DMVAE_EINVAL; }
+    ProfScope ps(s, kernel_name<BM, BN, LAYOUT, EPI, NSTAGE, NW>(false), 2.0 * a.M * a.N * (double)a.K, gemm_bytes(a));
     DMVAE_LAUNCH((gemm_bf16_kernel<BM, BN, LAYOUT, EPI, NSTAGE, NW>), grid, dim3(64 * NW), 0, s, a);
     return check_launch("gemm_bf16");
 }
@@ -953,7 +972,7 @@ int gemm_bf16_tile_m(int M, int N, int split) {
 // one wave per SIMD; a second resident workgroup fills the gaps):
 //   128x128: 2 x 32 KiB, 128x64 / 64x128: 3 x 24 KiB, 64x64: 4 x 16 KiB  (<= 72 KiB -> 2 blocks/CU)
 template <int LAYOUT, int EPI>
-static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split, const dmvae_finalize_args* riders = nullptr) {
+static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split, const GemmRiders* riders = nullptr) {
     GemmArgs a = a0;
     int t = gemm_bf16_tile_m(a.M, a.N, split);
     if (a.conv_c) {          // conv mode (csrc/conv.hip): the three (layout, epilogue) pairs a convolution layer uses
@@ -987,7 +1006,7 @@ static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split, const dmva
     //  17.1 vs 19.0 us; whole step at B = 16384: 1.0753 vs 1.0706 ms, at B = 8192 / D 256 / K 50: 0.8079 vs
     //  0.7922 ms.  Two resident workgroups overlapping their load / compute / store phases beat the
     //  smaller intake of one.)
-    if (riders && (a.conv_c || !(LAYOUT == DMVAE_GEMM_DX && EPI == DMVAE_EPI_LATENT))) { set_error("gemm_bf16: step_finalize riders are carried by the dense DX / LATENT launch only"); return DMVAE_EINVAL; }
+    if (riders && (a.conv_c || LAYOUT != DMVAE_GEMM_DX || gemm_bf16_256_ok(LAYOUT, EPI, a.M, a.N, a.K, false))) { set_error("gemm_bf16: riders are carried by the dense small-tile DX launches only (ask gemm_bf16_riders_room first)"); return DMVAE_EINVAL; }
     if (split == 1 && gemm_bf16_256_ok(LAYOUT, EPI, a.M, a.N, a.K, false)) return gemm_bf16_256_launch(s, LAYOUT, a);
     a.group_m = gemm_auto_group_m(a.M / (t / 1000), a.N / (t % 1000), t / 1000, t % 1000);
     if (g_shortk && a.K <= 128 && split == 1 && LAYOUT != DMVAE_GEMM_DW && EPI != DMVAE_EPI_BIAS_RECON) {
@@ -1010,7 +1029,18 @@ static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split, const dmva
     }
 }
 
-int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split, const dmvae_finalize_args* riders) {
+// Workgroup slots a dense small-tile DX launch of this shape leaves free for riders that want a CU of their own (256 - tiles), or that are
+// content to be the second resident workgroup of a CU (512 - tiles); < 0: the launch runs on another kernel (macro tile, conv) -- no riders.
+int gemm_bf16_riders_room(const GemmArgs& a, bool own_cu) {
+    if (a.conv_c || gemm_bf16_256_ok(DMVAE_GEMM_DX, a.epi.kind, a.M, a.N, a.K, false)) return -1;
+    if (a.epi.kind != DMVAE_EPI_LATENT && a.epi.kind != DMVAE_EPI_RELU_MASK) return -1;
+    int t = gemm_bf16_tile_m(a.M, a.N, 1);
+    if (g_shortk && a.K <= 128) t = 64064;
+    const int tiles = (a.M / (t / 1000)) * (a.N / (t % 1000));
+    return (own_cu ? 256 : 512) - tiles;
+}
+
+int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split, const GemmRiders* riders) {
     const int epi = a.epi.kind;
 #define CASE(L, E) \
     if (layout == L && epi == E) return launch_tiled<L, E>(s, a, split, riders);

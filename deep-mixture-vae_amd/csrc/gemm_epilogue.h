@@ -83,6 +83,93 @@ __device__ __forceinline__ float xent_logits(float l, float x) {
     return fmaxf(l, 0.f) - l * x + log1pf(__expf(-fabsf(l)));
 }
 __device__ __forceinline__ float sigmoidf_(float l) { return 1.0f / (1.0f + __expf(-l)); }
+// Batch assembly (Dataset.get_batches, includes/utils.py:449-463: row r <- data[perm[first + r]]) as a device function: the gather kernel
+// (elementwise.hip) runs it over its own grid, and `nblocks` workgroups of ANOTHER launch can run it as riders (the next batch fetched under
+// the trunk's dX GEMM, gemm_bf16.hip / api.hip dmvae_plan_prefetch_batch).  16-byte loads of the f32 source row; writes the act copy (bf16:
+// 8-byte stores) and / or the f32 copy; pad rows and pad columns are zeros.  st != nullptr: first = st->batch_cursor * batch.
+struct dmvae_gather_args {
+    const float* data; int64_t n_rows; int dim; const int32_t* perm;
+    int64_t first; int batch, n_valid, B_pad;
+    void* out_act; int64_t ld_act; float* out_f32; int64_t ld_f32; int cols_pad;
+    const dmvae_state* st;
+    int nblocks;                      // workgroups that share the work (grid-stride)
+};
+// A thread's chain is permutation entry -> source row -> store: two dependent memory round trips per quad.  U quads per pass, each stage issued
+// for all of them before the next stage starts, and every load UNCONDITIONAL (indices clamped, the result selected afterwards): a load inside a
+// divergent `if` is waited for at the join, so the "batched" first form ran its 16 chains one after the other -- as riders (few blocks: a rider
+// block holds its host kernel's LDS) the gather then took 16-20 us inside an 11-us launch (rocprofv3, profiles/r04_prefetch.txt).
+// Fast path: input_dim a multiple of 4 and a 16-byte aligned dataset (every quad inside a row is then one aligned 16-byte load).
+template <typename ACT, int U, bool PERM>
+__device__ __forceinline__ void gather_rows_pass(const int base, const int nthreads, const int total, const int quads, const int64_t first, const dmvae_gather_args& g) {
+    int r[U], c[U];
+    int64_t idx[U];
+    bool inb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = base + u * nthreads;
+        r[u] = i < total ? i / quads : -1;
+        c[u] = i < total ? (i - r[u] * quads) * 4 : 0;
+        const int64_t sr = first + r[u];
+        inb[u] = r[u] >= 0 && r[u] < g.n_valid && sr >= 0 && sr < g.n_rows;      // (the permutation has n_rows entries: a batch that runs past them reads zeros)
+        idx[u] = inb[u] ? sr : 0;
+    }
+    if constexpr (PERM) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) idx[u] = (int64_t)g.perm[idx[u]];
+    }
+    float4 q[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        inb[u] = inb[u] && idx[u] >= 0 && idx[u] < g.n_rows && c[u] < g.dim;
+        q[u] = *reinterpret_cast<const float4*>(g.data + (inb[u] ? idx[u] * g.dim + c[u] : 0));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (r[u] < 0) continue;
+        const float v[4] = {inb[u] ? q[u].x : 0.f, inb[u] ? q[u].y : 0.f, inb[u] ? q[u].z : 0.f, inb[u] ? q[u].w : 0.f};
+        if (g.out_act) ActIO<ACT>::store4(g.out_act, (int64_t)r[u] * g.ld_act + c[u], v);
+        if (g.out_f32) ActIO<float>::store4(g.out_f32, (int64_t)r[u] * g.ld_f32 + c[u], v);
+    }
+}
+template <typename ACT, int U = 8>        // (U = 16 for riders: gemm_bf16_dx_riders_kernel)
+__device__ __forceinline__ void gather_rows_block(const int bx, const int nthreads, const dmvae_gather_args& g) {
+    int64_t first = g.first;
+    if (g.st) first = (int64_t)g.st->batch_cursor * g.batch;
+    const int quads = g.cols_pad >> 2;
+    const int total = g.B_pad * quads;                  // (< 2^31: gather_launch / the plan's sizes)
+    if (g.dim % 4 == 0 && (reinterpret_cast<uintptr_t>(g.data) & 15) == 0 && g.n_rows > 0) {
+        for (int base = bx * nthreads * U + (int)threadIdx.x; base < total; base += g.nblocks * nthreads * U) {
+            if (g.perm) gather_rows_pass<ACT, U, true>(base, nthreads, total, quads, first, g);
+            else gather_rows_pass<ACT, U, false>(base, nthreads, total, quads, first, g);
+        }
+        return;
+    }
+    for (int i = bx * nthreads + (int)threadIdx.x; i < total; i += g.nblocks * nthreads) {      // any input_dim / alignment: one quad at a time, element loads
+        const int r = i / quads, c = (i - r * quads) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < g.n_valid) {
+            int64_t src = first + r;
+            if (g.perm) src = (src >= 0 && src < g.n_rows) ? (int64_t)g.perm[src] : -1;
+            if (src >= 0 && src < g.n_rows) {
+                const float* p = g.data + src * g.dim + c;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (c + j < g.dim) ? p[j] : 0.f;
+            }
+        }
+        if (g.out_act) ActIO<ACT>::store4(g.out_act, (int64_t)r * g.ld_act + c, v);
+        if (g.out_f32) ActIO<float>::store4(g.out_f32, (int64_t)r * g.ld_f32 + c, v);
+    }
+}
+
+// Workgroups of other work riding in the FIRST ids of a dX GEMM launch (gemm_bf16_dx_riders_kernel): nfin ids for the step_finalize blocks
+// (fin.nblocks of them work), then ngat ids for the gather of the next batch (all work); nfin, ngat multiples of 8, so that id % 8 -- the XCD a
+// workgroup lands on -- stays what the tile mapping assumes.
+struct GemmRiders {
+    dmvae_finalize_args fin; int nfin = 0;
+    dmvae_gather_args gat; int ngat = 0;
+    int gat_last = 0;                 // 1: the gather blocks take the LAST ids of the grid instead (behind the tiles; not counted in the tile mapping's lead)
+};
+
 // cross entropy AND sigmoid from ONE exponential: e = exp(-|l|);
 //   xent = max(l,0) - l*x + log(1+e),  sigmoid = l >= 0 ? 1/(1+e) : e/(1+e)
 // (3 transcendental issues per element instead of log1pf + 2 expf; log(1+e) loses e below 6e-8,

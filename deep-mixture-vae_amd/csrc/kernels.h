@@ -16,7 +16,8 @@ struct AdamArgs {
 
 #define DMVAE_MAX_GROUP 16
 // riders: the step_finalize blocks as extra workgroups of this launch (the dense DX / LATENT GEMM only: gemm_bf16_dz_riders_kernel)
-int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split, const dmvae_finalize_args* riders = nullptr);
+int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split, const GemmRiders* riders = nullptr);
+int gemm_bf16_riders_room(const GemmArgs& a, bool own_cu);
 int gemm_bf16_grouped_dw(hipStream_t s, const GemmArgs* probs, int nprob);
 // fin: the step_finalize blocks ride as extra workgroups of this launch (DX / RELU_MASK groups only)
 int gemm_bf16_grouped(hipStream_t s, int layout, const GemmArgs* probs, int nprob, const dmvae_finalize_args* fin = nullptr);
@@ -68,6 +69,8 @@ int loss_finalize_launch(hipStream_t s, const float* rp, int nr, const float* lp
 int step_finalize_launch(hipStream_t s, const float* rp, int nr, const float* lp, int nl, float inv_B, void* st, int bump_adam,
                          float b1, float b2, const float* part, int nblk, int ncol, float* gout);
 int gemm_bf16_grouped_dw_adam(hipStream_t s, const GemmArgs* probs, int nprob, const dmvae_adam_ctx& ctx);
+dmvae_gather_args gather_args(int act_dtype, const float* data, int64_t n_rows, int dim, const int32_t* perm, int64_t first, int batch, int n_valid,
+                              int B_pad, void* out_act, int64_t ld_act, float* out_f32, int64_t ld_f32, int cols_pad, const void* st);
 int gather_launch(hipStream_t s, int act_dtype, const float* data, int64_t n_rows, int dim, const int32_t* perm, int64_t first, int batch,
                   int n_valid, int B_pad, void* out_act, int64_t ld_act, float* out_f32, int64_t ld_f32, int cols_pad, const void* st);
 int philox_launch(hipStream_t s, float* out, int64_t n, uint64_t seed, uint64_t step, uint32_t sid, int gumbel);

@@ -3,7 +3,7 @@
 // compile time) and none of the stamp tables exists -- the product kernels execute no stamp and carry no table.
 //
 // tools/ablate.sh N builds a separately named library (build/libdmvae_hip_abl<N>.so, never the product one, selected with
-// DMVAE_HIP_LIB) with -DDMVAE_ABLATE=N.  Results of builds 1-5, 8, 9 and 11 are WRONG by construction: timing only.
+// DMVAE_HIP_LIB) with -DDMVAE_ABLATE=N.  Results of builds 1-5, 8, 9, 11 and 12 are WRONG by construction: timing only.
 //   1  no MFMA (fragments still read)            2  no LDS fragment reads            3  no global -> LDS loads inside the K loop
 //   4  = 1 + 2                                   5  no epilogue (accumulators kept live)
 //   6  per-workgroup stamps: tools/stamps.py (placement, K-loop / epilogue timeline of a grouped launch), tools/anatomy.py (phases
@@ -15,6 +15,7 @@
 //      until the workgroup ends (a stamp STORE inside the walk would count in the walk's own vmcnt arithmetic)
 //  11  the batch gather of dmvae_plan_load_batch_step not enqueued after its first two calls (the step then trains on a stale batch): the upper
 //      bound of a gather that runs under another launch (the next batch fetched by riders of the weight-gradient launch)
+//  12  the gather blocks that ride in the dZ launch (a prefetched batch) return at once: what their presence costs that launch without their work
 // Stamp values go to tables of their own (or, build 7, behind the loss partials in the caller's buffer); no output is computed
 // from them (MI355X_MICROARCH.md, DVFS give-back item 6).
 #pragma once
@@ -32,6 +33,7 @@ constexpr bool MEAS_NO_MASK_READ = DMVAE_ABLATE == 8;
 constexpr bool MEAS_NO_BIAS_MFMA = DMVAE_ABLATE == 9;
 constexpr bool MEAS_STAMPS = DMVAE_ABLATE == 6;
 constexpr bool MEAS_NO_STEP_GATHER = DMVAE_ABLATE == 11;
+constexpr bool MEAS_EMPTY_GATHER_RIDERS = DMVAE_ABLATE == 12;
 }  // namespace dmvae
 
 #if DMVAE_ABLATE == 6

@@ -16,8 +16,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DMVAE_HIP_LIB: another build of the SAME library (e.g. a measurement variant from tools/ablate.sh)
 LIB_PATH = os.environ.get("DMVAE_HIP_LIB") or os.path.join(_HERE, "libdmvae_hip.so")
 
-ABI_VERSION = 3          # DMVAE_ABI_VERSION of include/dmvae_hip.h
+ABI_VERSION = 4          # DMVAE_ABI_VERSION of include/dmvae_hip.h
 F32, BF16 = 0, 1
+EUNSUPPORTED = -2        # DMVAE_EUNSUPPORTED
 ADAM_ZERO_GRAD, ADAM_IEEE = 1, 2
 GEMM_FWD, GEMM_DX, GEMM_DW = 0, 1, 2
 (EPI_BIAS_RELU, EPI_BIAS_F32, EPI_BIAS_RECON, EPI_RELU_MASK, EPI_LATENT,
@@ -34,7 +35,7 @@ EXPORTS = [
     "dmvae_adam_tf", "dmvae_adam_finish", "dmvae_gather_rows", "dmvae_philox_normal",
     "dmvae_philox_gumbel", "dmvae_cast_f32_to_bf16", "dmvae_cast_bf16_to_f32",
     "dmvae_plan_create", "dmvae_plan_destroy", "dmvae_plan_sizes", "dmvae_plan_tensor",
-    "dmvae_plan_bind", "dmvae_plan_load_batch", "dmvae_plan_load_batch_step", "dmvae_plan_forward_backward",
+    "dmvae_plan_bind", "dmvae_plan_load_batch", "dmvae_plan_load_batch_step", "dmvae_plan_prefetch_batch", "dmvae_plan_swap_batch", "dmvae_plan_forward_backward",
     "dmvae_plan_update", "dmvae_plan_encode", "dmvae_plan_decode", "dmvae_plan_view",
     "dmvae_prof_enable", "dmvae_prof_collect", "dmvae_debug_spin", "dmvae_debug_stamps", "dmvae_debug_anatomy", "dmvae_debug_anatomy256", "dmvae_debug_set_tile", "dmvae_debug_set_knob", "dmvae_abi_version", "dmvae_last_error",
 ]
@@ -174,6 +175,8 @@ def _load():
         "dmvae_plan_bind": [vp, P(Buffers)],
         "dmvae_plan_load_batch": [vp, vp, vp, i64, vp, i64, i32, i32],
         "dmvae_plan_load_batch_step": [vp, vp, vp, i64, vp, i64, i32, i32],
+        "dmvae_plan_prefetch_batch": [vp, vp, i64, vp, i64, i32, i32],
+        "dmvae_plan_swap_batch": [vp],
         "dmvae_plan_forward_backward": [vp, vp, i32, vp, i64, vp, i64, f32],
         "dmvae_plan_update": [vp, vp, f32],
         "dmvae_plan_encode": [vp, vp, i32],

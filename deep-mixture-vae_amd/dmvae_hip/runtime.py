@@ -100,6 +100,9 @@ def layer_table(input_dim, latent_dim, n_classes, enc_layers, head_dim, dec_laye
     return t
 
 
+PIPELINE_MAX_BATCH = 1024      # capture_step: batches up to this many rows assemble the next batch under the running step by default (measured: see capture_step)
+
+
 class StepEngine:
     """One DMVAE model instance on one GPU: parameter / gradient / Adam arenas,
     activation workspace, device step state, and the enqueue methods of the
@@ -176,6 +179,8 @@ class StepEngine:
             self.tensors[ti.name.decode()] = (ti.offset, ti.rows, ti.cols, ti.ld)
         self.write_state(kl_ratio=1.0, lr=0.002, epoch_weight=1.0, batches_per_epoch=0)
         self._graph = None
+        self._pf_primed = False        # capture_step's pipelined form: the current batch buffer holds the batch of the device cursor
+        self._xsel = 0
 
     def __del__(self):
         try:
@@ -280,6 +285,7 @@ class StepEngine:
             setattr(st, k, v)
         host = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8)
         self.state_t.copy_(host)
+        self._pf_primed = False        # (the batch cursor may have moved)
 
     def reset_optimizer(self, lr=None):
         """A fresh tf.train.AdamOptimizer instance (base_models.py:102, :307-320 create one per
@@ -309,6 +315,7 @@ class StepEngine:
         assert data.dtype == torch.float32 and data.is_contiguous() and data.shape[1] == self.input_dim
         assert perm is None or (perm.dtype == torch.int32 and perm.is_contiguous())
         n_valid = self.max_batch if n_valid is None else int(n_valid)
+        self._pf_primed = False
         check(lib.dmvae_plan_load_batch(self._plan, self._stream(), ptr(data), data.shape[0], ptr(perm),
                                         int(first), n_valid, 1 if use_state_cursor else 0), "dmvae_plan_load_batch")
 
@@ -320,6 +327,7 @@ class StepEngine:
         assert perm is None or (perm.dtype == torch.int32 and perm.is_contiguous())
         n_valid = self.max_batch if n_valid is None else int(n_valid)
         self._step_src = (data, perm)                       # keep them alive
+        self._pf_primed = False
         check(lib.dmvae_plan_load_batch_step(self._plan, self._stream(), ptr(data), data.shape[0], ptr(perm),
                                              int(first), n_valid, 1 if use_state_cursor else 0), "dmvae_plan_load_batch_step")
 
@@ -576,9 +584,39 @@ class StepEngine:
         self.forward_backward(n_valid, eps, gumbel, inv_B)
         self.update(grad_scale)
 
-    def capture_step(self, data, perm, grad_sync=None, grad_scale=1.0, inv_B=None):
+    def _prefetch_batch(self, data, perm, first=0, n_valid=None, use_state_cursor=True):
+        """dmvae_plan_prefetch_batch: the next forward + backward pass also assembles the NEXT batch (host state only: nothing is enqueued)."""
+        n_valid = self.max_batch if n_valid is None else int(n_valid)
+        self._step_src = (data, perm)
+        check(lib.dmvae_plan_prefetch_batch(self._plan, ptr(data), data.shape[0], ptr(perm), int(first), n_valid, 1 if use_state_cursor else 0),
+              "dmvae_plan_prefetch_batch")
+
+    def _prefetch_ok(self, data, perm, side):
+        """assembles the batch of the device cursor (eagerly) and asks the plan whether it can prefetch behind it"""
+        if self.dtype != _lib.BF16:
+            return False
+        with torch.cuda.stream(side):
+            self._load_batch_for_step(data, perm, 0, None, True)
+        side.synchronize()
+        rc = lib.dmvae_plan_prefetch_batch(self._plan, ptr(data), data.shape[0], ptr(perm), 0, self.max_batch, 1)
+        if rc == _lib.EUNSUPPORTED:
+            return False
+        check(rc, "dmvae_plan_prefetch_batch")
+        return True
+
+    def capture_step(self, data, perm, grad_sync=None, grad_scale=1.0, inv_B=None, pipelined=None):
         """Capture one full-batch step (device Philox noise, batch cursor read from
-        the device state) into a HIP graph; returns a callable that replays it."""
+        the device state) into a HIP graph; returns a callable that replays it.
+        pipelined: the step no longer starts with its batch gather -- each step assembles the NEXT batch under its own backward pass
+        (dmvae_plan_prefetch_batch: the gather rides on the idle CUs of the dZ launch, step_finalize one launch earlier) into the other
+        of two batch buffers.  Two graphs, one per buffer, replayed in turn; the callable assembles the batch of the device cursor itself
+        (one eager gather) whenever something other than its own replays has moved the cursor or touched the batch since (reset_epoch,
+        an eager step, encode ...).  Bit-identical to the plain graph (tests/test_gpu_step.py).  Default: batches of at most
+        PIPELINE_MAX_BATCH rows on plans that support it, no gradient exchange; DMVAE_PREFETCH=1 / 0 forces it on / off.  MEASURED
+        (round 4, tools/knob_step.py <cfg> pf 0 1 1 0, one engine, same buffers): 100 rows 0.1535 -> 0.1494 ms (-2.7 %; -3.4 % on
+        another box); 4096 rows 0.2704 vs 0.2700 (nothing: the launch it saves, 5.9 us, comes back as +1.8 us in the dZ launch and a few
+        tenths in most other kernels -- the batch is no longer fresh in the caches when the first layer reads it); 8192 rows, where the
+        dZ launch has no idle CUs and the gather is a launch of its own mid-backward, 0.6085 vs 0.6109 (+0.4 %)."""
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         saved = (self.param.clone(), self.m.clone(), self.v.clone(), self.state_t.clone())
@@ -595,6 +633,28 @@ class StepEngine:
         self._master_stale = False
         self.refresh_shadow()
         torch.cuda.synchronize(self.device)
+        if pipelined is None:
+            env = os.environ.get("DMVAE_PREFETCH", "")
+            pipelined = env == "1" if env in ("0", "1") else self.max_batch <= PIPELINE_MAX_BATCH
+        if grad_sync is None and pipelined and float(grad_scale) == 1.0 and self._prefetch_ok(data, perm, side):
+            graphs = []
+            for _ in range(2):                       # one graph per batch buffer; the plan is back on the first buffer afterwards
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    self._prefetch_batch(data, perm)
+                    self.forward_backward_update(None, None, None, inv_B)
+                check(lib.dmvae_plan_swap_batch(self._plan), "dmvae_plan_swap_batch")
+                graphs.append(g)
+            self._graph = tuple(graphs)
+            self._pf_primed, self._xsel = True, 0    # (_prefetch_ok left the batch of the device cursor in the first buffer; capturing ran nothing)
+
+            def replay_pipelined():
+                if not self._pf_primed:
+                    self._load_batch_for_step(data, perm, 0, None, True)
+                    self._pf_primed, self._xsel = True, 0
+                graphs[self._xsel].replay()
+                self._xsel ^= 1
+            return replay_pipelined
         if grad_sync is None:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):

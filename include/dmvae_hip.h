@@ -33,7 +33,7 @@ extern "C" {
  *    dmvae_prof_row.kernel_ms were added after version 1; a client compiled against an older header passes shorter
  *    structs, so every binding checks dmvae_abi_version() == DMVAE_ABI_VERSION when it loads the library. */
 /* 3: dmvae_plan_set_stage_groups added (no struct changed). */
-#define DMVAE_ABI_VERSION 3
+#define DMVAE_ABI_VERSION 4
 
 enum { DMVAE_F32 = 0, DMVAE_BF16 = 1 };
 
@@ -336,6 +336,16 @@ int dmvae_plan_load_batch(dmvae_plan* p, void* stream, const float* data, int64_
  * afterwards.  Any other plan: exactly dmvae_plan_load_batch. */
 int dmvae_plan_load_batch_step(dmvae_plan* plan, void* stream, const float* data, int64_t n_rows, const int32_t* perm,
                                int64_t first, int n_valid, int use_state_cursor);
+/* Batch assembly overlapped with the step (Dataset.get_batches, includes/utils.py:449-463, one batch ahead): arms the assembly of the NEXT
+ * batch inside the next dmvae_plan_forward_backward / _train_step -- by workgroups riding in one of its launches where that launch leaves
+ * them room, else by a gather launch of its own -- into the other of the plan's two bf16 batch buffers; with use_state_cursor the rows are
+ * those of the device cursor after that pass has advanced it.  dmvae_plan_swap_batch (host state only) then makes that batch the current
+ * one, in place of the dmvae_plan_load_batch_step in front of the following step.  DMVAE_EUNSUPPORTED on plans that assemble their batches
+ * with dmvae_plan_load_batch (f32, conv trunk, output layer on the macro tile).  `data` / `perm`: alive and unchanged until the step that
+ * consumes the batch has run.  A captured step holds the buffer it was captured with: capture one graph per buffer and alternate them. */
+int dmvae_plan_prefetch_batch(dmvae_plan* plan, const float* data, int64_t n_rows, const int32_t* perm, int64_t first, int n_valid,
+                              int use_state_cursor);
+int dmvae_plan_swap_batch(dmvae_plan* plan);
 /* forward + loss + backward: fills the grad arena and the loss partials.
  * eps / gumbel: caller-supplied noise (parity mode) or NULL (on-device Philox). */
 int dmvae_plan_forward_backward(dmvae_plan* p, void* stream, int n_valid,

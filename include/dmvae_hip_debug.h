@@ -72,7 +72,10 @@ int dmvae_debug_set_tile(int bm, int bn);
  *             knob 14 = blocks the latent kernel's geometry aims at (512; rows per block = 16 .. 64).  The plan sizes its partial sums for the largest
  *                       count and takes the count at enqueue time, so it may change while a plan exists.  1024 at 16384 rows: 0.9500 vs 0.9493 ms,
  *             knob 16 = where the step_finalize blocks run: 1 (default) as riders of the dZ GEMM while tiles + riders <= 256 (4096 rows), else of the
- *                       heads' dX launch; 2 always the heads' dX launch; 0 a launch of their own (0.2796 vs 0.2753 ms at 4096 rows) */
+ *                       heads' dX launch; 2 always the heads' dX launch; 0 a launch of their own (0.2796 vs 0.2753 ms at 4096 rows),
+ *             knob 17 = where the gather of a prefetched batch (dmvae_plan_prefetch_batch) runs: 1 (default) on the idle CUs of the dZ GEMM, one block
+ *                       each, in the last ids of its grid (12.98 us for that launch at 4096 rows, 11.2 without riders); 2 the same in the first ids
+ *                       (14.1 us); 3 two blocks per idle CU, last ids (15.5 us); 0 a launch of its own in front of the trunk's backward pass */
 int dmvae_debug_set_knob(int which, int value);
 
 #ifdef __cplusplus

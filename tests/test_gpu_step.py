@@ -22,6 +22,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import dmvae_oracle as O
 
 
+@pytest.fixture(scope="module")
+def hip():
+    from dmvae_hip import _lib
+    torch.cuda.set_device(0)
+    return _lib
+
+
 def make(cfg_kw, dtype, B, mode="exact", deterministic=True, seed=0):
     from dmvae_hip import StepEngine
     eng = StepEngine(dtype=dtype, max_batch=B, mode=mode, temperature=0.5, deterministic=deterministic, **cfg_kw)
@@ -314,6 +321,75 @@ def test_graph_replay_matches_eager_and_epoch_accounting():
     assert out[0][0] == out[1][0]
     assert torch.equal(out[0][4], out[1][4])
     assert 100 < out[0][0] < 600          # epoch-mean loss in nats, 784*ln2 = 543 at init
+
+
+@pytest.mark.parametrize("B,knobs", [(256, ()), (4096, ()), (4096, ((17, 0),)), (256, ((1, 0),)), (16384, ())])
+def test_pipelined_capture_equals_the_plain_graph(hip, B, knobs):
+    """capture_step's pipelined form (two graphs, each assembling the NEXT batch under its own backward pass: dmvae_plan_prefetch_batch /
+    dmvae_plan_swap_batch, riders of the trunk's dX launch) against the plain captured step (the gather in front): same loss, parameters,
+    moments, cursor -- over an epoch wrap, a reset_epoch in between, an eager step in between, an encode in between (each of which
+    makes the callable assemble the cursor's batch itself).  Placements: by default the gather rides in the dZ GEMM and step_finalize one
+    launch earlier, in the output layer's dX launch (256 and 4096 rows; knob 1 = 0: the four-wave tiles); knob 17 = 0, and 16 384 rows
+    (the dZ launch has no idle CUs there): the gather is a launch of its own in front of the trunk's backward pass."""
+    kw = dict(input_dim=784, latent_dim=64, n_classes=10)
+    N = 5 * B
+    X = torch.as_tensor(O.synthetic_images(min(N, 8192), 784, seed=18)).cuda()
+    if N > X.shape[0]: X = X.repeat((N + X.shape[0] - 1) // X.shape[0], 1)[:N].contiguous()
+    perm = torch.randperm(N, device="cuda").to(torch.int32)
+    try:
+        for k, v in knobs:
+            hip.check(hip.lib.dmvae_debug_set_knob(k, v))
+        plain, pipe = make(kw, "bf16", B, seed=6), make(kw, "bf16", B, seed=6)
+        for e in (plain, pipe):
+            e.reset_epoch(5)
+        rp, rq = plain.capture_step(X, perm, pipelined=False), pipe.capture_step(X, perm, pipelined=True)
+        assert len(plain._graph) == 1 and len(pipe._graph) == 2, "the pipelined form was not taken"
+
+        def both(n):
+            for _ in range(n):
+                rp(); rq()
+            torch.cuda.synchronize()
+            a, b = plain.read_state(), pipe.read_state()
+            assert (a.last_loss, a.epoch_loss, a.batch_cursor, a.adam_t, a.noise_step) == (b.last_loss, b.epoch_loss, b.batch_cursor, b.adam_t, b.noise_step)
+            for name in ("param", "m", "v", "param_bf16"):
+                assert torch.equal(getattr(plain, name), getattr(pipe, name)), name
+        both(7)                                   # wraps the 5-batch epoch: batches 0 1 2 3 4 0 1
+        for e in (plain, pipe):
+            e.reset_epoch(3)                      # cursor back to 0, another epoch length: the prefetched batch (2) is not the next one
+        both(4)
+        for e in (plain, pipe):
+            e.train_step(X, perm, use_state_cursor=True)     # an eager step between replays
+        both(3)
+        for e in (plain, pipe):                   # something else uses the batch buffer
+            e.load_batch(X[:B].contiguous(), None, 0, B); e.encode(B)
+        both(2)
+        assert plain.param.abs().sum().item() > 0
+    finally:
+        for k, v in knobs:
+            hip.check(hip.lib.dmvae_debug_set_knob(k, 1))
+
+
+def test_prefetch_refused_where_the_plan_cannot(hip):
+    """fp32 plans keep the f32 copy of the batch (dmvae_plan_load_batch): no prefetch; a swap without a pass behind the prefetch is refused"""
+    kw = dict(input_dim=784, latent_dim=64, n_classes=10)
+    X = torch.as_tensor(O.synthetic_images(512, 784, seed=3)).cuda()
+    f = make(kw, "fp32", 256, seed=1)
+    f._load_batch_for_step(X, None, 0, 256)
+    assert hip.lib.dmvae_plan_prefetch_batch(f._plan, hip.ptr(X), 512, None, 256, 256, 0) == hip.EUNSUPPORTED
+    rp = f.capture_step(X, None)                  # falls back to the plain graph
+    assert len(f._graph) == 1
+    b = make(kw, "bf16", 256, seed=1)
+    with pytest.raises(Exception, match="no current batch"):
+        b._prefetch_batch(X, None, 256, 256, False)
+    b._load_batch_for_step(X, None, 0, 256)
+    b._prefetch_batch(X, None, 256, 256, False)
+    assert hip.lib.dmvae_plan_swap_batch(b._plan) != 0        # nothing has run since
+    # explicit `first` (no device cursor), eager: prefetch -> step -> swap -> step == load -> step -> load -> step
+    ref = make(kw, "bf16", 256, seed=1)
+    b.forward_backward_update(256); hip.check(hip.lib.dmvae_plan_swap_batch(b._plan)); b.forward_backward_update(256)
+    ref.train_step(X, None, 256, None, None, 0, False); ref.train_step(X, None, 256, None, None, 256, False)
+    torch.cuda.synchronize()
+    assert b.read_state().last_loss == ref.read_state().last_loss and torch.equal(b.param, ref.param)
 
 
 def test_encode_decode_views():

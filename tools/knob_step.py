@@ -1,5 +1,5 @@
 """A/B a tuning knob on the step of a BASELINE.json config: interleaved rounds of HIP-graph replays on one box.
-python tools/knob_step.py <cfg1..cfg5> <knob> <values...>        (knobs: include/dmvae_hip_debug.h, dmvae_debug_set_knob)
+python tools/knob_step.py <cfg1..cfg5> <knob | pf> <values...>   (knobs: include/dmvae_hip_debug.h, dmvae_debug_set_knob; pf: the pipelined capture, 0 / 1)
 One engine; one captured graph per LISTED value, all on the same buffers; a value may be listed more than once.  CONTROL: list the values
 as  a b b a : the spread between the two graphs of the same value is the harness's own spread, and a difference between values means
 something only beyond it."""
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "deep-mixture-vae_amd")); sys.path.insert(0, ROOT)
 from dmvae_hip import StepEngine, _lib as L
 import bench
-cfg = bench.PRESETS[sys.argv[1]]; which = int(sys.argv[2]); values = [int(v) for v in sys.argv[3:]]
+cfg = bench.PRESETS[sys.argv[1]]; which = -1 if sys.argv[2] == "pf" else int(sys.argv[2]); values = [int(v) for v in sys.argv[3:]]      # "pf": capture_step(pipelined = value)
 torch.cuda.set_device(0)
 tup = lambda t: tuple(int(x) for x in t.split(","))
 B, I = cfg["batch"], cfg.get("input_dim", 784)
@@ -24,8 +24,17 @@ e = StepEngine(I, cfg["latent_dim"], cfg["n_clusters"], enc_layers=tup(cfg.get("
 e.init_parameters(0); e.write_state(lr=cfg.get("lr", 0.002)); e.reset_epoch(4)
 graphs = []
 for v in values:
-    L.check(L.lib.dmvae_debug_set_knob(which, v))
-    graphs.append(e.capture_step(data, perm))
+    if which >= 0: L.check(L.lib.dmvae_debug_set_knob(which, v))
+    if which < 0: L.check(L.lib.dmvae_debug_set_knob(17, v - 10 if v >= 10 else 1))   # pf 1x: pipelined with knob 17 = x (0: the gather as a launch of its own, ...)
+    if which < 0 and v == 3:                       # pf 3 (control): two PLAIN graphs replayed in turn -- what alternating graph executables costs by itself
+        pair = [e.capture_step(data, perm, pipelined=False) for _ in range(2)]
+        e._graph_keep = getattr(e, "_graph_keep", []) + [pair]
+        state = [0]
+        def alt(pair=pair, state=state):
+            pair[state[0]](); state[0] ^= 1
+        graphs.append(alt)
+        continue
+    graphs.append(e.capture_step(data, perm, pipelined=bool(v)) if which < 0 else e.capture_step(data, perm))
     e._graph_keep = getattr(e, "_graph_keep", []) + [e._graph]          # capture_step keeps only the latest graph alive
 res = {i: [] for i in range(len(values))}
 steps = 200 if B <= 4096 else 30
