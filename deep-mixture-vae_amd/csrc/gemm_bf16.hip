@@ -254,6 +254,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
     // the oldest vector-memory operations, so the counted vmcnt waits below stay exact.
     constexpr int NQ = BM * (BN / 4) / (64 * NW);
     float4 target[EPI == DMVAE_EPI_BIAS_RECON ? NQ : 1];       // BIAS_RECON: likewise the f32 reconstruction targets
+    unsigned target_zero = 0;                                   // bit q: quad q's target is zeros (a row / column outside the batch), whatever was loaded
     if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
         // recon_kind bit 8 (the plan's step path, dmvae_plan_load_batch_step): no f32 copy of the batch exists -- row m's targets are
         // row perm[first + m] of the dataset itself: aux0 = data [ld2 rows][ld0 = input_dim floats], aux1 = perm (int32 or null),
@@ -264,22 +265,40 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
             const dmvae_state* tst = reinterpret_cast<const dmvae_state*>(a.epi.aux2);
             tfirst = tst ? (int64_t)tst->batch_cursor * a.epi.d_off : a.epi.ld1;
         }
+        if (tg) {
+            // EVERY load unconditional (indices clamped, the result selected afterwards) and each stage issued for all NQ quads before the next: a
+            // load inside a divergent `if` is waited for at the join, and the first form -- [permutation entry -> vmcnt(0) -> target row] per quad,
+            // inside ifs -- ran its 2 NQ round trips one after the other in front of the K loop (seen in the ISA; round 4)
+            const int32_t* perm = reinterpret_cast<const int32_t*>(a.epi.aux1);
+            int64_t src[NQ];
+            bool ok[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int idx = q * (64 * NW) + tid;
-            const int ml = idx / (BN / 4), c = idx % (BN / 4);
-            if (tg) {
-                const int m = m0 + ml, n = n0 + c * 4;
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < a.epi.m_valid && n + 3 < (int)a.epi.ld0) {
-                    int64_t src = tfirst + m;
-                    const int32_t* perm = reinterpret_cast<const int32_t*>(a.epi.aux1);
-                    if (perm) src = perm[src];
-                    if (src >= 0 && src < a.epi.ld2) t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.epi.aux0) + src * a.epi.ld0 + n);
-                }
-                target[q] = t;
-            } else
-            target[q] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.epi.aux0) + (int64_t)(m0 + ml) * a.epi.ld0 + n0 + c * 4);
+            for (int q = 0; q < NQ; ++q) {
+                const int idx = q * (64 * NW) + tid;
+                const int m = m0 + idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
+                const int64_t sr = tfirst + m;
+                ok[q] = m < a.epi.m_valid && n + 3 < (int)a.epi.ld0 && sr >= 0 && sr < a.epi.ld2;      // (the permutation has ld2 = n_rows entries)
+                src[q] = ok[q] ? sr : 0;
+            }
+            if (perm) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) src[q] = (int64_t)perm[src[q]];
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int idx = q * (64 * NW) + tid;
+                const int n = n0 + (idx % (BN / 4)) * 4;
+                ok[q] = ok[q] && src[q] >= 0 && src[q] < a.epi.ld2;
+                target[q] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.epi.aux0) + (ok[q] ? src[q] * a.epi.ld0 + n : 0));
+                if (!ok[q]) target_zero |= 1u << q;          // (selected in the epilogue: touching the value here would wait for it in front of the ring's first loads)
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int idx = q * (64 * NW) + tid;
+                const int ml = idx / (BN / 4), c = idx % (BN / 4);
+                target[q] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.epi.aux0) + (int64_t)(m0 + ml) * a.epi.ld0 + n0 + c * 4);
+            }
         }
     }
     constexpr bool LAT_PRE = EPI == DMVAE_EPI_LATENT && NQ <= 4;       // (12 registers per quad: the small tiles only)
@@ -424,7 +443,8 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
             v[3] = __uint_as_float(y.y & 0xffff0000u) > 0.f ? v[3] : 0.f;
             ActIO<bf16_t>::store4(a.epi.out, (int64_t)(m0 + ml) * a.epi.ldo + n0 + c * 4, v);
         } else if constexpr (EPI == DMVAE_EPI_BIAS_RECON) {
-            const float xq[4] = {target[q].x, target[q].y, target[q].z, target[q].w};
+            const bool tz = (target_zero >> q) & 1u;
+            const float xq[4] = {tz ? 0.f : target[q].x, tz ? 0.f : target[q].y, tz ? 0.f : target[q].z, tz ? 0.f : target[q].w};
             epilogue_quad<EPI, bf16_t>(a.epi, m0 + ml, n0 + c * 4, v, loss, xq, nullptr, bq);
         } else if constexpr (LAT_PRE) {
             epilogue_quad<EPI, bf16_t>(a.epi, m0 + ml, n0 + c * 4, v, loss, lat[q]);

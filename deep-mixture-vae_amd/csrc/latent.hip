@@ -120,8 +120,20 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
     MEAS_LAT_STAMP(1);
     // ---- prologue: c_k, tables of chunk 0 into LDS, per-row softmax / zeta, KL_C ----
     for (int k = tid >> 4; k < K; k += 16) {
+        // four loads in flight per lane (index clamped, value selected): one load per trip of `for d: s += table[d]` was a memory round trip
+        // per trip, on the path to phase 1 -- most of the "prior-table staging 2.0 us" of profiles/r04_latent_phases.txt.  Same order of additions.
         float s = 0.f;
-        for (int d = lr; d < D; d += 16) s += a.prior_log_vars[(int64_t)k * D + d];
+        for (int d0 = lr; d0 < D; d0 += 64) {
+            float t[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d = d0 + 16 * i;
+                t[i] = a.prior_log_vars[(int64_t)k * D + (d < D ? d : 0)];
+                t[i] = d < D ? t[i] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s += t[i];
+        }
         s = row_sum16(s);
         if (lr == 0) ck[k] = s;
     }

@@ -58,7 +58,17 @@ __global__ __launch_bounds__(256) void latent_vade_kernel(dmvae_latent_args a) {
     }
     for (int k = rsub; k < K; k += 16) {
         float s = 0.f;
-        for (int d = lr; d < D; d += 16) s += a.prior_log_vars[(int64_t)k * D + d];
+        for (int d0 = lr; d0 < D; d0 += 64) {      // four loads in flight per lane (latent.hip: one load per trip was a round trip per trip); same order of additions
+            float t[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d = d0 + 16 * i;
+                t[i] = a.prior_log_vars[(int64_t)k * D + (d < D ? d : 0)];
+                t[i] = d < D ? t[i] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s += t[i];
+        }
         s = sum16(s);
         if (lr == 0) ck[k] = s;
     }
