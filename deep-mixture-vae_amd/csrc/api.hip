@@ -921,10 +921,15 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     bool fin_in_dz = false, fin_in_out = false;
     const int fin_lead = (fin.nblocks + 7) & ~7;
     GemmArgs dz_shape{}, out_shape{};           // (shapes only: what gemm_bf16_riders_room looks at)
-    dz_shape.M = p->Bp; dz_shape.N = p->Dp; dz_shape.K = p->dec.empty() ? 64 : p->dec[0].out_pad; dz_shape.epi.kind = DMVAE_EPI_LATENT;
+    dz_shape.M = p->Bp; dz_shape.N = p->Dp; dz_shape.K = p->dec.empty() ? 64 : p->dec[0].out_pad; dz_shape.epi.kind = DMVAE_EPI_LATENT; dz_shape.k_split = dz_shape.K;
     out_shape.M = p->Bp; out_shape.N = p->dec.empty() ? 64 : p->dec.back().out_pad; out_shape.K = p->Ip; out_shape.epi.kind = DMVAE_EPI_RELU_MASK;
     const int dz_room = (dt == DMVAE_BF16 && !p->dec.empty()) ? gemm_bf16_riders_room(dz_shape, true) : -1;
-    if (fin_rides && g_fin_rides == 1) fin_in_dz = dz_room >= fin_lead;
+    const int out_room = (dt == DMVAE_BF16 && !p->dec.empty()) ? gemm_bf16_riders_room(out_shape, false) : -1;
+    // knob 16 = 3: step_finalize as second workgroups of the output layer's dX launch whenever it has the room (free there: 0.2717 vs 0.2721 ms
+    // against the dZ placement) -- where it also goes by default when the dZ launch runs on its two-wave 16-row tiles, which cannot carry it
+    if (fin_rides && g_fin_rides == 3 && out_room >= fin_lead) fin_in_out = true;
+    if (fin_rides && g_fin_rides == 1) fin_in_dz = dz_room >= fin_lead && gemm_bf16_carries_finalize(dz_shape);
+    if (fin_rides && g_fin_rides == 1 && !fin_in_dz && out_room >= fin_lead) fin_in_out = true;      // (free there: 9.3 vs 9.2 us for that launch)
     // A prefetched batch (dmvae_plan_prefetch_batch): its gather takes the idle CUs of the dZ launch -- behind step_finalize, which has moved the
     // batch cursor on: those blocks then ride one launch EARLIER, as second workgroups of the output layer's dX launch (their inputs, the loss
     // partials, are complete behind the output layer's forward GEMM).  Without the room for both: step_finalize where it was, the gather as a
@@ -933,7 +938,7 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     if (p->pf.armed && (all || stage == 0)) {
         p->pf.gat = gather_args(DMVAE_BF16, p->pf.data, p->pf.n_rows, c.input_dim, p->pf.perm, p->pf.first, c.max_batch, p->pf.n_valid, p->Bp, XB(p, 1), p->Ip,
                                 nullptr, p->Ip, p->Ip, p->pf.st);
-        if (fin_rides && g_fin_rides == 1 && g_pf_rides && dz_room >= 64 && gemm_bf16_riders_room(out_shape, false) >= fin_lead) {
+        if (fin_rides && g_fin_rides == 1 && g_pf_rides && dz_room >= 64 && out_room >= fin_lead) {
             fin_in_dz = false; fin_in_out = true;
             rid_out.fin = fin; rid_out.nfin = fin_lead;
             rid_dz.gat = p->pf.gat;
@@ -942,6 +947,7 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
         }
     }
     if (fin_in_dz) { rid_dz.fin = fin; rid_dz.nfin = fin_lead; }
+    if (fin_in_out) { rid_out.fin = fin; rid_out.nfin = fin_lead; }
   if (all || stage == 0) {
     p->dw_queue.clear();
     p->csum_of.clear();
@@ -1361,6 +1367,7 @@ extern "C" int dmvae_debug_set_knob(int which, int value) {
     if (which == 13) { heads_dx_stream_set(value); return 0; }
     if (which == 16) { g_fin_rides = value; return 0; }
     if (which == 17) { g_pf_rides = value; return 0; }
+    if (which == 18) { gemm_bf16_set_knob(which, value); return 0; }
     if (which == 14) { latent_set_blocks_target(value); return 0; }      // (the block count in use is taken at enqueue time and checked against the plan's capacity)
     DMVAE_REQUIRE(which >= 0 && which <= 9 && which != 3, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, (3: removed, the deep-ring policy), 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy, 7 = short-K workgroups, 8 = first-tile stagger of the merged dW grid, 9 = waves per workgroup of a grouped dX launch; 10 / 11 = K slices of the dW groups, 12 = heads dX as one or two launches, 13 = heads dX on the streaming kernel (1) or the grouped tiles (0), 14 = blocks the latent kernel's geometry aims at (512)");
     gemm_bf16_set_knob(which, value);

@@ -635,6 +635,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_bf16_grouped_ke
 }
 
 // ---------------------------------------------------------------- host side
+static int g_thin = 2;                     // tuning knob (dmvae_debug_set_knob 18): thin tiles for the dZ GEMM (gemm_bf16_thin_rows): 0 never, 1 down to 32 rows, 2 down to 16
 static int g_group_m = 0;                   // tuning knob (dmvae_debug_set_knob 0): supertile rows, 0 = automatic
 // Supertile height.  An XCD owns a run of R = tiles/8 consecutive tile ids and walks it in
 // supertiles gm tile-rows high, so its L2 sees ~gm A panels (BM x K each) and ~R/gm B panels
@@ -958,6 +959,19 @@ void gemm_bf16_set_knob(int which, int v) {
     if (which == 7) g_shortk = v;
     if (which == 8) gemm_bf16_256_set_stagger(v);
     if (which == 9) g_dx_group_nw = v;
+    if (which == 18) g_thin = v;
+}
+
+// A thin launch (few 64 x 64 tiles, long K: the dZ GEMM at 4096 rows is 64 tiles of 32 K tiles) is bound by the per-CU intake of its activations --
+// written by the previous launch from other XCDs, nothing of them in this XCD's L2: ~35 GB/s per CU -- times the CUs it occupies (MEASURED round 4:
+// neither an 8-slot ring nor two K pipelines per workgroup moved it).  32- / 16-row tiles put two / four times the CUs on the same bytes; the
+// weight panel each workgroup re-reads comes from L2.  The dZ launch at 4096 rows (rocprofv3, 302 replays): 11.49 us on 64 tiles of 64 rows,
+// 10.19 on 128 of 32 rows, 8.92 on 256 of 16 rows (two waves per workgroup; the step_finalize blocks then ride in the output layer's dX launch).
+static int gemm_bf16_thin_rows(const GemmArgs& a) {      // 0: the general tiles; 32 / 16: rows of the thin tile -- the thinnest that still fits one round of 256 CUs
+    if (!g_thin || a.conv_c || a.N != 64 || a.K < 1024 || a.k_split != a.K) return 0;
+    if (g_thin >= 2 && a.M % 16 == 0 && a.M / 16 <= 256) return 16;
+    if (a.M % 32 == 0 && a.M / 32 <= 256) return 32;
+    return 0;
 }
 
 // Tile choice, BM*1000+BN.  These GEMMs run at the per-CU L2->LDS streaming rate, so the figure
@@ -1038,6 +1052,18 @@ static int launch_tiled(hipStream_t s, const GemmArgs& a0, int split, const Gemm
     //  workgroup per CU by LDS -- was knob 3 until round 4: 0.2926 vs 0.2860 ms per step at cfg2; the K loop of a 4096x512x512 layer
     //  took 2.92 vs 2.96 us and its first tile landed 0.5 us later.  Removed with its 18 instantiations, which also could not meet
     //  the two-workgroups-per-CU register bound of the kernel template.)
+    if constexpr (LAYOUT == DMVAE_GEMM_DX && EPI == DMVAE_EPI_LATENT) {
+        const int thin = gemm_bf16_thin_rows(a);   // the dZ GEMM on 32- or 16-row tiles: two / four times the CUs streaming its activations
+        if (thin == 32) {
+            a.group_m = gemm_auto_group_m(a.M / 32, a.N / 64, 32, 64);
+            return launch<32, 64, LAYOUT, EPI, 4>(s, a, split, riders);
+        }
+        if (thin == 16) {
+            if (riders && riders->nfin) { set_error("gemm_bf16: the 16-row tile (two waves) cannot carry the step_finalize blocks"); return DMVAE_EINVAL; }
+            a.group_m = gemm_auto_group_m(a.M / 16, a.N / 64, 16, 64);
+            return launch<16, 64, LAYOUT, EPI, 4, 2>(s, a, split, riders);
+        }
+    }
     switch (t) {
         case 128128:
             return g_nw8 ? launch<128, 128, LAYOUT, EPI, 2, 8>(s, a, split, riders) : launch<128, 128, LAYOUT, EPI, 2>(s, a, split, riders);
@@ -1056,9 +1082,12 @@ int gemm_bf16_riders_room(const GemmArgs& a, bool own_cu) {
     if (a.epi.kind != DMVAE_EPI_LATENT && a.epi.kind != DMVAE_EPI_RELU_MASK) return -1;
     int t = gemm_bf16_tile_m(a.M, a.N, 1);
     if (g_shortk && a.K <= 128) t = 64064;
+    if (a.epi.kind == DMVAE_EPI_LATENT && gemm_bf16_thin_rows(a)) t = gemm_bf16_thin_rows(a) * 1000 + 64;
     const int tiles = (a.M / (t / 1000)) * (a.N / (t % 1000));
     return (own_cu ? 256 : 512) - tiles;
 }
+
+bool gemm_bf16_carries_finalize(const GemmArgs& a) { return !(a.epi.kind == DMVAE_EPI_LATENT && gemm_bf16_thin_rows(a) == 16); }
 
 int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split, const GemmRiders* riders) {
     const int epi = a.epi.kind;

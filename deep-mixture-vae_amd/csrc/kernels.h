@@ -18,6 +18,7 @@ struct AdamArgs {
 // riders: the step_finalize blocks as extra workgroups of this launch (the dense DX / LATENT GEMM only: gemm_bf16_dz_riders_kernel)
 int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split, const GemmRiders* riders = nullptr);
 int gemm_bf16_riders_room(const GemmArgs& a, bool own_cu);
+bool gemm_bf16_carries_finalize(const GemmArgs& a);      // false: this launch's tile has fewer than four waves (step_finalize_block needs 256 threads)
 int gemm_bf16_grouped_dw(hipStream_t s, const GemmArgs* probs, int nprob);
 // fin: the step_finalize blocks ride as extra workgroups of this launch (DX / RELU_MASK groups only)
 int gemm_bf16_grouped(hipStream_t s, int layout, const GemmArgs* probs, int nprob, const dmvae_finalize_args* fin = nullptr);

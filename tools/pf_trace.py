@@ -9,6 +9,8 @@ B, I = 4096, 784
 data = torch.rand((4 * B, I), device="cuda"); perm = torch.randperm(4 * B, device="cuda").to(torch.int32)
 e = StepEngine(I, 64, 10, dtype="bf16", max_batch=B); e.init_parameters(0); e.write_state(lr=0.002); e.reset_epoch(4)
 k = int(sys.argv[1])
+for kv in os.environ.get("DMVAE_KNOBS", "").split(","):          # e.g. DMVAE_KNOBS=18=2
+    if kv: L.check(L.lib.dmvae_debug_set_knob(int(kv.split("=")[0]), int(kv.split("=")[1])))
 if k >= 0: L.check(L.lib.dmvae_debug_set_knob(17, k))
 rp = e.capture_step(data, perm, pipelined=k >= 0)
 for _ in range(300): rp()
