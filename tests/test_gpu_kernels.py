@@ -243,6 +243,39 @@ def test_epilogues(hip, dtype):
     np.testing.assert_allclose(o[:, D:], dZ * clv + glv, atol=tol * 3, rtol=tol)
 
 
+@pytest.mark.parametrize("M,K,form", [(256, 1024, "16-row tiles"), (4096, 2048, "16-row tiles, one round of 256"), (8192, 1024, "32-row tiles"),
+                                      (16384, 1024, "the general 64 x 64 tiles (thin ones would not fit one round)")])
+def test_dz_gemm_on_thin_tiles(hip, M, K, form):
+    """The dZ GEMM (DX layout, LATENT epilogue, 64 columns, K >= 1024) runs on the thinnest of 16- / 32-row tiles that fits one round of the
+    chip (gemm_bf16_thin_rows): against the float64 product of the bf16 operands, and bit-identical to the general 64 x 64 tiles (knob 18 = 0):
+    the same MFMA chain per output element, k ascending, whatever the tile height."""
+    L = hip
+    D = 64
+    g = torch.Generator(device="cuda"); g.manual_seed(M + K)
+    A = (torch.randn(M, K, device="cuda", generator=g) * 0.2).bfloat16()
+    W = (torch.randn(D, K, device="cuda", generator=g) * 0.2).bfloat16()
+    gmu, glv, clv = (torch.randn(M, D, device="cuda", generator=g) for _ in range(3))
+    outs = []
+    for knob in (0, 2):
+        L.check(L.lib.dmvae_debug_set_knob(18, knob))
+        try:
+            out = torch.full((M + 64, 2 * D), 7.0, device="cuda", dtype=torch.bfloat16)
+            e = L.Epilogue(); e.kind = L.EPI_LATENT; e.out, e.ldo, e.d_off = out.data_ptr(), 2 * D, D
+            e.aux0, e.ld0, e.aux1, e.ld1, e.aux2, e.ld2 = gmu.data_ptr(), D, glv.data_ptr(), D, clv.data_ptr(), D
+            L.check(L.lib.dmvae_gemm(stream(), L.BF16, 1, M, D, K, L.ptr(A), K, L.ptr(W), K, C.byref(e), 1))
+            torch.cuda.synchronize()
+            outs.append(out)
+        finally:
+            L.check(L.lib.dmvae_debug_set_knob(18, 2))
+    assert torch.equal(outs[0], outs[1]), form
+    assert bool((outs[1][M:] == 7.0).all()), "stray store below the output"
+    dZ = A.double() @ W.double().t()
+    o = outs[1][:M].double()
+    scale = float(dZ.abs().max())
+    assert float((o[:, :D] - (dZ + gmu.double())).abs().max()) <= 2e-2 * max(1.0, scale)
+    assert float((o[:, D:] - (dZ * clv.double() + glv.double())).abs().max()) <= 2e-2 * max(1.0, scale) * max(1.0, float(clv.abs().max()))
+
+
 def test_gemm_rejects_unaligned_shapes(hip):
     L = hip
     a = torch.zeros(64 * 64, dtype=torch.float32, device="cuda")
