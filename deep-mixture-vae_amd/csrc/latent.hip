@@ -159,10 +159,18 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
         const bool valid = b < a.B;
         // this lane's clusters k = lr + 16 i: the first KF logits (and Gumbel draws) live in registers
         float lg[KF], gk[KF];
+        if (!first) {                 // (later rows of the block: one batch of unconditional loads, row and column clamped -- see phase 1a)
+            const int64_t bb = valid ? b : 0;
+#pragma unroll
+            for (int i = 0; i < KF; ++i) {
+                const int k = lr + 16 * i;
+                lg[i] = a.logits[bb * a.ld_logits + (k < K ? k : 0)];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < KF; ++i) {
             const int k = lr + 16 * i;
-            lg[i] = first ? lg_pre[i] : ((valid && k < K) ? a.logits[(int64_t)b * a.ld_logits + k] : 0.f);
+            lg[i] = first ? lg_pre[i] : ((valid && k < K) ? lg[i] : 0.f);
             gk[i] = 0.f;
             if (MODE == 1 && valid && k < K)
                 gk[i] = a.gumbel ? a.gumbel[(int64_t)b * a.ld_gumbel + k] : philox_gumbel_at(a.seed, nstep, 1u, (uint64_t)b * K + k);
@@ -257,6 +265,24 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                 }
             }
             MEAS_LAT_STAMP(7);
+            // this row's mean / log_var / eps: the block's first row was fetched at kernel entry; every later row (32 and 64 rows per block:
+            // batches >= 16 384) in ONE batch of unconditional loads (row and column clamped, values used only where valid): inside the
+            // `if (ok) { if (valid) {` below each of them was a memory round trip of its own, waited for at the join
+            float mu_r[DSL], lv_r[DSL], ep_r[DSL];
+            if (first) {
+#pragma unroll
+                for (int i = 0; i < DSL; ++i) { mu_r[i] = mu_pre[i]; lv_r[i] = lv_pre[i]; ep_r[i] = ep_pre[i]; }
+            } else {
+                const int64_t bb = valid ? b : 0;               // (row 0 exists)
+#pragma unroll
+                for (int i = 0; i < DSL; ++i) {
+                    const int d = lr + 16 * i;
+                    const int dgc = d0 + (d < dc ? d : 0);
+                    mu_r[i] = a.mean[bb * a.ld_mean + dgc];
+                    lv_r[i] = a.log_var[bb * a.ld_log_var + dgc];
+                    ep_r[i] = a.eps ? a.eps[bb * a.ld_eps + dgc] : 0.f;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < DSL; ++i) {
                 const int d = lr + 16 * i;
@@ -266,11 +292,11 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
                     const int dg = d0 + d;
                     float z = 0.f, cl = 0.f;
                     if (valid) {
-                        mu[i] = first ? mu_pre[i] : a.mean[(int64_t)b * a.ld_mean + dg];
-                        lvv[i] = first ? lv_pre[i] : a.log_var[(int64_t)b * a.ld_log_var + dg];
+                        mu[i] = mu_r[i];
+                        lvv[i] = lv_r[i];
                         e[i] = __expf(lvv[i]);
                         const float sd = __expf(0.5f * lvv[i]);
-                        const float ep = a.eps ? (first ? ep_pre[i] : a.eps[(int64_t)b * a.ld_eps + dg]) : nz[i];
+                        const float ep = a.eps ? ep_r[i] : nz[i];
                         z = mu[i] + sd * ep;
                         cl = ep * 0.5f * sd;
                         lvsum += lvv[i];
