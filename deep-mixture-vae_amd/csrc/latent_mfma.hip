@@ -110,25 +110,85 @@ __global__ __launch_bounds__(256) void latent_pre_kernel(LatentMfmaArgs L, int n
     float* Wm = L.ws + L.w.Wm + (int64_t)b * Kp;
     float* X1 = L.ws + L.w.X1 + (int64_t)b * XW;
 
-    // softmax over K (lane owns k = lane16 + 16 i), KL_C
-    float mx = -INFINITY;
-    for (int k = lane16; k < K; k += 16) mx = fmaxf(mx, valid ? a.logits[(int64_t)b * a.ld_logits + k] : 0.f);
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
-    float se = 0.f;
-    for (int k = lane16; k < K; k += 16) se += __expf((valid ? a.logits[(int64_t)b * a.ld_logits + k] : 0.f) - mx);
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o, 16);
+    // softmax over K (lane owns k = lane16 + 16 i), KL_C.  Loads of a pad row read row 0 (their values are not used): every load below is
+    // unconditional -- a load inside a divergent `if` (or `cond ? load : 0`) is waited for at the join, and the three passes over the logits
+    // were twelve memory round trips per row at K = 50 (round 4; the same arithmetic in the same order)
+    const int64_t br = valid ? b : 0;
+    const float* lrow = a.logits + br * a.ld_logits;
     const float logK = __logf((float)K);
     float kc = 0.f;
-    for (int k = lane16; k < Kp; k += 16) {
-        float q = 0.f;
-        if (valid && k < K) {
-            q = __expf(a.logits[(int64_t)b * a.ld_logits + k] - mx) / se;
-            kc += q * (__logf(q + 1e-20f) + logK);
+    if (K <= 64) {            // a lane's clusters fit four registers: one batch of loads serves the three passes
+        float v[4];
+        bool in[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = lane16 + 16 * j;
+            in[j] = k < K;
+            v[j] = lrow[in[j] ? k : 0];
+            v[j] = valid ? v[j] : 0.f;
         }
-        Wm[k] = q;
-        if (a.weights && k < K) a.weights[(int64_t)b * a.ld_w + k] = q;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mx = in[j] ? fmaxf(mx, v[j]) : mx;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+        float se = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) se += in[j] ? __expf(v[j] - mx) : 0.f;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o, 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = lane16 + 16 * j;
+            if (k < Kp) {
+                float q = 0.f;
+                if (valid && in[j]) {
+                    q = __expf(v[j] - mx) / se;
+                    kc += q * (__logf(q + 1e-20f) + logK);
+                }
+                Wm[k] = q;
+                if (a.weights && in[j]) a.weights[(int64_t)b * a.ld_w + k] = q;
+            }
+        }
+    } else {
+        float mx = -INFINITY;
+        for (int k0 = lane16; k0 < K; k0 += 64) {          // four loads in flight per lane and trip
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = lrow[k0 + 16 * j < K ? k0 + 16 * j : 0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mx = k0 + 16 * j < K ? fmaxf(mx, valid ? v[j] : 0.f) : mx;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+        float se = 0.f;
+        for (int k0 = lane16; k0 < K; k0 += 64) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = lrow[k0 + 16 * j < K ? k0 + 16 * j : 0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) se += k0 + 16 * j < K ? __expf((valid ? v[j] : 0.f) - mx) : 0.f;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o, 16);
+        for (int k0 = lane16; k0 < Kp; k0 += 64) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = lrow[k0 + 16 * j < K ? k0 + 16 * j : 0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + 16 * j;
+                if (k < Kp) {
+                    float q = 0.f;
+                    if (valid && k < K) {
+                        q = __expf(v[j] - mx) / se;
+                        kc += q * (__logf(q + 1e-20f) + logK);
+                    }
+                    Wm[k] = q;
+                    if (a.weights && k < K) a.weights[(int64_t)b * a.ld_w + k] = q;
+                }
+            }
+        }
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) kc += __shfl_xor(kc, o, 16);
@@ -138,6 +198,64 @@ __global__ __launch_bounds__(256) void latent_pre_kernel(LatentMfmaArgs L, int n
     const bool vec = (D % 4 == 0) && (a.ld_mean % 4 == 0) && (a.ld_log_var % 4 == 0) && (a.ld_g % 4 == 0) && (a.ld_Z % 4 == 0) &&
                      (!a.eps || a.ld_eps % 4 == 0) && (!a.Z_f32 || a.ld_Zf % 4 == 0);
     float lvsum = 0.f;
+    if (vec) {
+        // four quads per lane and trip: their 12 loads issued together, unconditionally (pad rows read row 0, pad quads read quad 0); the outputs
+        // as 8- / 16-byte stores.  Same arithmetic as the general loop below.
+        const float* mrow = a.mean + br * a.ld_mean;
+        const float* vrow = a.log_var + br * a.ld_log_var;
+        const float* erow = a.eps ? a.eps + br * a.ld_eps : nullptr;
+        const int nq = Dp / 4;
+        for (int q0 = lane16; q0 < nq; q0 += 64) {
+            float4 m4[4], l4[4], e4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int d0 = 4 * (q0 + 16 * u);
+                const int off = (q0 + 16 * u < nq && d0 < D) ? d0 : 0;
+                m4[u] = *reinterpret_cast<const float4*>(mrow + off);
+                l4[u] = *reinterpret_cast<const float4*>(vrow + off);
+                e4[u] = erow ? *reinterpret_cast<const float4*>(erow + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q4 = q0 + 16 * u, d0 = 4 * q4;
+                if (q4 >= nq) continue;
+                const bool in = valid && d0 < D;            // (D % 4 == 0 here: the whole quad)
+                float mu[4] = {in ? m4[u].x : 0.f, in ? m4[u].y : 0.f, in ? m4[u].z : 0.f, in ? m4[u].w : 0.f};
+                const float lv[4] = {in ? l4[u].x : 0.f, in ? l4[u].y : 0.f, in ? l4[u].z : 0.f, in ? l4[u].w : 0.f};
+                float ep[4] = {in ? e4[u].x : 0.f, in ? e4[u].y : 0.f, in ? e4[u].z : 0.f, in ? e4[u].w : 0.f};
+                if (in && !a.eps) philox_normal4(a.seed, nstep, 0u, (uint64_t)b * (Dp / 4) + q4, ep);
+                float z[4], cl[4], x1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float e = __expf(lv[j]), sd = __expf(0.5f * lv[j]);
+                    z[j] = in ? mu[j] + sd * ep[j] : 0.f;
+                    cl[j] = in ? ep[j] * 0.5f * sd : 0.f;
+                    x1[j] = in ? e + mu[j] * mu[j] : 0.f;
+                    lvsum += in ? lv[j] : 0.f;
+                }
+                *reinterpret_cast<float4*>(X1 + d0) = make_float4(x1[0], x1[1], x1[2], x1[3]);
+                *reinterpret_cast<float4*>(X1 + Dp + d0) = make_float4(mu[0], mu[1], mu[2], mu[3]);
+                if (d0 + 4 <= a.ld_Z) {
+                    if (a.act_dtype == DMVAE_BF16) {
+                        uint2 pk;
+                        pk.x = pack2bf(z[0], z[1]); pk.y = pack2bf(z[2], z[3]);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.Z_act) + (int64_t)b * a.ld_Z + d0) = pk;
+                    } else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.Z_act) + (int64_t)b * a.ld_Z + d0) = make_float4(z[0], z[1], z[2], z[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (d0 + j < a.ld_Z) {
+                            if (a.act_dtype == DMVAE_BF16) reinterpret_cast<bf16_t*>(a.Z_act)[(int64_t)b * a.ld_Z + d0 + j] = f2bf(z[j]);
+                            else reinterpret_cast<float*>(a.Z_act)[(int64_t)b * a.ld_Z + d0 + j] = z[j];
+                        }
+                }
+                if (d0 < D) {
+                    if (a.Z_f32) *reinterpret_cast<float4*>(a.Z_f32 + (int64_t)b * a.ld_Zf + d0) = make_float4(z[0], z[1], z[2], z[3]);
+                    *reinterpret_cast<float4*>(a.clv + (int64_t)b * a.ld_g + d0) = make_float4(cl[0], cl[1], cl[2], cl[3]);
+                }
+            }
+        }
+    } else
     for (int q4 = lane16; q4 < Dp / 4; q4 += 16) {
         const int d0 = 4 * q4;
         float mu[4] = {0.f, 0.f, 0.f, 0.f}, lv[4] = {0.f, 0.f, 0.f, 0.f}, ep[4] = {0.f, 0.f, 0.f, 0.f};
@@ -243,7 +361,40 @@ __global__ __launch_bounds__(256) void latent_post_kernel(LatentMfmaArgs L, int 
     auto Ssum = [&](int k) { float v = S0[k]; for (int sl = 1; sl < L.w.nsplit_s; ++sl) v += S0[sl * sstr + k]; return v; };
     const float* Wm = L.ws + L.w.Wm + (int64_t)b * Kp;
     const float* X1 = L.ws + L.w.X1 + (int64_t)b * XW;
-    // gradients wrt mean / log_var
+    // gradients wrt mean / log_var.  Aligned shapes: four quads per lane and trip, every load unconditional (a pad row reads row 0 of log_var),
+    // 16-byte stores -- the general loop below fetched log_var one element at a time inside `if (d < D)`, a memory round trip each
+    const int64_t br = valid ? b : 0;
+    if (D % 4 == 0 && a.ld_log_var % 4 == 0 && a.ld_g % 4 == 0) {
+        const float* vrow = a.log_var + br * a.ld_log_var;
+        const int nq = D / 4;
+        for (int q0 = lane16; q0 < nq; q0 += 64) {
+            float4 A4[4], C4[4], M4[4], V4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int d0 = q0 + 16 * u < nq ? 4 * (q0 + 16 * u) : 0;
+                A4[u] = *reinterpret_cast<const float4*>(AC + d0);
+                C4[u] = *reinterpret_cast<const float4*>(AC + Dp + d0);
+                M4[u] = *reinterpret_cast<const float4*>(X1 + Dp + d0);
+                V4[u] = *reinterpret_cast<const float4*>(vrow + d0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (q0 + 16 * u >= nq) continue;
+                const int d0 = 4 * (q0 + 16 * u);
+                const float A[4] = {A4[u].x, A4[u].y, A4[u].z, A4[u].w}, Cc[4] = {C4[u].x, C4[u].y, C4[u].z, C4[u].w};
+                const float mu[4] = {M4[u].x, M4[u].y, M4[u].z, M4[u].w}, lv[4] = {V4[u].x, V4[u].y, V4[u].z, V4[u].w};
+                float gm[4], gl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float e = valid ? __expf(lv[j]) : 0.f;
+                    gm[j] = valid ? rB * (mu[j] * A[j] - Cc[j]) : 0.f;
+                    gl[j] = valid ? rB2 * (e * A[j] - 1.f) : 0.f;
+                }
+                *reinterpret_cast<float4*>(a.gmu + (int64_t)b * a.ld_g + d0) = make_float4(gm[0], gm[1], gm[2], gm[3]);
+                *reinterpret_cast<float4*>(a.glv + (int64_t)b * a.ld_g + d0) = make_float4(gl[0], gl[1], gl[2], gl[3]);
+            }
+        }
+    } else
     for (int q4 = lane16; q4 < (D + 3) / 4; q4 += 16) {
         const int d0 = 4 * q4;
         const float4 A4 = *reinterpret_cast<const float4*>(AC + d0);
@@ -263,6 +414,53 @@ __global__ __launch_bounds__(256) void latent_post_kernel(LatentMfmaArgs L, int 
     // KL_Z and the gradient wrt the logits
     const float rl = L.ws[L.w.RL + b], logK = __logf((float)K);
     float s_wdw = 0.f, s_qdq = 0.f, klz = 0.f;
+    if (K <= 64) {            // a lane's clusters fit four registers: one batch of unconditional loads serves both passes (same arithmetic, same order)
+        float w[4], t[4], dq[4];
+        bool in[4];
+        float ss[4], c2v[4], ckv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = lane16 + 16 * j;
+            in[j] = k < K;
+            const int kk = in[j] ? k : 0;
+            w[j] = Wm[kk]; ss[j] = S0[kk]; c2v[j] = L.ws[L.w.c2 + kk]; ckv[j] = L.ws[L.w.ck + kk];
+        }
+        for (int sl = 1; sl < L.w.nsplit_s; ++sl) {
+            float sv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sv[j] = S0[sl * sstr + (in[j] ? lane16 + 16 * j : 0)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ss[j] += sv[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[j] = ss[j] + c2v[j] + ckv[j] - rl - (float)D;
+            dq[j] = rB * (__logf(w[j] + 1e-20f) + w[j] / (w[j] + 1e-20f) + logK);
+            if (in[j]) {
+                klz += 0.5f * w[j] * t[j];
+                s_wdw += w[j] * (rB2 * t[j]);
+                s_qdq += w[j] * dq[j];
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            s_wdw += __shfl_xor(s_wdw, o, 16); s_qdq += __shfl_xor(s_qdq, o, 16); klz += __shfl_xor(klz, o, 16);
+        }
+        for (int k = lane16; k < a.ld_dl; k += 16) {
+            float dl = 0.f;
+            const int j = (k - lane16) >> 4;
+            if (k < K && valid) {
+                const float wj = j == 0 ? w[0] : j == 1 ? w[1] : j == 2 ? w[2] : w[3];
+                const float tj = j == 0 ? t[0] : j == 1 ? t[1] : j == 2 ? t[2] : t[3];
+                const float dj = j == 0 ? dq[0] : j == 1 ? dq[1] : j == 2 ? dq[2] : dq[3];
+                dl = wj * (dj - s_qdq) + wj * (rB2 * tj - s_wdw);
+            }
+            if (a.act_dtype == DMVAE_BF16) reinterpret_cast<bf16_t*>(a.dlogits_act)[(int64_t)b * a.ld_dl + k] = f2bf(dl);
+            else reinterpret_cast<float*>(a.dlogits_act)[(int64_t)b * a.ld_dl + k] = dl;
+        }
+        klz_acc += valid ? klz : 0.f;
+        continue;
+    }
     for (int k = lane16; k < K; k += 16) {
         const float w = Wm[k];
         const float t = Ssum(k) + L.ws[L.w.c2 + k] + L.ws[L.w.ck + k] - rl - (float)D;
