@@ -15,7 +15,8 @@ struct AdamArgs {
 };
 
 #define DMVAE_MAX_GROUP 16
-// riders: the step_finalize blocks as extra workgroups of this launch (the dense DX / LATENT GEMM only: gemm_bf16_dz_riders_kernel)
+// riders: the step_finalize blocks and / or the gather of the next batch as extra workgroups of this launch (dense small-tile DX launches with the
+// LATENT or RELU_MASK epilogue: gemm_bf16_dx_riders_kernel; ask gemm_bf16_riders_room / gemm_bf16_carries_finalize first)
 int gemm_bf16_dispatch(hipStream_t s, int layout, const GemmArgs& a, int split, const GemmRiders* riders = nullptr);
 int gemm_bf16_riders_room(const GemmArgs& a, bool own_cu);
 bool gemm_bf16_carries_finalize(const GemmArgs& a);      // false: this launch's tile has fewer than four waves (step_finalize_block needs 256 threads)
