@@ -369,6 +369,29 @@ def test_pipelined_capture_equals_the_plain_graph(hip, B, knobs):
             hip.check(hip.lib.dmvae_debug_set_knob(k, 1))
 
 
+def test_pipelined_capture_is_the_default_for_small_batches_only(monkeypatch):
+    """capture_step's default: pipelined up to PIPELINE_MAX_BATCH rows (measured: -2.7 % at 100 rows, nothing at 4096), DMVAE_PREFETCH=0 / 1 forces"""
+    from dmvae_hip import runtime
+    kw = dict(input_dim=784, latent_dim=64, n_classes=10)
+    monkeypatch.delenv("DMVAE_PREFETCH", raising=False)
+    for B, want in ((256, 2), (runtime.PIPELINE_MAX_BATCH, 2), (2048, 1)):
+        X = torch.rand((2 * B, 784), device="cuda")
+        perm = torch.randperm(2 * B, device="cuda").to(torch.int32)
+        e = make(kw, "bf16", B, seed=1); e.reset_epoch(2)
+        e.capture_step(X, perm)
+        assert len(e._graph) == want, B
+    monkeypatch.setenv("DMVAE_PREFETCH", "0")
+    e = make(kw, "bf16", 256, seed=1); e.reset_epoch(2)
+    X = torch.rand((512, 784), device="cuda"); perm = torch.randperm(512, device="cuda").to(torch.int32)
+    e.capture_step(X, perm)
+    assert len(e._graph) == 1
+    monkeypatch.setenv("DMVAE_PREFETCH", "1")
+    e = make(kw, "bf16", 2048, seed=1); e.reset_epoch(2)
+    X = torch.rand((4096, 784), device="cuda"); perm = torch.randperm(4096, device="cuda").to(torch.int32)
+    e.capture_step(X, perm)
+    assert len(e._graph) == 2
+
+
 def test_prefetch_refused_where_the_plan_cannot(hip):
     """fp32 plans keep the f32 copy of the batch (dmvae_plan_load_batch): no prefetch; a swap without a pass behind the prefetch is refused"""
     kw = dict(input_dim=784, latent_dim=64, n_classes=10)
