@@ -100,7 +100,7 @@ def layer_table(input_dim, latent_dim, n_classes, enc_layers, head_dim, dec_laye
     return t
 
 
-PIPELINE_MAX_BATCH = 1024      # capture_step: batches up to this many rows assemble the next batch under the running step by default (measured: see capture_step)
+PIPELINE_MAX_BATCH = 2048      # capture_step: batches up to this many rows assemble the next batch under the running step by default (measured: see capture_step)
 
 
 class StepEngine:
@@ -613,8 +613,8 @@ class StepEngine:
         (one eager gather) whenever something other than its own replays has moved the cursor or touched the batch since (reset_epoch,
         an eager step, encode ...).  Bit-identical to the plain graph (tests/test_gpu_step.py).  Default: batches of at most
         PIPELINE_MAX_BATCH rows on plans that support it, no gradient exchange; DMVAE_PREFETCH=1 / 0 forces it on / off.  MEASURED
-        (round 4, tools/knob_step.py <cfg> pf 0 1 1 0, one engine, same buffers): 100 rows 0.1535 -> 0.1494 ms (-2.7 %; -3.4 % on
-        another box); 4096 rows 0.2704 vs 0.2700 (nothing: the launch it saves, 5.9 us, comes back as +1.8 us in the dZ launch and a few
+        (round 4, tools/knob_step.py <cfg>[:batch=N] pf 0 1 1 0, one engine, same buffers): 100 rows 0.1535 -> 0.1494 ms (-2.7 %; -3.4 % on
+        another box); 256 / 512 / 1024 / 2048 rows -2.8 / -2.5 / -2.6 / -1.7 %; 4096 rows 0.2704 vs 0.2700 (nothing: the launch it saves, 5.9 us, comes back as +1.8 us in the dZ launch and a few
         tenths in most other kernels -- the batch is no longer fresh in the caches when the first layer reads it); 8192 rows, where the
         dZ launch has no idle CUs and the gather is a launch of its own mid-backward, 0.6085 vs 0.6109 (+0.4 %)."""
         side = torch.cuda.Stream(device=self.device)

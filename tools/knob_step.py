@@ -1,5 +1,5 @@
 """A/B a tuning knob on the step of a BASELINE.json config: interleaved rounds of HIP-graph replays on one box.
-python tools/knob_step.py <cfg1..cfg5> <knob | pf> <values...>   (knobs: include/dmvae_hip_debug.h, dmvae_debug_set_knob; pf: the pipelined capture, 0 / 1)
+python tools/knob_step.py <cfg1..cfg5>[:batch=N] <knob | pf> <values...>   (knobs: include/dmvae_hip_debug.h, dmvae_debug_set_knob; pf: the pipelined capture, 0 / 1)
 One engine; one captured graph per LISTED value, all on the same buffers; a value may be listed more than once.  CONTROL: list the values
 as  a b b a : the spread between the two graphs of the same value is the harness's own spread, and a difference between values means
 something only beyond it."""
@@ -9,7 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "deep-mixture-vae_amd")); sys.path.insert(0, ROOT)
 from dmvae_hip import StepEngine, _lib as L
 import bench
-cfg = bench.PRESETS[sys.argv[1]]; which = -1 if sys.argv[2] == "pf" else int(sys.argv[2]); values = [int(v) for v in sys.argv[3:]]      # "pf": capture_step(pipelined = value)
+cfg = dict(bench.PRESETS[sys.argv[1].split(":")[0]])
+for kv in sys.argv[1].split(":")[1:]: cfg[kv.split("=")[0]] = int(kv.split("=")[1])          # e.g. cfg2:batch=1024
+which = -1 if sys.argv[2] == "pf" else int(sys.argv[2]); values = [int(v) for v in sys.argv[3:]]      # "pf": capture_step(pipelined = value)
 torch.cuda.set_device(0)
 tup = lambda t: tuple(int(x) for x in t.split(","))
 B, I = cfg["batch"], cfg.get("input_dim", 784)
