@@ -386,6 +386,9 @@ def main():
             # fp32 master is current on its own slice only, and the engine refuses to update stale weights -- bring it up to date first
             # (a collective: every rank runs this leg)
             eng.sync_master(ex)
+            # ... and its Adam moments likewise (sync_master gathers weights only): the profiled steps run on a fresh optimizer
+            # (timing does not care; the engine refuses a replicated update on slice-only moments)
+            eng.reset_optimizer()
         prof_enable(True)
         import ctypes
         for _ in range(args.profile_steps):
@@ -440,6 +443,9 @@ def main():
     if rank_regions:      # per-rank finish of each timed region before the closing barrier: min / max over ranks, ms per step
         out["rank_ms_per_step_min_max"] = [[round(1e3 * a / args.steps, 4), round(1e3 * b / args.steps, 4)] for a, b in rank_regions]
     if exch is not None:
+        # the first sharded step of a multi-rank job compares the replicas (checksums of the gathered weights and of the replicated
+        # tail, all-reduce MIN == MAX: parallel.ShardedExchange.self_check); a failed check raises on every rank before this line
+        exch["self_check"] = getattr(eng, "_exchange_check", None) or ("not run (%s)" % ("all-reduce form: every rank applies the same sum" if not getattr(sync, "sharded", False) else "one rank"))
         out["exchange"] = exch
     out["timing"] = "median of %d regions of %d steps, each bracketed by barrier + synchronize" % (len(regions), args.steps)
     if rows:

@@ -525,7 +525,8 @@ extern "C" int dmvae_plan_load_batch_step(dmvae_plan* p, void* stream, const flo
 
 // Arms the assembly of the NEXT batch inside the next forward + backward pass (see dmvae_plan::pf); with use_state_cursor the rows are those
 // of the device cursor AFTER that pass's step_finalize has advanced it.  Needs a current batch assembled by dmvae_plan_load_batch_step (or
-// made current by dmvae_plan_swap_batch) on an eligible plan; `data` / `perm` must stay alive and unchanged until the step AFTER next has run.
+// made current by dmvae_plan_swap_batch) on an eligible plan; `data` / `perm` must stay alive and unchanged until the step that CONSUMES the
+// prefetched batch has run (the step after the one that assembles it: that step's reconstruction epilogue still reads the targets through them).
 extern "C" int dmvae_plan_prefetch_batch(dmvae_plan* p, const float* data, int64_t n_rows, const int32_t* perm, int64_t first, int n_valid,
                                          int use_state_cursor) {
     DMVAE_REQUIRE(p && p->bound && data, "dmvae_plan_prefetch_batch: plan not bound / null data");
@@ -991,7 +992,9 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
             DMVAE_REQUIRE(p->tsrc.n_valid == n_valid, "dmvae_plan_forward_backward: n_valid=%d, but dmvae_plan_load_batch_step assembled %d rows", n_valid, p->tsrc.n_valid);
             DMVAE_REQUIRE(!p->tsrc_used, "dmvae_plan_forward_backward: the batch assembled by dmvae_plan_load_batch_step has been consumed by an earlier pass "
                                          "(it has no f32 copy and the batch cursor has advanced): load the batch again, or use dmvae_plan_load_batch");
-            p->tsrc_used = true;
+            // (only a batch addressed by the DEVICE cursor goes stale: step_finalize advances the cursor.  With an explicit `first` the bf16
+            //  batch and the targets are both addressed by it, and a second pass over the same batch -- gradient checks, repeat passes -- is valid)
+            if (p->tsrc.st) p->tsrc_used = true;
         }
         if (dt == DMVAE_BF16 && p->o_cs_dl >= 0 && gemm_bf16_256_ok(DMVAE_GEMM_FWD, DMVAE_EPI_BIAS_RECON, p->Bp, p->Ip, Kd, false)) {
             GemmArgs a;      // the macro-tile kernel also leaves dLoss/dlogits' column sums = the output bias gradient

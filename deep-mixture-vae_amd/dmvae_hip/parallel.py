@@ -201,6 +201,36 @@ class ShardedExchange(GradExchange):
             return None
         return dist.all_gather_into_tensor(whole, mine, group=self.group, async_op=async_op)
 
+    # First-step cross-rank self-check.  After a sharded step every bit a step READS must be the same on
+    # every rank: the gathered weights (bf16 shadow on bf16 plans, fp32 else) over [0, sharded_hi) and the all-reduced, replicated
+    # tail.  An aliasing fault of the in-place reduce-scatter / all-gather (a slice landing at another rank's offset, a slice not
+    # gathered) leaves replicas that disagree and still train -- a plausible number.  So: a checksum of the BITS (the elements viewed
+    # as int16 / int32: NaN-proof, and -0.0 != +0.0) -- sum and sum of squares in int64 (modular: exact and independent of the order
+    # of the additions), per range -- then all-reduce MIN and MAX of the checksums; unequal on any rank => raise on EVERY rank (the
+    # collectives' results are the same everywhere), naming the fallback.
+    @staticmethod
+    def checksum(t):
+        """(sum, sum of squares) mod 2^64 of a tensor's elements viewed as signed integers of its own width"""
+        bits = t.contiguous().view({1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[t.element_size()]).to(torch.int64)
+        return torch.stack([bits.sum(), (bits * bits).sum()])
+
+    def self_check(self, gathered, sharded_hi, tail):
+        """COLLECTIVE (two small all-reduces).  gathered[0:sharded_hi]: what the all-gathers of one sharded step wrote; tail: the
+        replicated small-tensor range after its update.  Returns "ok" or raises RuntimeError on every rank."""
+        if not self.enabled or self.world == 1:
+            return "one rank: nothing to compare"
+        cs = torch.cat([self.checksum(gathered[:sharded_hi]), self.checksum(tail)])
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if not torch.equal(lo, hi):
+            bad = [n for n, a, b in zip(("weights: sum", "weights: sum of squares", "tail: sum", "tail: sum of squares"), lo.tolist(), hi.tolist()) if a != b]
+            raise RuntimeError(
+                "sharded gradient exchange: after the first step the replicas DISAGREE (%s differ between ranks; this rank: %s, min %s, max %s). "
+                "The in-place reduce-scatter / all-gather did not leave identical weights on every rank; rerun with DMVAE_DP_MODE=allreduce "
+                "(one all-reduce + replicated Adam)." % (", ".join(bad), cs.tolist(), lo.tolist(), hi.tolist()))
+        return "ok"
+
 
 def make_exchange(param_bytes=0, group=None):
     """the exchange for this process group: None-like (enabled False) in a world of one"""

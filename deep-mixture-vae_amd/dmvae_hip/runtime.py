@@ -263,6 +263,7 @@ class StepEngine:
         self.param.zero_()
         self.m.zero_()
         self.v.zero_()
+        self._moments_sharded = False
         self.grad.zero_()
         self.set_parameters(p)
         st = self.read_state()
@@ -292,6 +293,7 @@ class StepEngine:
         training stage): zero m and v, t back to 0, optionally a new learning rate."""
         self.m.zero_()
         self.v.zero_()
+        self._moments_sharded = False
         kw = dict(adam_t=0, lr_t=0.0)
         if lr is not None:
             kw["lr"] = float(lr)
@@ -338,6 +340,7 @@ class StepEngine:
         if gumbel is not None:
             assert gumbel.dtype == torch.float32 and gumbel.is_contiguous() and gumbel.shape == (n_valid, self.n_classes)
         inv_B = 1.0 / n_valid if inv_B is None else float(inv_B)
+        self._pf_primed = False            # (moves the device cursor: the pipelined callable must re-assemble its batch)
         check(lib.dmvae_plan_forward_backward(self._plan, self._stream(), n_valid, ptr(eps), self.latent_dim,
                                               ptr(gumbel), self.n_classes, inv_B), "dmvae_plan_forward_backward")
 
@@ -434,6 +437,12 @@ class StepEngine:
                 grad_sync.all_gather(gather, 0, tlo)
                 self._shard_ranges = [(0, tlo)]
             self._master_stale = self.param_bf16 is not None and grad_sync.world > 1
+            self._moments_sharded = grad_sync.world > 1      # m, v are current on the owned slice only until reset_optimizer
+            if grad_sync.world > 1 and getattr(self, "_exchange_check", None) is None:
+                # the FIRST sharded step of this engine on a real multi-rank group: every bit a step reads must be identical on
+                # all ranks (parallel.ShardedExchange.self_check: raises on every rank, naming DMVAE_DP_MODE=allreduce)
+                torch.cuda.synchronize(self.device)
+                self._exchange_check = grad_sync.self_check(gather, tlo, self.param[tlo:thi])
             return
         if getattr(grad_sync, "overlap", False):
             groups, buckets = self._stage_groups(grad_sync, buckets)
@@ -492,14 +501,25 @@ class StepEngine:
             torch.cuda.synchronize(self.device)
         self._master_stale = False
 
+    def _require_whole_moments(self, what):
+        """sync_master all-gathers the fp32 WEIGHTS; the Adam moments m, v stay current on each rank's own slice only.  A
+        replicated update over the whole arena with such moments would let the replicas drift apart silently: refuse until
+        reset_optimizer (a fresh optimizer: what every product path does between stages)."""
+        if getattr(self, "_moments_sharded", False):
+            raise RuntimeError("%s: the Adam moments m, v are current on this rank's slice only after sharded data-parallel steps "
+                               "(sync_master gathers the weights, not the moments); call reset_optimizer() first" % what)
+
     def update(self, grad_scale=1.0):
         self._require_current_master("update (replicated Adam over the whole arena)")
+        self._require_whole_moments("update (replicated Adam over the whole arena)")
         check(lib.dmvae_plan_update(self._plan, self._stream(), float(grad_scale)), "dmvae_plan_update")
 
     def forward_backward_update(self, n_valid=None, eps=None, gumbel=None, inv_B=None):
         """forward + loss + backward + Adam with the update fused into the dW launch
         (dmvae_plan_train_step): single-process training, the gradient arena is not written."""
         self._require_current_master("forward_backward_update (fused Adam over the whole arena)")
+        self._require_whole_moments("forward_backward_update (fused Adam over the whole arena)")
+        self._pf_primed = False            # a step outside the pipelined callable's replays consumes the batch and moves the cursor
         n_valid = self.max_batch if n_valid is None else int(n_valid)
         if eps is not None:
             assert eps.dtype == torch.float32 and eps.is_contiguous() and eps.shape == (n_valid, self.latent_dim)
@@ -614,12 +634,13 @@ class StepEngine:
         an eager step, encode ...).  Bit-identical to the plain graph (tests/test_gpu_step.py).  Default: batches of at most
         PIPELINE_MAX_BATCH rows on plans that support it, no gradient exchange; DMVAE_PREFETCH=1 / 0 forces it on / off.  MEASURED
         (round 4, tools/knob_step.py <cfg>[:batch=N] pf 0 1 1 0, one engine, same buffers): 100 rows 0.1535 -> 0.1494 ms (-2.7 %; -3.4 % on
-        another box); 256 / 512 / 1024 / 2048 rows -2.8 / -2.5 / -2.6 / -1.7 %; 4096 rows 0.2704 vs 0.2700 (nothing: the launch it saves, 5.9 us, comes back as +1.8 us in the dZ launch and a few
+        another box); 256 / 512 / 1024 / 2048 rows -2.8 / -2.5 / -2.6 / -1.7 %; 4096 rows 0.2704 vs 0.2700 (nothing: measured with the 64-row dZ tiles, where the launch it saves, 5.9 us, comes back as +1.8 us in the dZ launch and a few
         tenths in most other kernels -- the batch is no longer fresh in the caches when the first layer reads it); 8192 rows, where the
-        dZ launch has no idle CUs and the gather is a launch of its own mid-backward, 0.6085 vs 0.6109 (+0.4 %)."""
+        dZ launch has no idle CUs and the gather is a launch of its own mid-backward, 0.6085 vs 0.6109 (+0.4 %).  Since the thin dZ tiles
+        (knob 18 = 2) the 4096-row dZ launch has no room for riders either: the gather is a launch of its own there too."""
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
-        saved = (self.param.clone(), self.m.clone(), self.v.clone(), self.state_t.clone())
+        saved = (self.param.clone(), self.m.clone(), self.v.clone(), self.state_t.clone(), getattr(self, "_moments_sharded", False))
         with torch.cuda.stream(side):
             for _ in range(2):   # warm-up outside capture (lazy module loads, RCCL channels)
                 self.train_step(data, perm, None, None, None, 0, True, grad_sync, grad_scale, inv_B)
@@ -631,6 +652,7 @@ class StepEngine:
         # (without this the guard of refresh_shadow refused -- every multi-rank bench.py / train_op run failed here: found by the
         # two-rank rehearsal, now tests/test_gpu_step.py::test_captured_step_under_the_sharded_exchange_two_ranks)
         self._master_stale = False
+        self._moments_sharded = saved[4]             # (m, v are back to what they were before the warm-up steps)
         self.refresh_shadow()
         torch.cuda.synchronize(self.device)
         if pipelined is None:
@@ -660,7 +682,11 @@ class StepEngine:
             with torch.cuda.graph(g, stream=side):
                 self.train_step(data, perm, None, None, None, 0, True, None, grad_scale, inv_B)
             self._graph = (g,)
-            return g.replay
+
+            def replay():                  # (a plain replay between pipelined replays of one engine moves the cursor under them)
+                self._pf_primed = False
+                g.replay()
+            return replay
         # data parallel: issued eagerly.  MEASURED (one GPU, no-op exchange, `bench.py --dp-dry-run`): replaying the sequence as
         # several small graphs with the collectives between them was slower (three segments + three bucket updates: 0.362
         # vs 0.396 ms; one backward + Adam: 0.313 vs 0.326 ms) -- the host stays ahead of a 0.3 ms step and every graph

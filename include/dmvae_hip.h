@@ -33,6 +33,8 @@ extern "C" {
  *    dmvae_prof_row.kernel_ms were added after version 1; a client compiled against an older header passes shorter
  *    structs, so every binding checks dmvae_abi_version() == DMVAE_ABI_VERSION when it loads the library. */
 /* 3: dmvae_plan_set_stage_groups added (no struct changed). */
+/* 4: dmvae_plan_prefetch_batch / dmvae_plan_swap_batch added (a second bf16 batch buffer in the plan's workspace:
+ *    dmvae_sizes.work_bytes grows; no struct layout changed). */
 #define DMVAE_ABI_VERSION 4
 
 enum { DMVAE_F32 = 0, DMVAE_BF16 = 1 };
@@ -342,7 +344,8 @@ int dmvae_plan_load_batch_step(dmvae_plan* plan, void* stream, const float* data
  * those of the device cursor after that pass has advanced it.  dmvae_plan_swap_batch (host state only) then makes that batch the current
  * one, in place of the dmvae_plan_load_batch_step in front of the following step.  DMVAE_EUNSUPPORTED on plans that assemble their batches
  * with dmvae_plan_load_batch (f32, conv trunk, output layer on the macro tile).  `data` / `perm`: alive and unchanged until the step that
- * consumes the batch has run.  A captured step holds the buffer it was captured with: capture one graph per buffer and alternate them. */
+ * CONSUMES the prefetched batch has run -- i.e. the step AFTER the one that assembles it (its reconstruction epilogue reads the targets
+ * through them).  A captured step holds the buffer it was captured with: capture one graph per buffer and alternate them. */
 int dmvae_plan_prefetch_batch(dmvae_plan* plan, const float* data, int64_t n_rows, const int32_t* perm, int64_t first, int n_valid,
                               int use_state_cursor);
 int dmvae_plan_swap_batch(dmvae_plan* plan);

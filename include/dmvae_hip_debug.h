@@ -75,7 +75,9 @@ int dmvae_debug_set_tile(int bm, int bn);
  *                       heads' dX launch; 2 always the heads' dX launch; 0 a launch of their own (0.2796 vs 0.2753 ms at 4096 rows),
  *             knob 17 = where the gather of a prefetched batch (dmvae_plan_prefetch_batch) runs: 1 (default) on the idle CUs of the dZ GEMM, one block
  *                       each, in the last ids of its grid (12.98 us for that launch at 4096 rows, 11.2 without riders); 2 the same in the first ids
- *                       (14.1 us); 3 two blocks per idle CU, last ids (15.5 us); 0 a launch of its own in front of the trunk's backward pass,
+ *                       (14.1 us); 3 two blocks per idle CU, last ids (15.5 us); 0 a launch of its own in front of the trunk's backward pass.
+ *                       (Those figures: the 64-row dZ tiles of knob 18 = 0.  With the default thin dZ tiles a 4096-row launch is 256 workgroups and has
+ *                       no room for riders, so there the gather is a launch of its own whatever this knob says; riders run at <= 2048 rows.)
  *             knob 18 = thin tiles for the dZ GEMM (a 64-wide output with K >= 1024): 2 (default) the thinnest of 16 / 32 rows that still fits one
  *                       round of 256 CUs, 1 down to 32 rows only, 0 the general 64 x 64 tiles (that launch at 4096 rows: 8.92 / 10.19 / 11.49 us) */
 int dmvae_debug_set_knob(int which, int value);

@@ -323,14 +323,21 @@ def test_graph_replay_matches_eager_and_epoch_accounting():
     assert 100 < out[0][0] < 600          # epoch-mean loss in nats, 784*ln2 = 543 at init
 
 
-@pytest.mark.parametrize("B,knobs", [(256, ()), (4096, ()), (4096, ((17, 0),)), (256, ((1, 0),)), (16384, ())])
+_KNOB_DEFAULTS = {1: 1, 17: 1, 18: 2}
+
+
+@pytest.mark.parametrize("B,knobs", [(256, ()), (4096, ()), (4096, ((17, 0),)), (256, ((1, 0),)), (16384, ()),
+                                     (4096, ((18, 0),)), (4096, ((18, 1),)), (4096, ((18, 0), (17, 2))), (4096, ((18, 1), (17, 3))), (1024, ((18, 0), (17, 3)))])
 def test_pipelined_capture_equals_the_plain_graph(hip, B, knobs):
     """capture_step's pipelined form (two graphs, each assembling the NEXT batch under its own backward pass: dmvae_plan_prefetch_batch /
-    dmvae_plan_swap_batch, riders of the trunk's dX launch) against the plain captured step (the gather in front): same loss, parameters,
-    moments, cursor -- over an epoch wrap, a reset_epoch in between, an eager step in between, an encode in between (each of which
-    makes the callable assemble the cursor's batch itself).  Placements: by default the gather rides in the dZ GEMM and step_finalize one
-    launch earlier, in the output layer's dX launch (256 and 4096 rows; knob 1 = 0: the four-wave tiles); knob 17 = 0, and 16 384 rows
-    (the dZ launch has no idle CUs there): the gather is a launch of its own in front of the trunk's backward pass."""
+    dmvae_plan_swap_batch) against the plain captured step (the gather in front): same loss, parameters, moments, cursor -- over an epoch
+    wrap, a reset_epoch in between, an eager step in between, an encode in between (each of which makes the callable assemble the
+    cursor's batch itself).  Placements of the prefetched gather: at 256 rows it rides in the dZ GEMM (knob 1 = 0: on the four-wave tiles).
+    At 4096 rows with the default THIN dZ tiles (knob 18 = 2: 256 two-wave workgroups of 16 rows) that launch has no room for riders
+    (gemm_bf16_riders_room = 0), so the gather is a launch of its own whatever knob 17 says ((4096, ()) and (4096, ((17, 0),)) are the same
+    placement); the rider forms of gemm_bf16_dx_riders_kernel on the LATENT tiles are reached with knob 18 = 0 (64-row tiles) / 1 (32-row
+    tiles) and knob 17 = 1 (last ids), 2 (first ids), 3 (two blocks per idle CU) -- ADVICE r4.  16 384 rows: the dZ launch is full, the
+    gather is a launch of its own in front of the trunk's backward pass."""
     kw = dict(input_dim=784, latent_dim=64, n_classes=10)
     N = 5 * B
     X = torch.as_tensor(O.synthetic_images(min(N, 8192), 784, seed=18)).cuda()
@@ -366,7 +373,29 @@ def test_pipelined_capture_equals_the_plain_graph(hip, B, knobs):
         assert plain.param.abs().sum().item() > 0
     finally:
         for k, v in knobs:
-            hip.check(hip.lib.dmvae_debug_set_knob(k, 1))
+            hip.check(hip.lib.dmvae_debug_set_knob(k, _KNOB_DEFAULTS[k]))
+
+
+def test_a_batch_loaded_by_explicit_first_takes_repeat_passes(hip):
+    """the consumed-batch guard of dmvae_plan_load_batch_step concerns batches addressed by the DEVICE cursor (step_finalize
+    advances it under them).  With an explicit `first` a second forward_backward over the same batch is valid -- gradient checks, repeat
+    passes -- and gives the same gradients; with the cursor it is refused."""
+    kw, B = dict(input_dim=784, latent_dim=64, n_classes=10), 256
+    X = torch.as_tensor(O.synthetic_images(2 * B, 784, seed=5)).cuda()
+    perm = torch.randperm(2 * B, device="cuda").to(torch.int32)
+    eps = torch.randn((B, 64), device="cuda")
+    e = make(kw, "bf16", B, seed=2)
+    e._load_batch_for_step(X, perm, B, B, False)
+    e.forward_backward(B, eps)
+    g0, l0 = e.grad.clone(), e.read_state().last_loss
+    e.forward_backward(B, eps)                     # same batch, same noise: same bits
+    torch.cuda.synchronize()
+    assert torch.equal(e.grad, g0) and e.read_state().last_loss == l0
+    e.reset_epoch(2)
+    e._load_batch_for_step(X, perm, 0, B, True)
+    e.forward_backward(B, eps)
+    with pytest.raises(Exception, match="consumed by an earlier pass"):
+        e.forward_backward(B, eps)
 
 
 def test_pipelined_capture_is_the_default_for_small_batches_only(monkeypatch):

@@ -400,6 +400,59 @@ def test_sharded_exchange_world2_gloo():
     assert all(r[1] for r in res) and res[0][2] == res[1][2]
 
 
+def _self_check_worker(rank, world, port, perturb, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "deep-mixture-vae_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), DMVAE_DP_MODE="sharded")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dmvae_hip.parallel import make_exchange
+    ex = make_exchange(param_bytes=0)
+    n = ex.padded(5000)
+    g = torch.Generator().manual_seed(11)                 # the same "weights" on every rank ...
+    shadow = torch.randn(n, generator=g).to(torch.bfloat16)
+    tail = torch.randn(300, generator=g)
+    slo, shi = ex.owned(0, n)
+    ex.all_gather(shadow, 0, n)                           # a real in-place gather (every rank takes part) ...
+    if perturb == "slice" and rank == 1:                  # ... then ONE rank's copy differs inside a slice (what an aliasing fault of the
+        shadow[slo + 7] += 1.0                            # in-place collective, or a lost gather, would leave)
+    elif perturb == "tail" and rank == 0:
+        tail[5] = -tail[5] if float(tail[5]) != 0.0 else 1.0
+    elif perturb == "sign-of-zero":                       # bits, not values: -0.0 == +0.0 as floats
+        shadow[3] = 0.0
+        if rank == 1:
+            shadow[3] = -shadow[3]
+    try:
+        res = ex.self_check(shadow, n, tail)
+    except RuntimeError as e:
+        res = "raised: " + str(e)
+    out.put((rank, res))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("perturb", ["none", "slice", "tail", "sign-of-zero"])
+def test_sharded_exchange_self_check_world2_gloo(perturb):
+    """the first sharded step of a multi-rank job compares the replicas (checksums of the gathered bf16 shadow and of
+    the replicated tail; all-reduce MIN == MAX).  Unperturbed: "ok" on both ranks.  One rank's owned slice (or the tail, or only the
+    SIGN of a zero) different: RuntimeError on EVERY rank, naming the all-reduce fallback."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_self_check_worker, args=(r, 2, port, perturb, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    if perturb == "none":
+        assert [r[1] for r in res] == ["ok", "ok"]
+    else:
+        assert all(r[1].startswith("raised: ") and "DMVAE_DP_MODE=allreduce" in r[1] for r in res), res
+        assert all(("tail" if perturb == "tail" else "weights") in r[1] for r in res), res
+
+
 def test_png_writer_roundtrip(tmp_path):
     """includes/visualization.py writes its figures with its own PNG encoder: decode it by hand."""
     import struct, zlib
