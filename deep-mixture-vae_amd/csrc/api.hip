@@ -669,7 +669,8 @@ static int conv_trunk_backward(dmvae_plan* p, hipStream_t s) {
     return 0;
 }
 
-static int encode_impl(dmvae_plan* p, hipStream_t s) {
+// heads = false: stop behind the [z|c]-hidden layer (the step then runs the two head layers inside the latent launch: heads_latent.hip)
+static int encode_impl(dmvae_plan* p, hipStream_t s, bool heads = true) {
     const void* in = p->conv.empty() ? XB(p) : WS(p, p->o_x);
     int64_t ld = p->Ip;
     int kd = p->Ip;
@@ -685,6 +686,7 @@ static int encode_impl(dmvae_plan* p, hipStream_t s) {
     if (p->vade)      // VaDE: [mean | log_var] straight off the trunk (base_models.py:501-507), no logits
         return fwd_dense(p, s, in, ld, kd, p->mv, 2 * p->Dp, 0, DMVAE_EPI_BIAS_F32, WS(p, p->o_mv), 2 * p->Dp);
     TRY(fwd_dense(p, s, in, ld, kd, p->zc, 2 * p->Hp, 0, DMVAE_EPI_BIAS_RELU, WS(p, p->o_hzc), 2 * p->Hp));
+    if (!heads) return 0;
     // the two head layers [mean|log_var] = hz.Wmv and logits = hc.Wl are independent siblings:
     // bf16 issues them as one grouped grid (each alone is 64..128 workgroups)
     GemmArgs q[2];
@@ -906,7 +908,9 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     // launch of their own, here.  MEASURED earlier: as a side BRANCH of the graph (fork / join events) the step
     // took 0.344 ms against 0.326 ms -- a second branch costs more than the launch it hides.
     const int KD2 = 2 * c.n_classes * c.latent_dim;
-    const int n_lblk = p->vade ? p->n_lblk : latent_nblocks(p->Bp, c.latent_dim, c.n_classes);      // under the knob's CURRENT value: what latent_launch will use
+    // heads forward + latent stage as one launch where it applies (bf16, <= 4096 rows, Dp <= 128, K * D < 4096): blocks of 16 rows
+    const bool hl_fused = dt == DMVAE_BF16 && !p->vade && heads_latent_ok(p->Bp, c.latent_dim, c.n_classes, p->Dp, p->Kp, p->Hp, c.mode, 16) && p->mv.ldw >= 2 * p->Dp && p->lg.ldw >= p->Kp;
+    const int n_lblk = p->vade ? p->n_lblk : hl_fused ? p->Bp / 16 : latent_nblocks(p->Bp, c.latent_dim, c.n_classes);      // under the knob's CURRENT value: what latent_launch will use
     const int n_pblk = p->lws_bytes ? 1 : n_lblk;
     DMVAE_REQUIRE(n_lblk <= p->n_lblk_cap, "dmvae_plan_forward_backward: the latent kernel would run %d blocks, the plan's partial-sum buffers hold %d", n_lblk, p->n_lblk_cap);
     const dmvae_finalize_args fin = step_finalize_args(reinterpret_cast<float*>(WS(p, p->o_rpart)), p->n_rpart, reinterpret_cast<float*>(WS(p, p->o_lpart)),
@@ -952,7 +956,7 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
   if (all || stage == 0) {
     p->dw_queue.clear();
     p->csum_of.clear();
-    TRY(encode_impl(p, s));
+    TRY(encode_impl(p, s, !hl_fused));
 
     dmvae_latent_args la;
     memset(&la, 0, sizeof(la));
@@ -974,7 +978,16 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
     la.loss_partials = reinterpret_cast<float*>(WS(p, p->o_lpart));
     la.state = p->buf.state;
     la.mfma_ws = p->lws_bytes ? WS(p, p->o_lws) : nullptr; la.mfma_ws_bytes = p->lws_bytes;
-    TRY(latent_launch(s, &la));
+    if (hl_fused) {
+        dmvae_heads_args ha;
+        memset(&ha, 0, sizeof(ha));
+        ha.hz = WS(p, p->o_hzc); ha.lda = 2 * p->Hp; ha.Hp = p->Hp; ha.Dp = p->Dp; ha.Kp = p->Kp;
+        ha.W_mv = Wp(p, p->mv.w_off); ha.ld_mv = p->mv.ldw; ha.W_lg = Wp(p, p->lg.w_off); ha.ld_lg = p->lg.ldw;
+        ha.b_mv = p->buf.param + p->mv.b_off; ha.b_lg = p->buf.param + p->lg.b_off;
+        TRY(heads_latent_launch(s, &la, &ha));
+    } else {
+        TRY(latent_launch(s, &la));
+    }
 
     TRY(decode_hidden(p, s));
     {   // output layer + reconstruction loss + dLoss/dlogits in one epilogue
@@ -1232,6 +1245,14 @@ extern "C" int dmvae_latent_fwd(void* stream, const dmvae_latent_args* a) {
     DMVAE_REQUIRE(a->ld_Z >= a->D && (a->ld_dl >= a->K || a->mode == 2) && a->ld_g >= a->D, "dmvae_latent_fwd: leading dimension too small");
     return latent_launch((hipStream_t)stream, a);
 }
+extern "C" int dmvae_heads_latent_ok(int B_pad, int D, int K, int Dp, int Kp, int Hp, int mode) { return heads_latent_ok(B_pad, D, K, Dp, Kp, Hp, mode, 16) ? 1 : 0; }
+extern "C" int dmvae_heads_latent_fwd(void* stream, const dmvae_heads_args* h, const dmvae_latent_args* a) {
+    DMVAE_REQUIRE(h && a && a->mode >= 0 && a->mode <= 1, "dmvae_heads_latent_fwd: bad arguments / mode");
+    DMVAE_REQUIRE(h->hz && h->W_mv && h->W_lg && h->b_mv && h->b_lg && a->mean && a->log_var && a->logits && a->prior_means && a->prior_log_vars && a->Z_act && a->gmu &&
+                  a->glv && a->clv && a->dlogits_act && a->dprior_partials && a->loss_partials, "dmvae_heads_latent_fwd: null pointer");
+    DMVAE_REQUIRE(a->ld_Z >= a->D && a->ld_dl >= a->K && a->ld_g >= a->D, "dmvae_heads_latent_fwd: leading dimension too small");
+    return heads_latent_launch((hipStream_t)stream, a, h);
+}
 extern "C" int dmvae_recon_nblocks(int B_pad, int I_pad) { return recon_nblocks(B_pad, I_pad); }
 extern "C" int dmvae_recon_fwd_bwd(void* stream, int act_dtype, int recon_kind, int B, int B_pad, int I, int I_pad, const float* logits,
                                    int64_t ldl, const float* x, int64_t ldx, float inv_B, void* dl, int64_t ldd, float* partials) {
@@ -1256,6 +1277,7 @@ extern "C" int dmvae_adam_tf(void* stream, int64_t n, float* param, float* grad,
     a.n = n; a.p = param; a.g = grad; a.m = m; a.v = v; a.pb = reinterpret_cast<bf16_t*>(param_bf16);
     a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = epsilon; a.gscale = grad_scale; a.zero_grad = (flags & DMVAE_ADAM_ZERO_GRAD) != 0; a.ieee = (flags & DMVAE_ADAM_IEEE) != 0;
     a.t_host = t_host; a.st = reinterpret_cast<const dmvae_state*>(state);
+    if (flags & DMVAE_ADAM_SHADOW) return adam_shadow_launch((hipStream_t)stream, a, (flags >> 8) & 0xffff);
     return adam_launch((hipStream_t)stream, a);
 }
 extern "C" int dmvae_adam_finish(void* stream, void* state) {
@@ -1370,9 +1392,10 @@ extern "C" int dmvae_debug_set_knob(int which, int value) {
     if (which == 13) { heads_dx_stream_set(value); return 0; }
     if (which == 16) { g_fin_rides = value; return 0; }
     if (which == 17) { g_pf_rides = value; return 0; }
-    if (which == 18) { gemm_bf16_set_knob(which, value); return 0; }
+    if (which == 18 || which == 20) { gemm_bf16_set_knob(which, value); return 0; }
+    if (which == 19) { heads_latent_set(value); return 0; }
     if (which == 14) { latent_set_blocks_target(value); return 0; }      // (the block count in use is taken at enqueue time and checked against the plan's capacity)
-    DMVAE_REQUIRE(which >= 0 && which <= 9 && which != 3, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, (3: removed, the deep-ring policy), 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy, 7 = short-K workgroups, 8 = first-tile stagger of the merged dW grid, 9 = waves per workgroup of a grouped dX launch; 10 / 11 = K slices of the dW groups, 12 = heads dX as one or two launches, 13 = heads dX on the streaming kernel (1) or the grouped tiles (0), 14 = blocks the latent kernel's geometry aims at (512)");
+    DMVAE_REQUIRE(which >= 0 && which <= 9 && which != 3, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, (3: removed, the deep-ring policy), 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy, 7 = short-K workgroups, 8 = first-tile stagger of the merged dW grid, 9 = waves per workgroup of a grouped dX launch; 10 / 11 = K slices of the dW groups, 12 = heads dX as one or two launches, 13 = heads dX on the streaming kernel (1) or the grouped tiles (0), 14 = blocks the latent kernel's geometry aims at (512), 19 = fused heads + latent launch, 20 = XCD partition of the grouped dW launch");
     gemm_bf16_set_knob(which, value);
     return 0;
 }

@@ -91,6 +91,104 @@ __global__ __launch_bounds__(256) void adam_slabs_kernel(AdamArgs a, const float
     }
 }
 
+// ---------------------------------------------------------------- Adam in the SHADOW of a macro-tile GEMM
+// The same update as adam_tf_kernel (same adam_elem: same bits), shaped to run BESIDE the 256x256 macro-tile GEMM
+// (gemm_bf16_256.hip: one workgroup of 8 waves, 128 KiB of LDS, 2 x 232 VGPRs per SIMD lane on every CU) instead of behind it: what that
+// kernel leaves free on a CU is 48 VGPRs per SIMD lane, 32 KiB of LDS and wave slots.  So: one workgroup of four waves (one per SIMD)
+// per CU, <= 48 VGPRs, and the loads in flight live in LDS, not in registers -- every wave owns a private ring of SHADOW_NST stages x
+// {p, m, v, g} x 1 KiB filled by LDS-DMA (global_load_lds_dwordx4, 64 lanes x 16 B per instruction): 32 KiB in flight per CU.  No
+// barrier anywhere (a wave reads only what it requested itself; vmcnt retires in order).  lr_t is READ from the step state (state->lr_t as
+// step_finalize left it for t = state->adam_t: the t_host == ~0 convention of adam_tf_kernel); the host refuses the other forms.
+constexpr int SHADOW_NST = 2;
+__device__ __forceinline__ void shadow_glds(const float* base, unsigned voff, unsigned lds) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(base), "v"(voff), "s"(lds)
+        : "memory");
+}
+template <bool FAST>
+__global__ __launch_bounds__(256) void adam_shadow_kernel(AdamArgs a) {
+    __shared__ __attribute__((aligned(16))) float ring[4 * SHADOW_NST * 4 * 256];      // [wave][stage][array][256 floats]: 32 KiB
+    const float lr_t = a.st->lr_t;                          // (the double-precision pow of adam_lr_t alone takes more registers than this kernel may use)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int nchunk = (int)(a.n >> 8);                    // chunks of 256 elements = 64 lanes x one quad (the host hands the remainder to adam_tf_kernel; n < 2^39)
+    const int cstep = (int)gridDim.x * 4;
+    float* mine = ring + wave * (SHADOW_NST * 4 * 256);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) float*)mine));
+    const unsigned voff = (unsigned)lane * 16u;
+    auto issue = [&](int c, int slot) {                     // the four 1-KiB rows of chunk c -> stage `slot`
+        const int64_t e = (int64_t)c << 8;
+        const unsigned l = lds0 + (unsigned)slot * 4096u;
+        shadow_glds(a.p + e, voff, l);
+        shadow_glds(a.m + e, voff, l + 1024u);
+        shadow_glds(a.v + e, voff, l + 2048u);
+        shadow_glds(a.g + e, voff, l + 3072u);
+    };
+    const int c0 = (int)blockIdx.x * 4 + wave;
+    const int mycount = c0 < nchunk ? (nchunk - 1 - c0) / cstep + 1 : 0;      // chunks of this wave: c0 + k * cstep
+#pragma unroll
+    for (int s = 0; s < SHADOW_NST; ++s)
+        if (s < mycount) issue(c0 + s * cstep, s);
+    int slot = 0;
+    for (int k = 0; k < mycount; ++k) {
+        const int c = c0 + k * cstep;
+        // chunk c has landed when at most the loads of the SHADOW_NST - 1 younger chunks are outstanding; the stores of the previous
+        // trips are OLDER than those loads, so the same count also covers them (no assumption about how stores and loads interleave)
+        if (k + SHADOW_NST - 1 < mycount) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (SHADOW_NST - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float* st = mine + slot * 1024 + lane * 4;
+        float4 p = *reinterpret_cast<const float4*>(st);
+        float4 m = *reinterpret_cast<const float4*>(st + 256);
+        float4 v = *reinterpret_cast<const float4*>(st + 512);
+        const float4 g = *reinterpret_cast<const float4*>(st + 768);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is in registers: its LDS may be refilled
+        if (k + SHADOW_NST < mycount) issue(c + SHADOW_NST * cstep, slot);
+        float* pp = &p.x; float* mp = &m.x; float* vp = &v.x; const float* gp = &g.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) adam_elem<FAST>(pp[j], mp[j], vp[j], gp[j], a.gscale, a.b1, a.b2, a.eps, lr_t);
+        const int64_t i = ((int64_t)c << 6) + lane;
+        reinterpret_cast<float4*>(a.p)[i] = p;
+        reinterpret_cast<float4*>(a.m)[i] = m;
+        reinterpret_cast<float4*>(a.v)[i] = v;
+        if (a.pb) {
+            uint2 q;
+            q.x = pack2bf(p.x, p.y);
+            q.y = pack2bf(p.z, p.w);
+            reinterpret_cast<uint2*>(a.pb)[i] = q;
+        }
+        if (a.zero_grad) reinterpret_cast<float4*>(a.g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        slot = slot + 1 == SHADOW_NST ? 0 : slot + 1;
+    }
+}
+// n elements (multiple of 4); the part that is not a whole number of 256-element chunks goes through adam_tf_kernel
+int adam_shadow_launch(hipStream_t s, const AdamArgs& a0, int blocks) {
+    if (!a0.st || a0.t_host != ~0ull) { set_error("adam (shadow form): needs the step state with t already advanced (state != NULL, t_host = ~0): it reads state->lr_t"); return DMVAE_EINVAL; }
+    AdamArgs a = a0;
+    const int64_t body = (a.n >> 8) << 8;
+    if (body > 0) {
+        a.n = body;
+        if (blocks <= 0) blocks = 256;
+        blocks = (int)std::min<int64_t>(blocks, (body >> 8) / 4 + 1);
+        ProfScope ps(s, "adam_shadow", 12.0 * body, (28.0 + (a.pb ? 2.0 : 0.0) + (a.zero_grad ? 4.0 : 0.0)) * body);
+        if (a.pb && !a.ieee) DMVAE_LAUNCH(adam_shadow_kernel<true>, dim3(blocks), dim3(256), 0, s, a);      // (the arithmetic follows the mode: adam_elem)
+        else DMVAE_LAUNCH(adam_shadow_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
+        const int rc = check_launch("adam_shadow");
+        if (rc) return rc;
+    }
+    if (body < a0.n) {
+        AdamArgs r = a0;
+        r.n = a0.n - body; r.p += body; r.g += body; r.m += body; r.v += body;
+        if (r.pb) r.pb += body;
+        return adam_launch(s, r);
+    }
+    return 0;
+}
+
 int adam_launch(hipStream_t s, const AdamArgs& a) {
     const int64_t n4 = a.n >> 2;
     int blocks = (int)((n4 + 255) / 256);

@@ -563,6 +563,9 @@ struct GroupedArgs {
     dmvae_adam_ctx adam;      // DMVAE_EPI_ADAM launches only
     dmvae_finalize_args fin;  // DMVAE_EPI_RELU_MASK launches: fin.nblocks extra workgroups run step_finalize (0 = none)
     int lead, lead_work;      // ... in the first `lead` (fin.nblocks rounded up to 8) workgroup ids of the grid; ADAM launches: the lead_work workgroups of the extra segment, likewise
+    // xcut (round 5, weight-gradient groups): the XCD runs are cut over the WHOLE item sequence by streamed bytes instead of per tile-shape class by
+    // count: XCD x (workgroup ids with id % 8 == x) owns the contiguous items [xr0[x], xr0[x] + xcnt[x]); the ids beyond its count return at once
+    int xcut, xr0[8], xcnt[8];
 };
 // SHORTK: every problem has K <= 128 (one or two K tiles: the dX of the narrow heads).  Such a workgroup is all prologue
 // and epilogue -- what helps is MORE of them per CU: 64x64 tiles on a 2-slot ring = 32 KiB of LDS, four to five workgroups
@@ -604,9 +607,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_bf16_grouped_ke
         }
         bx -= g.lead;
     }
-    int i = 0;
-    while (i + 1 < g.nprob && bx >= g.start[i + 1]) ++i;
-    const int item = g.cls_start[i] + xcd_run_index(bx, g.cls_start[i], g.cls_end[i]);
+    int i = 0, item;
+    if (g.xcut) {
+        const int x = bx & 7, j = bx >> 3;
+        if (j >= g.xcnt[x]) return;
+        item = g.xr0[x] + j;
+    } else {
+        while (i + 1 < g.nprob && bx >= g.start[i + 1]) ++i;
+        item = g.cls_start[i] + xcd_run_index(bx, g.cls_start[i], g.cls_end[i]);
+    }
     i = 0;
     while (i + 1 < g.nprob && item >= g.start[i + 1]) ++i;
     int bid = item - g.start[i];
@@ -655,6 +664,9 @@ static int g_conv_short = 2;                // tuning knob (dmvae_debug_set_knob
 static int g_grouped_cls = 1;               // tuning knob (dmvae_debug_set_knob 4): XCD runs cut per tile-shape class (1) or per problem (0)
 static int g_dx_group_nw = 0;               // tuning knob (dmvae_debug_set_knob 9): waves per workgroup of a grouped dX launch, 0 = automatic, 4, 8
 static int g_grouped_mixed = 1;             // tuning knob (dmvae_debug_set_knob 2): 0 all 64x64, 1 planned per-problem tiles, 2 largest tile each shape divides
+static int g_grouped_xcut = 0;              // tuning knob (dmvae_debug_set_knob 20): weight-gradient groups: XCD runs cut by streamed bytes over the whole sequence (1) or per tile-shape class by count (0, default).
+                                            // MEASURED (round 5, tools/xcut_ab.sh, profiles/r05_dw_refetch.txt): 1 fetches less -- 651 -> 569 MB per launch at 8192 rows, as tools/dw_refetch_model.py
+                                            // predicts -- and is SLOWER: 0.2732 -> 0.2854 ms per step at 4096 rows, 0.6092 -> 0.6463 at 8192, 0.9103 -> 0.9310 at 16 384
 template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4>
 static const char* kernel_name(bool grouped) {   // the template instantiation, as rocprofv3 prints it
     static char nm[2][64];
@@ -816,6 +828,40 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
             }
             lo = hi;
         }
+    // Weight-gradient groups (round 5, knob 20 = 1; NOT the default -- it fetches less and runs slower, see g_grouped_xcut): cut the XCD runs over the WHOLE sequence by streamed bytes.  Per class by count, a problem that is alone in its
+    // class (the 832-wide first / last layer on 64x64 or 128x64 tiles) is spread over all eight XCDs and each of the eight L2s fetches most of its
+    // operand panels: tools/dw_refetch_model.py -- at 8192 rows the partition alone makes the launch fetch 481 MB of operands for 309 MB (measured
+    // with the update's reads: 647 MB for 384), of which the first layer 77.6 MB for 22.0.  Cut by bytes, every XCD gets one contiguous stretch of the
+    // longest-first sequence -- a small problem lands in one or two L2s (floor 411 MB; 734 for 981 at 16 384 rows) -- and the same bytes to stream; the
+    // tile COUNT per XCD then differs (128x128 tiles up front, 64x64 at the end), so the grid is 8 x the largest count and the surplus ids return at once.
+    g.xcut = 0;
+    int grid_items = total;
+    if (LAYOUT == DMVAE_GEMM_DW && g_grouped_xcut && total >= 64) {
+        double tot_b = 0.0;
+        std::vector<double> cost((size_t)total);
+        for (int i = 0; i < nprob; ++i)
+            for (int j = g.start[i]; j < g.start[i + 1]; ++j) { cost[j] = wg_bytes(g.p[i], g.kind[i]); tot_b += cost[j]; }
+        int cuts[9] = {0};
+        double acc = 0.0;
+        int x = 1;
+        for (int j = 0; j < total && x < 8; ++j) {
+            acc += cost[j];
+            while (x < 8 && acc >= tot_b * x / 8.0 - 1e-6) cuts[x++] = j + 1;
+        }
+        while (x < 8) cuts[x++] = total;
+        cuts[8] = total;
+        int mx = 0;
+        for (int k = 0; k < 8; ++k) { g.xr0[k] = cuts[k]; g.xcnt[k] = cuts[k + 1] - cuts[k]; mx = std::max(mx, g.xcnt[k]); }
+        g.xcut = 1;
+        grid_items = 8 * mx;
+        for (int i = 0; i < nprob; ++i) {        // supertile height from the largest share of the problem's tiles that one XCD holds
+            int share = 1;
+            for (int k = 0; k < 8; ++k) share = std::max(share, std::min(cuts[k + 1], g.start[i + 1]) - std::max(cuts[k], g.start[i]));
+            const int kind = g.kind[i], bm = kind >= 2 ? 64 : 128, bn = kind == 0 ? 128 : 64;
+            const int t = (g.start[i + 1] - g.start[i]) / g.nsl[i];
+            g.p[i].group_m = gemm_auto_group_m(g.p[i].M / bm, g.p[i].N / bn, bm, bn, std::min<double>(t, share));
+        }
+    }
     int extra = 0;
     g.fin = dmvae_finalize_args{};
     g.lead = 0; g.lead_work = 0;
@@ -852,7 +898,7 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
             return check_launch("gemm_bf16_grouped");
         }
     }
-    DMVAE_LAUNCH((gemm_bf16_grouped_kernel<64, 64, LAYOUT, EPI, 4, 4>), dim3(total + extra), dim3(256), 0, s, g);
+    DMVAE_LAUNCH((gemm_bf16_grouped_kernel<64, 64, LAYOUT, EPI, 4, 4>), dim3(grid_items + extra), dim3(256), 0, s, g);
     return check_launch("gemm_bf16_grouped");
 }
 
@@ -960,6 +1006,7 @@ void gemm_bf16_set_knob(int which, int v) {
     if (which == 8) gemm_bf16_256_set_stagger(v);
     if (which == 9) g_dx_group_nw = v;
     if (which == 18) g_thin = v;
+    if (which == 20) g_grouped_xcut = v;
 }
 
 // A thin launch (few 64 x 64 tiles, long K: the dZ GEMM at 4096 rows is 64 tiles of 32 K tiles) is bound by the per-CU intake of its activations --

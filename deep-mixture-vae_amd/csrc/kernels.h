@@ -51,11 +51,17 @@ void latent_set_blocks_target(int v);
 // VaDE's latent stage (latent_vade.hip): mode 2
 int latent_vade_nblocks(int B_pad);
 int latent_vade_launch(hipStream_t s, const dmvae_latent_args* a);
+// the two head layers' forward pass + the latent stage as one launch (heads_latent.hip); rows_per_latent_block: what latent_nblocks implies (must be 16)
+bool heads_latent_ok(int B_pad, int D, int K, int Dp, int Kp, int Hp, int mode, int rows_per_latent_block);
+int heads_latent_launch(hipStream_t s, const dmvae_latent_args* a, const dmvae_heads_args* h);
+void heads_latent_set(int v);
 // MFMA form for large prior tables (latent_mfma.hip)
 bool latent_mfma_applies(int D, int K, int mode);
 int64_t latent_mfma_ws_bytes(int B_pad, int D, int K);
 int latent_mfma_launch(hipStream_t s, const dmvae_latent_args* a, float* ws, int64_t ws_bytes);
 int adam_launch(hipStream_t s, const AdamArgs& a);
+// the same update shaped to run beside a macro-tile GEMM (<= 48 VGPRs, 32 KiB LDS ring filled by LDS-DMA, `blocks` workgroups of four waves; 0 = 256)
+int adam_shadow_launch(hipStream_t s, const AdamArgs& a, int blocks);
 int adam_finish_launch(hipStream_t s, void* st);
 // TF-Adam on a gradient that arrives as nslab K-slice slabs (slab j at slabs + j * stride; same element offsets as the arenas);
 // [seg_lo, seg_hi): elements whose gradient is complete in a.g instead (prior tables)

@@ -16,10 +16,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DMVAE_HIP_LIB: another build of the SAME library (e.g. a measurement variant from tools/ablate.sh)
 LIB_PATH = os.environ.get("DMVAE_HIP_LIB") or os.path.join(_HERE, "libdmvae_hip.so")
 
-ABI_VERSION = 4          # DMVAE_ABI_VERSION of include/dmvae_hip.h
+ABI_VERSION = 5          # DMVAE_ABI_VERSION of include/dmvae_hip.h
 F32, BF16 = 0, 1
 EUNSUPPORTED = -2        # DMVAE_EUNSUPPORTED
-ADAM_ZERO_GRAD, ADAM_IEEE = 1, 2
+ADAM_ZERO_GRAD, ADAM_IEEE, ADAM_SHADOW = 1, 2, 4
 GEMM_FWD, GEMM_DX, GEMM_DW = 0, 1, 2
 (EPI_BIAS_RELU, EPI_BIAS_F32, EPI_BIAS_RECON, EPI_RELU_MASK, EPI_LATENT,
  EPI_STORE_F32, EPI_ATOMIC_F32, EPI_BIAS_SIGMOID, EPI_ADAM) = range(9)
@@ -30,7 +30,7 @@ MODEL_DMVAE, MODEL_VADE = 0, 1
 EXPORTS = [
     "dmvae_gemm", "dmvae_gemm_partials", "dmvae_gemm_grouped_dw", "dmvae_gemm_grouped", "dmvae_gemm_grouped_dw_adam", "dmvae_plan_train_step", "dmvae_latent_ws_bytes", "dmvae_latent_nblocks_vade",
     "dmvae_plan_forward_backward_stage", "dmvae_plan_grad_buckets", "dmvae_plan_set_stage_groups", "dmvae_plan_update_range",
-"dmvae_latent_nblocks", "dmvae_latent_fwd",
+"dmvae_latent_nblocks", "dmvae_latent_fwd", "dmvae_heads_latent_fwd", "dmvae_heads_latent_ok",
     "dmvae_recon_fwd_bwd", "dmvae_recon_nblocks", "dmvae_colsum", "dmvae_loss_finalize",
     "dmvae_adam_tf", "dmvae_adam_finish", "dmvae_gather_rows", "dmvae_philox_normal",
     "dmvae_philox_gumbel", "dmvae_cast_f32_to_bf16", "dmvae_cast_bf16_to_f32",
@@ -89,6 +89,13 @@ class LatentArgs(C.Structure):
         ("state", C.c_void_p),
         ("mfma_ws", C.c_void_p), ("mfma_ws_bytes", C.c_int64),
     ]
+
+
+class HeadsArgs(C.Structure):          # dmvae_heads_args
+    _fields_ = [("hz", C.c_void_p), ("lda", C.c_int64),
+                ("Hp", C.c_int32), ("Dp", C.c_int32), ("Kp", C.c_int32), ("reserved", C.c_int32),
+                ("W_mv", C.c_void_p), ("ld_mv", C.c_int64), ("W_lg", C.c_void_p), ("ld_lg", C.c_int64),
+                ("b_mv", C.c_void_p), ("b_lg", C.c_void_p)]
 
 
 class State(C.Structure):
@@ -157,6 +164,8 @@ def _load():
         "dmvae_latent_nblocks_vade": [i32],
         "dmvae_latent_ws_bytes": [i32, i32, i32, i32],
         "dmvae_latent_fwd": [vp, P(LatentArgs)],
+        "dmvae_heads_latent_fwd": [vp, P(HeadsArgs), P(LatentArgs)],
+        "dmvae_heads_latent_ok": [i32, i32, i32, i32, i32, i32, i32],
         "dmvae_recon_fwd_bwd": [vp, i32, i32, i32, i32, i32, i32, vp, i64, vp, i64, f32, vp, i64, vp],
         "dmvae_recon_nblocks": [i32, i32],
         "dmvae_colsum": [vp, i32, vp, i64, i32, i32, vp],

@@ -35,7 +35,9 @@ extern "C" {
 /* 3: dmvae_plan_set_stage_groups added (no struct changed). */
 /* 4: dmvae_plan_prefetch_batch / dmvae_plan_swap_batch added (a second bf16 batch buffer in the plan's workspace:
  *    dmvae_sizes.work_bytes grows; no struct layout changed). */
-#define DMVAE_ABI_VERSION 4
+/* 5: dmvae_heads_latent_fwd / dmvae_heads_latent_ok / dmvae_heads_args added; DMVAE_ADAM_SHADOW flag of dmvae_adam_tf
+ *    (no existing struct changed). */
+#define DMVAE_ABI_VERSION 5
 
 enum { DMVAE_F32 = 0, DMVAE_BF16 = 1 };
 
@@ -186,6 +188,26 @@ int dmvae_latent_nblocks_vade(int B_pad);
 int64_t dmvae_latent_ws_bytes(int B_pad, int D, int K, int mode);   /* 0 when the MFMA form does not apply */
 int dmvae_latent_fwd(void* stream, const dmvae_latent_args* a);
 
+/* ---- the two head layers' forward pass AND the latent stage as one launch (csrc/heads_latent.hip) -----------------
+ * [mean | log_var] = hz . W_mv + b_mv and logits = hc . W_lg + b_lg (the three linear tf.layers.dense of base_models.py:229-249:
+ * 231-239 mean / log_var off the z-head's hidden layer, 241-248 logits off the c-head's) followed, on the same rows in the same
+ * workgroup, by everything dmvae_latent_fwd computes (priors.py:86-201).  `a` as for dmvae_latent_fwd, except that a->mean,
+ * a->log_var (= a->mean + Dp, one [B_pad][2 Dp] buffer) and a->logits ([B_pad][Kp]) are OUTPUTS here: the heads' f32 results are
+ * written there as dmvae_gemm with DMVAE_EPI_BIAS_F32 would write them -- same bits -- and every other output is bit-identical to
+ * dmvae_gemm_grouped + dmvae_latent_fwd on the same inputs.  bf16 operands only; Dp = 64 | 128, Kp = 64, K * D < 4096 (the one-kernel
+ * latent form), Hp a multiple of 64, B_pad a multiple of 16 and at most 4096 (one round of 256 workgroups: every workgroup streams
+ * both weight matrices); anything else: DMVAE_EUNSUPPORTED (dmvae_heads_latent_ok() == 0) -- use the two calls. */
+typedef struct dmvae_heads_args {
+    const void* hz; int64_t lda;     /* bf16 [B_pad][lda]: columns [0, Hp) = relu hidden layer of the z-head, [Hp, 2 Hp) = of the c-head */
+    int32_t Hp, Dp, Kp, reserved;    /* padded widths: head hidden layer, latent_dim, n_classes                                       */
+    const void* W_mv; int64_t ld_mv; /* bf16 [Hp][ld_mv]: columns [0, Dp) mean's kernel, [Dp, 2 Dp) log_var's                         */
+    const void* W_lg; int64_t ld_lg; /* bf16 [Hp][ld_lg]: the logits kernel                                                           */
+    const float* b_mv;               /* f32 [2 Dp] */
+    const float* b_lg;               /* f32 [Kp]   */
+} dmvae_heads_args;
+int dmvae_heads_latent_ok(int B_pad, int D, int K, int Dp, int Kp, int Hp, int mode);
+int dmvae_heads_latent_fwd(void* stream, const dmvae_heads_args* heads, const dmvae_latent_args* a);
+
 /* ---- stand-alone reconstruction loss (fused form: DMVAE_EPI_BIAS_RECON) --
  * tf.nn.sigmoid_cross_entropy_with_logits + reduce_sum/mean, base_models.py:72-85 */
 int dmvae_recon_fwd_bwd(void* stream, int act_dtype, int recon_kind, int B, int B_pad, int I, int I_pad,
@@ -230,6 +252,9 @@ int dmvae_loss_finalize(void* stream, const float* recon_partials, int n_recon,
  * chunks of one update see the same t). */
 #define DMVAE_ADAM_ZERO_GRAD 1
 #define DMVAE_ADAM_IEEE 2
+/* the same update (same bits) on the low-footprint kernel that can share a CU with a macro-tile GEMM running on another stream
+ * (<= 48 VGPRs, a 32 KiB LDS ring filled by LDS-DMA, four waves per workgroup); bits 8..23 of flags: workgroups (0 = 256) */
+#define DMVAE_ADAM_SHADOW 4
 int dmvae_adam_tf(void* stream, int64_t n, float* param, float* grad, float* m, float* v,
                   void* param_bf16, float lr, float beta1, float beta2, float epsilon,
                   float grad_scale, int flags, uint64_t t_host, const void* state);

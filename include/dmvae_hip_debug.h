@@ -79,7 +79,11 @@ int dmvae_debug_set_tile(int bm, int bn);
  *                       (Those figures: the 64-row dZ tiles of knob 18 = 0.  With the default thin dZ tiles a 4096-row launch is 256 workgroups and has
  *                       no room for riders, so there the gather is a launch of its own whatever this knob says; riders run at <= 2048 rows.)
  *             knob 18 = thin tiles for the dZ GEMM (a 64-wide output with K >= 1024): 2 (default) the thinnest of 16 / 32 rows that still fits one
- *                       round of 256 CUs, 1 down to 32 rows only, 0 the general 64 x 64 tiles (that launch at 4096 rows: 8.92 / 10.19 / 11.49 us) */
+ *                       round of 256 CUs, 1 down to 32 rows only, 0 the general 64 x 64 tiles (that launch at 4096 rows: 8.92 / 10.19 / 11.49 us),
+ *             knob 19 = heads forward + latent stage as ONE launch (csrc/heads_latent.hip) where it applies -- bf16, at most 4096 rows, Dp <= 128, K * D < 4096 -- (1,
+ *                       default) or as the grouped heads GEMM + latent_fwd_kernel (0): that pair 26.3 us, the fused launch 25.3 us at 4096 rows; step -0.3 .. -0.8 %,
+ *             knob 20 = XCD partition of the grouped weight-gradient launch: runs per tile-shape class by count (0, default) or cut over the whole sequence by streamed
+ *                       bytes (1: fetches 13 % less at 8192 rows and is 2 .. 6 % slower on the step at every size: profiles/r05_dw_refetch.txt) */
 int dmvae_debug_set_knob(int which, int value);
 
 #ifdef __cplusplus

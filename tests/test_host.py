@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(_lib.lib, name), "libdmvae_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     m = re.search(r"#define DMVAE_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "dmvae_hip.h")).read())
-    assert _lib.lib.dmvae_abi_version() == int(m.group(1)) == _lib.ABI_VERSION == 4
+    assert _lib.lib.dmvae_abi_version() == int(m.group(1)) == _lib.ABI_VERSION == 5
 
 
 def test_ctypes_structs_match_header_layout():
