@@ -226,6 +226,9 @@ class DeepMixtureVAE(VAE):
             raise ValueError("per-rank batch %d != the size the model was built for (%d)" % (b, eng.max_batch))
         rows = data.device_rows(sess.device)
         perm, n_full, tail, weight = self._epoch_perm(data, sess)
+        import time
+        torch.cuda.synchronize(sess.device)
+        self._epoch_t0 = time.perf_counter()                   # (behind the row upload and the epoch's permutation: the steps themselves)
         ex = make_exchange(4 * eng.param.numel())
         sync = ex if ex.enabled else None
         eng.reset_epoch(n_full + (1 if tail else 0), kl_ratio=kl_ratio, epoch_weight=weight)
@@ -259,10 +262,19 @@ class DeepMixtureVAE(VAE):
             eps, g = host_feed(tail) if host_noise else (None, None)
             inv_B = 1.0 / tail
             eng.train_step(rows, perm, tail, eps, g, first=n_full * b, grad_sync=sync, grad_scale=ex.grad_scale, inv_B=inv_B)
+        import time
+        t_wall = getattr(self, "_epoch_t0", None)
         torch.cuda.synchronize(sess.device)
-        loss = float(eng.read_state().epoch_loss)
+        st = eng.read_state()
+        loss = float(st.epoch_loss)
+        terms = [loss, float(st.epoch_recon), float(st.epoch_klz), float(st.epoch_klc)]
         if world > 1:
-            loss = ex.mean_scalars([loss])[0]
+            terms = ex.mean_scalars(terms)
+            loss = terms[0]
+        # what the epoch was made of (the reference prints only the loss; train.py writes these to its metrics log)
+        n_rows = n_full * gb + tail
+        self.last_epoch = dict(loss=terms[0], recon=terms[1], kl_z=terms[2], kl_c=terms[3], kl_ratio=float(kl_ratio), rows=int(n_rows),
+                               steps=int(n_full + (1 if tail else 0)), seconds=(time.perf_counter() - t_wall) if t_wall is not None else None)
         return loss
 
     # ------------------------------------------------------------------ inference pieces
@@ -374,6 +386,9 @@ class DeepMixtureVAE(VAE):
             raise ValueError("batch_size %d does not match the model (%d per rank x %d ranks)" % (data.batch_size, eng.max_batch, world))
         rows = data.device_rows(sess.device)
         perm, n_full, tail, weight = self._epoch_perm(data, sess)
+        import time
+        torch.cuda.synchronize(sess.device)
+        self._epoch_t0 = time.perf_counter()                   # (behind the row upload and the epoch's permutation: the steps themselves)
         ex = make_exchange(4 * eng.param.numel())
         sync = ex if ex.enabled else None
         # recon-only objective = the full loss at kl_ratio 0: every KL gradient carries the factor r

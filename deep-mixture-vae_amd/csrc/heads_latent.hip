@@ -209,7 +209,8 @@ static int hl_dc(int D, int K) {
 
 bool heads_latent_ok(int B_pad, int D, int K, int Dp, int Kp, int Hp, int mode, int rows_per_latent_block) {
     if (!g_heads_latent || mode < 0 || mode > 1) return false;
-    if (B_pad % 16 || B_pad / 16 > 256 || rows_per_latent_block != 16) return false;      // one round of the chip; the partial sums are per 16-row block
+    // one round of the chip (knob 19 = 2 lifts that: a row-strip measurement at large batches); the partial sums are per 16-row block
+    if (B_pad % 16 || (B_pad / 16 > 256 && g_heads_latent < 2) || rows_per_latent_block != 16) return false;
     if ((Dp != 64 && Dp != 128) || Kp != 64 || K > 64 || D > Dp || Hp % BK || Hp < BK) return false;
     if (latent_mfma_applies(D, K, mode)) return false;
     const int DC = hl_dc(D, K);

@@ -14,6 +14,7 @@ New flags (defaults = reference behaviour): --batch_size, --dtype, --seed,
 --host_noise, --gumbel, --temperature, --enc_layers, --head_dim, --dec_layers.
 """
 import argparse
+import json
 import math
 import os
 import sys
@@ -202,6 +203,14 @@ def main(argv):
                     with open(ckpt_path + ".tmp", "wb") as f:
                         np.savez(f, **model.state_dict())
                     os.replace(ckpt_path + ".tmp", ckpt_path)
+            if rank == 0:      # one JSON line per epoch (the reference has no metrics log; its tqdm postfix is the only record)
+                ep = dict(getattr(model, "last_epoch", None) or {})
+                sec = ep.pop("seconds", None)
+                rec = dict(epoch=epoch, **ep, images_per_sec=(ep.get("rows", 0) / sec if sec else None), train_seconds=sec,
+                           acc_train=float(accTrain), acc_test=float(accTest), max_acc=float(max(maxAcc, accTest) if improved else maxAcc),
+                           world=world, batch_size=argv.batch_size, dtype=argv.dtype, model=model_str)
+                with open(argv.model + "_metrics.jsonl", "a") as fl:
+                    fl.write(json.dumps(rec) + "\n")
             if math.isnan(loss):
                 raise FloatingPointError("loss is NaN at epoch %d (the reference drops into pdb here, train.py:320-321)" % epoch)
             bar.set_postfix({"loss": "%.4f" % loss, "accTrain": "%.4f" % accTrain, "accTest": "%.4f" % accTest,

@@ -561,6 +561,38 @@ def test_adam_tf_matches_oracle_over_steps(hip, shadow, ieee):
     np.testing.assert_allclose(p1.cpu().numpy(), -0.002 * np.sign(g1.cpu().numpy()), rtol=1e-4)
 
 
+@pytest.mark.parametrize("shadow,ieee,blocks", [(True, False, 0), (True, True, 64), (False, False, 7)])
+def test_adam_shadow_form_equals_the_plain_kernel(hip, shadow, ieee, blocks):
+    """DMVAE_ADAM_SHADOW (csrc/elementwise.hip adam_shadow_kernel: <= 48 VGPRs, loads in flight in a wave-private LDS ring filled by LDS-DMA) gives the
+    bits of adam_tf_kernel -- both arithmetic modes, a size that is not a multiple of its 256-element chunks (the remainder runs on the plain
+    kernel), few and many workgroups, zero_grad -- over three steps driven by the device state; without the state it is refused."""
+    L = hip
+    rng = np.random.RandomState(11)
+    n = 256 * 1237 + 132
+    lr, b1, b2 = (float(np.float32(x)) for x in (0.002, 0.9, 0.999))
+    base = [dev(rng.randn(n)), dev(np.zeros(n)), dev(np.abs(rng.randn(n)) * 1e-3)]
+    a = [t.clone() for t in base]; b = [t.clone() for t in base]
+    pa = torch.zeros(n, dtype=torch.bfloat16, device="cuda") if shadow else None
+    pb = torch.zeros(n, dtype=torch.bfloat16, device="cuda") if shadow else None
+    fl = L.ADAM_ZERO_GRAD | (L.ADAM_IEEE if ieee else 0)
+    NOT = C.c_uint64(2 ** 64 - 1)
+    for t in range(1, 4):
+        st = L.State(); st.adam_t, st.lr = t, lr
+        st.lr_t = float(np.float32(lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)))          # as common.h adam_lr_t rounds it
+        state = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).cuda()
+        g = dev(rng.randn(n) * 10 ** rng.uniform(-3, 1))
+        ga, gb = g.clone(), g.clone()
+        L.check(L.lib.dmvae_adam_tf(stream(), n, L.ptr(a[0]), L.ptr(ga), L.ptr(a[1]), L.ptr(a[2]), L.ptr(pa) if shadow else None, lr, b1, b2, 1e-8, 0.5, fl, NOT, L.ptr(state)))
+        L.check(L.lib.dmvae_adam_tf(stream(), n, L.ptr(b[0]), L.ptr(gb), L.ptr(b[1]), L.ptr(b[2]), L.ptr(pb) if shadow else None, lr, b1, b2, 1e-8, 0.5,
+                                    fl | L.ADAM_SHADOW | (blocks << 8), NOT, L.ptr(state)))
+        torch.cuda.synchronize()
+        for x, y, what in zip(a, b, "pmv"):
+            assert torch.equal(x, y), (what, t, int((x != y).sum().item()))
+        assert not ga.any().item() and not gb.any().item()
+        if shadow: assert torch.equal(pa, pb) and torch.equal(pb, b[0].to(torch.bfloat16))
+    assert L.lib.dmvae_adam_tf(stream(), n, L.ptr(b[0]), L.ptr(gb), L.ptr(b[1]), L.ptr(b[2]), None, lr, b1, b2, 1e-8, 1.0, L.ADAM_SHADOW, 1, None) != 0      # needs the state
+
+
 def test_gather_rows_follows_dataset_order(hip):
     L = hip
     rng = np.random.RandomState(6)

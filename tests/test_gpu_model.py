@@ -283,6 +283,10 @@ def test_train_cli_one_epoch(tmp_path, monkeypatch):
     assert np.isfinite(loss) and 50 < loss < 560
     assert os.path.exists(tmp_path / "saved-models" / "mnist" / "dmvae" / "model" / "parameters.ckpt")
     assert "Max Accuracy" in open(tmp_path / "dmvae_logs.txt").read()
+    import json
+    recs = [json.loads(l) for l in open(tmp_path / "dmvae_metrics.jsonl")]          # one JSON line per epoch: loss terms, img/s, accuracies
+    assert [r["epoch"] for r in recs] == [0, 1] and recs[-1]["loss"] == pytest.approx(loss, rel=1e-6)
+    assert all(abs(r["recon"] + r["kl_ratio"] * (r["kl_z"] + r["kl_c"]) - r["loss"]) < 1e-2 and r["images_per_sec"] > 0 and r["rows"] == 1200 for r in recs)
     # a checkpoint this revision cannot read (another format at the same path, a truncated archive, other shapes)
     # must not abort start-up: the reason is printed and training starts from the initial parameters, as in the reference
     ck = tmp_path / "saved-models" / "mnist" / "dmvae" / "model" / "parameters.ckpt"
