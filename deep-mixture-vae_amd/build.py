@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "dmvae_hip", "libdmvae_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_bf16_256.hip", "gemm_f32.hip", "latent.hip", "latent_mfma.hip", "latent_vade.hip", "elementwise.hip", "conv.hip", "heads_dx.hip", "heads_latent.hip", "api.hip"]
+SOURCES = ["gemm_bf16.hip", "gemm_bf16_256.hip", "gemm_f32.hip", "latent.hip", "latent_mfma.hip", "latent_vade.hip", "elementwise.hip", "conv.hip", "heads_dx.hip", "heads_latent.hip", "strip_fwd2.hip", "api.hip"]
 # -amdgpu-mfma-vgpr-form: accumulators stay in VGPRs.  Left to its default, hipcc (ROCm 7.2) puts the
 # 4-wave GEMM tiles' accumulators in AGPRs and then shuffles them through v_accvgpr_read/write/mov on
 # every K step (256 such moves against 80 MFMAs in the 128x128 dW loop); no kernel here needs > 256 VGPRs.

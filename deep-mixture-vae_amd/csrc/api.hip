@@ -118,6 +118,8 @@ static int gemm_partials(int, int M, int N) { return (M / 64) * (N / 64); }
 
 using namespace dmvae;
 
+constexpr int KSPLIT_MAX_ROWS = 256, KSPLIT_MAX_SLICES = 8;      // K slices of thin dense launches (ksplit_for): batches of at most this many rows
+
 // tuning knob (dmvae_debug_set_knob 10): K slices of the dense weight-gradient group (0 = the plan's rule, 1 = none, 2 / 4 = forced where
 // the plan has the slabs); see dmvae_plan::dw_slices_max
 static int g_dw_slices = 0;
@@ -175,6 +177,8 @@ struct dmvae_plan {
     std::vector<int64_t> o_enc, o_dec, o_denc, o_ddec;
     int64_t o_rpart, o_lpart, o_dprior, o_cs, o_lws = 0;
     int64_t lws_bytes = 0;            // scratch of the MFMA form of the latent contractions (0: the one-kernel form)
+    // K slices of the thin dense launches of a SMALL batch (ksplit_for): slabs of f32 partial tiles + one ticket per tile (zero between launches)
+    int64_t o_ksws = -1, ksws_elems = 0, o_ktick = -1;
     int n_rpart, n_lblk, n_pblk;      // loss-partial blocks of the latent kernel; rows of its prior-table gradient partials (as of plan creation)
     int n_lblk_cap = 0;               // rows the partial-sum buffers hold
     int64_t cs_elems;
@@ -406,6 +410,19 @@ extern "C" int dmvae_plan_create(const dmvae_config* c, dmvae_plan** out) {
     p->n_pblk = p->lws_bytes ? 1 : p->n_lblk;          // the MFMA form delivers the prior-table gradient complete, in one row
     p->o_dprior = take((int64_t)(p->lws_bytes ? 1 : p->n_lblk_cap) * 2 * KD * 4);
     if (p->lws_bytes) p->o_lws = take(p->lws_bytes);
+    if (c->dtype == DMVAE_BF16 && p->Bp <= 2048) {
+        // dense launches (<= KSPLIT_MAX_ROWS rows; the largest user: a 512-wide output, 8 slices, 64 x 64 tiles) and the fused heads + latent launch
+        // (blocks x slices <= 256: up to 2048 rows)
+        int64_t need = p->Bp <= KSPLIT_MAX_ROWS ? (int64_t)(p->Bp / 64) * 8 * KSPLIT_MAX_SLICES * 4096 : 0;
+        if (p->Dp == 64 || p->Dp == 128)
+            for (int S = 2; S <= KSPLIT_MAX_SLICES; S *= 2)
+                if ((p->Bp / 16) * S <= 256) need = std::max(need, heads_latent_kslice_floats(p->Bp, p->Dp, S));
+        if (need > 0) {
+            p->ksws_elems = need;
+            p->o_ksws = take(p->ksws_elems * 4);
+            p->o_ktick = take(256 * 4);
+        }
+    }
     int maxN = std::max(std::max(2 * p->Hp, p->Ip), p->flat);
     for (auto& L : p->enc) maxN = std::max(maxN, L.out_pad);
     for (auto& L : p->dec) maxN = std::max(maxN, L.out_pad);
@@ -550,13 +567,39 @@ extern "C" int dmvae_plan_swap_batch(dmvae_plan* p) {
     return 0;
 }
 
+// K slices for the thin dense launches of a small batch.  At 100 rows (the reference's own default, train.py:215-216) every GEMM of the
+// step is 2 x N / 64 tiles -- a few CUs, each walking the whole K chain and streaming its own weight panel: the launch lasts as long as that chain
+// (K = 4096: 64 K tiles, 18 us).  Cut into S slices the chain is S times shorter on S times the CUs; the slices' partial tiles meet in a fixed-order
+// sum by the last one to arrive (GemmArgs::tick): deterministic, no float atomics, no extra launch.  Returns S (1 = none).
+static int g_ksplit = 1;              // tuning knob (dmvae_debug_set_knob 21): 1 = the rule below, 0 = never
+static int ksplit_for(const dmvae_plan* p, int N, int K, int epi) {
+    if (!g_ksplit || p->o_ksws < 0 || p->Bp > KSPLIT_MAX_ROWS || p->cfg.dtype != DMVAE_BF16 || K < 2048) return 1;
+    if (epi != DMVAE_EPI_BIAS_RELU && epi != DMVAE_EPI_RELU_MASK && epi != DMVAE_EPI_BIAS_F32 && epi != DMVAE_EPI_LATENT) return 1;
+    const int tiles = (epi == DMVAE_EPI_LATENT ? (p->Bp + 15) / 16 : p->Bp / 64) * (N / 64);      // (the dZ GEMM runs on 16-row tiles; a slab is sized for a 64 x 64 tile either way)
+    int S = std::min(KSPLIT_MAX_SLICES, K / (g_ksplit == 2 ? 256 : 512));      // (knob 21 = 2: slices of 256 instead of 512)
+    while (S > 1 && (K % (S * 64) || tiles * S > 256 || (int64_t)tiles * S * 4096 > p->ksws_elems)) --S;
+    return (tiles <= 64 && tiles <= 256) ? std::max(S, 1) : 1;
+}
+// a dense problem of the plan with its K slices, if the rule gives it any
+static int gemm_plan(dmvae_plan* p, hipStream_t s, int layout, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const dmvae_epilogue* e,
+                     GemmArgs* deferred) {
+    const int S = deferred ? 1 : ksplit_for(p, N, K, e->kind);
+    if (S == 1) return gemm_checked(s, p->cfg.dtype, layout, p->Bp, N, K, A, lda, B, ldb, e, 1, deferred);
+    GemmArgs a;
+    TRY(gemm_checked(s, p->cfg.dtype, layout, p->Bp, N, K, A, lda, B, ldb, e, 1, &a));
+    if (gemm_bf16_256_ok(layout, e->kind, p->Bp, N, K, false)) return gemm_bf16_dispatch(s, layout, a, 1);
+    a.k_split = K / S;
+    a.ws = reinterpret_cast<float*>(WS(p, p->o_ksws)); a.ws_elems = p->ksws_elems;
+    a.tick = reinterpret_cast<int*>(WS(p, p->o_ktick));
+    return gemm_bf16_dispatch(s, layout, a, S);
+}
+
 static int fwd_dense(dmvae_plan* p, hipStream_t s, const void* A, int64_t lda, int Kdim, const PLayer& L, int N, int64_t w_col,
                      int kind, void* out, int64_t ldo, GemmArgs* deferred = nullptr) {
     dmvae_epilogue e;
     memset(&e, 0, sizeof(e));
     e.kind = kind; e.out = out; e.ldo = ldo; e.bias = p->buf.param + L.b_off + w_col;
-    return gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_FWD, p->Bp, N, Kdim, A, lda,
-                        reinterpret_cast<const char*>(Wp(p, L.w_off + w_col)), L.ldw, &e, 1, deferred);
+    return gemm_plan(p, s, DMVAE_GEMM_FWD, N, Kdim, A, lda, reinterpret_cast<const char*>(Wp(p, L.w_off + w_col)), L.ldw, &e, deferred);
 }
 
 // pointer to padded pixel 0 of a zero-bordered activation (skips the P + 1 guard rows)
@@ -868,7 +911,7 @@ static int dx_dense(dmvae_plan* p, hipStream_t s, const void* dY, int64_t ldy, i
         p->csum_of[cs_key] = std::make_pair((const float*)part, cs_ld);
         return gemm_bf16_dispatch(s, DMVAE_GEMM_DX, a, 1);
     }
-    return gemm_checked(s, p->cfg.dtype, DMVAE_GEMM_DX, p->Bp, N, Kdim, dY, ldy, Wp(p, w_off), ldw, &e, 1, deferred);
+    return gemm_plan(p, s, DMVAE_GEMM_DX, N, Kdim, dY, ldy, Wp(p, w_off), ldw, &e, deferred);
 }
 
 // stage < 0: the whole forward + backward.  stage 0 / 1 / 2: the three segments after which one
@@ -984,6 +1027,15 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
         ha.hz = WS(p, p->o_hzc); ha.lda = 2 * p->Hp; ha.Hp = p->Hp; ha.Dp = p->Dp; ha.Kp = p->Kp;
         ha.W_mv = Wp(p, p->mv.w_off); ha.ld_mv = p->mv.ldw; ha.W_lg = Wp(p, p->lg.w_off); ha.ld_lg = p->lg.ldw;
         ha.b_mv = p->buf.param + p->mv.b_off; ha.b_lg = p->buf.param + p->lg.b_off;
+        // few blocks (a small batch): K slices, while blocks x slices stay within one round of the chip (the scheme of ksplit_for)
+        if (g_ksplit && p->o_ksws >= 0) {
+            int S = KSPLIT_MAX_SLICES;
+            while (S > 1 && (p->Hp % (S * 64) || (p->Bp / 16) * S > 256 || heads_latent_kslice_floats(p->Bp, p->Dp, S) > p->ksws_elems)) S /= 2;
+            if (S > 1) {
+                ha.kslices = S; ha.kslice_ws = reinterpret_cast<float*>(WS(p, p->o_ksws)); ha.kslice_ws_floats = p->ksws_elems;
+                ha.kslice_tick = reinterpret_cast<int32_t*>(WS(p, p->o_ktick));
+            }
+        }
         TRY(heads_latent_launch(s, &la, &ha));
     } else {
         TRY(latent_launch(s, &la));
@@ -1041,10 +1093,16 @@ static int forward_backward_impl(dmvae_plan* p, void* stream, int n_valid, const
             memset(&e, 0, sizeof(e));
             e.kind = DMVAE_EPI_LATENT; e.out = WS(p, p->o_dmv); e.ldo = 2 * p->Dp; e.d_off = p->Dp;
             e.aux0 = la.gmu; e.ld0 = p->Dp; e.aux1 = la.glv; e.ld1 = p->Dp; e.aux2 = la.clv; e.ld2 = p->Dp;
-            if (rid_dz.nfin || rid_dz.ngat) {      // the step_finalize blocks, or the next batch's gather, ride here (see above)
+            const int S = ksplit_for(p, p->Dp, L.out_pad, DMVAE_EPI_LATENT);      // a small batch: K slices (GemmArgs::tick)
+            if (rid_dz.nfin || rid_dz.ngat || S > 1) {      // the step_finalize blocks, or the next batch's gather, ride here (see above)
                 GemmArgs ga;
                 TRY(gemm_checked(s, dt, DMVAE_GEMM_DX, p->Bp, p->Dp, L.out_pad, WS(p, p->o_ddec[0]), L.out_pad, Wp(p, L.w_off), L.ldw, &e, 1, &ga));
-                TRY(gemm_bf16_dispatch(s, DMVAE_GEMM_DX, ga, 1, &rid_dz));
+                if (S > 1) {
+                    ga.k_split = L.out_pad / S;
+                    ga.ws = reinterpret_cast<float*>(WS(p, p->o_ksws)); ga.ws_elems = p->ksws_elems;
+                    ga.tick = reinterpret_cast<int*>(WS(p, p->o_ktick));
+                }
+                TRY(gemm_bf16_dispatch(s, DMVAE_GEMM_DX, ga, S, (rid_dz.nfin || rid_dz.ngat) ? &rid_dz : nullptr));
                 if (rid_dz.ngat) { p->pf.armed = false; p->pf.done = true; }
             } else
             TRY(gemm_checked(s, dt, DMVAE_GEMM_DX, p->Bp, p->Dp, L.out_pad, WS(p, p->o_ddec[0]), L.out_pad, Wp(p, L.w_off), L.ldw, &e, 1));
@@ -1245,6 +1303,7 @@ extern "C" int dmvae_latent_fwd(void* stream, const dmvae_latent_args* a) {
     DMVAE_REQUIRE(a->ld_Z >= a->D && (a->ld_dl >= a->K || a->mode == 2) && a->ld_g >= a->D, "dmvae_latent_fwd: leading dimension too small");
     return latent_launch((hipStream_t)stream, a);
 }
+extern "C" int64_t dmvae_heads_latent_kslice_floats(int B_pad, int Dp, int kslices) { return heads_latent_kslice_floats(B_pad, Dp, kslices); }
 extern "C" int dmvae_heads_latent_ok(int B_pad, int D, int K, int Dp, int Kp, int Hp, int mode) { return heads_latent_ok(B_pad, D, K, Dp, Kp, Hp, mode, 16) ? 1 : 0; }
 extern "C" int dmvae_heads_latent_fwd(void* stream, const dmvae_heads_args* h, const dmvae_latent_args* a) {
     DMVAE_REQUIRE(h && a && a->mode >= 0 && a->mode <= 1, "dmvae_heads_latent_fwd: bad arguments / mode");
@@ -1310,6 +1369,10 @@ extern "C" int dmvae_cast_bf16_to_f32(void* stream, const void* in, float* out, 
 }
 
 extern "C" int dmvae_debug_spin(void* stream, int microseconds) { return spin_launch((hipStream_t)stream, microseconds); }
+extern "C" int dmvae_debug_strip_fwd2(void* stream, int B_pad, int K0, const void* X, int64_t ldx, const void* W0, int64_t ld0, const float* b0,
+                                      const void* W1, int64_t ld1, const float* b1, void* Y1, int64_t ldy1, void* Y2, int64_t ldy2) {
+    return strip_fwd2_launch((hipStream_t)stream, B_pad, K0, X, ldx, W0, ld0, b0, W1, ld1, b1, Y1, ldy1, Y2, ldy2);
+}
 extern "C" int dmvae_debug_stamps(void** device_ptr) {
     if (!device_ptr) return DMVAE_EINVAL;
     *device_ptr = gemm_bf16_stamps();
@@ -1394,8 +1457,9 @@ extern "C" int dmvae_debug_set_knob(int which, int value) {
     if (which == 17) { g_pf_rides = value; return 0; }
     if (which == 18 || which == 20) { gemm_bf16_set_knob(which, value); return 0; }
     if (which == 19) { heads_latent_set(value); return 0; }
+    if (which == 21) { g_ksplit = value; return 0; }
     if (which == 14) { latent_set_blocks_target(value); return 0; }      // (the block count in use is taken at enqueue time and checked against the plan's capacity)
-    DMVAE_REQUIRE(which >= 0 && which <= 9 && which != 3, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, (3: removed, the deep-ring policy), 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy, 7 = short-K workgroups, 8 = first-tile stagger of the merged dW grid, 9 = waves per workgroup of a grouped dX launch; 10 / 11 = K slices of the dW groups, 12 = heads dX as one or two launches, 13 = heads dX on the streaming kernel (1) or the grouped tiles (0), 14 = blocks the latent kernel's geometry aims at (512), 19 = fused heads + latent launch, 20 = XCD partition of the grouped dW launch");
+    DMVAE_REQUIRE(which >= 0 && which <= 9 && which != 3, "dmvae_debug_set_knob: knob 0 = supertile rows, 1 = 8-wave workgroups, 2 = per-problem tiles in grouped grids, (3: removed, the deep-ring policy), 4 = XCD runs per tile class in grouped grids, 5 = short-K conv tiles, 6 = 256x256 tile policy, 7 = short-K workgroups, 8 = first-tile stagger of the merged dW grid, 9 = waves per workgroup of a grouped dX launch; 10 / 11 = K slices of the dW groups, 12 = heads dX as one or two launches, 13 = heads dX on the streaming kernel (1) or the grouped tiles (0), 14 = blocks the latent kernel's geometry aims at (512), 19 = fused heads + latent launch, 20 = XCD partition of the grouped dW launch, 21 = K slices of a small batch's thin launches");
     gemm_bf16_set_knob(which, value);
     return 0;
 }

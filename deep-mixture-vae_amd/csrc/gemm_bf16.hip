@@ -398,6 +398,62 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
             *reinterpret_cast<f32x4*>(ct + ml * BN + ((c ^ (ml & 7)) << 2)) = acc[i][j];
         }
     __syncthreads();
+    // K slices with a fused epilogue (GemmArgs::tick): this workgroup's tile is a PARTIAL product.  It goes to its slab; the last slice to arrive
+    // adds all slabs in ascending order (its own included, from memory: the order does not depend on who is last) and carries on into the epilogue.
+    constexpr int KSPLIT_MAX_S = 8;
+    constexpr bool KSLICE_OK = !CONV && LAYOUT != DMVAE_GEMM_DW && BM * BN <= 4096 && NW <= 4 && BM * BN * 4 + 16 <= NSTAGE * STAGE * 2 &&      // (the 64-row and thinner tiles: what a small batch runs on)
+                               (EPI == DMVAE_EPI_BIAS_RELU || EPI == DMVAE_EPI_RELU_MASK || EPI == DMVAE_EPI_BIAS_F32 || EPI == DMVAE_EPI_LATENT);
+    if constexpr (KSLICE_OK) {
+        if (a.tick != nullptr && gridDim.y > 1) {
+            const int S = (int)gridDim.y, tile_lin = tm * tiles_n + tn;
+            constexpr int Q = BM * BN;                          // floats per tile
+            static_assert(KSPLIT_MAX_S == 8, "the combine issues eight loads per quad");
+            // The slabs cross XCDs (the slices of a tile land on different L2s).  A release / acquire FENCE at agent scope does it -- and was measured: it
+            // writes back and invalidates the XCD's whole L2 per workgroup, every other workgroup there loses its weight panels (the step +10.6 % at 100
+            // rows instead of faster).  So the slab traffic itself is agent-scope: write-through stores, L2-bypassing loads (sc1), one dword each; the
+            // stores are complete (vmcnt(0)) before the barrier in front of the ticket, the ticket is an agent-scope atomic.  No cache-wide operation.
+            // (16-byte accesses with the sc1 bit from inline asm: the dword forms of __hip_atomic_load ran one round trip after the other -- 128 of them per thread
+            //  for eight slabs: the sliced launch took twice the unsliced one.)  Up to eight slabs: all eight loads of a quad are issued together, surplus
+            //  ones re-read the last slab and are not added.
+            f32x4* slab0 = reinterpret_cast<f32x4*>(a.ws) + (int64_t)tile_lin * S * (Q / 4);
+            const f32x4* ct4 = reinterpret_cast<const f32x4*>(ct);
+            for (int q = tid; q < Q / 4; q += 64 * NW) {        // the LDS image as it is: the slab is this tile's own
+                const f32x4 v = ct4[q];
+                f32x4* dst = slab0 + (int64_t)blockIdx.y * (Q / 4) + q;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* flag = reinterpret_cast<int*>(ct + BM * BN);
+            if (tid == 0) *flag = __hip_atomic_fetch_add(a.tick + tile_lin, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (*flag != S - 1) return;
+            for (int q = tid; q < Q / 4; q += 64 * NW) {
+                const f32x4 *p0, *p1, *p2, *p3, *p4, *p5, *p6, *p7;
+                auto at = [&](int sl) { return slab0 + (int64_t)(sl < S ? sl : S - 1) * (Q / 4) + q; };
+                p0 = at(0); p1 = at(1); p2 = at(2); p3 = at(3); p4 = at(4); p5 = at(5); p6 = at(6); p7 = at(7);
+                f32x4 u0, u1, u2, u3, u4, u5, u6, u7;
+                asm volatile(
+                    "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\tglobal_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
+                    "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\tglobal_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\t"
+                    "s_waitcnt vmcnt(0)"
+                    : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(u4), "=&v"(u5), "=&v"(u6), "=&v"(u7)
+                    : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7)
+                    : "memory");
+                f32x4 v = u0;                                   // ascending slice order, whoever arrived last
+                if (1 < S) v += u1;
+                if (2 < S) v += u2;
+                if (3 < S) v += u3;
+                if (4 < S) v += u4;
+                if (5 < S) v += u5;
+                if (6 < S) v += u6;
+                if (7 < S) v += u7;
+                reinterpret_cast<f32x4*>(ct)[q] = v;
+            }
+            if (tid == 0) __hip_atomic_store(a.tick + tile_lin, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch (and the next replay of a captured one)
+            __syncthreads();
+        }
+    }
     if constexpr (EPI == DMVAE_EPI_ADAM && !CONV) {
         // the update in batches of NB quads whose parameter / m / v loads are in flight together (adam_quads, gemm_tile.h)
         constexpr int NQE = BM * CH / NT;
@@ -511,6 +567,7 @@ template <int BM, int BN, int EPI, int NSTAGE, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_bf16_dx_riders_kernel(GemmArgs a, GemmRiders r) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * (BM + BN) * BK];
     const int lead = r.nfin + (r.gat_last ? 0 : r.ngat);
+    if (blockIdx.y > 0 && ((int)blockIdx.x < lead || (r.gat_last && (int)blockIdx.x >= (int)gridDim.x - r.ngat))) return;      // (K slices of the host GEMM, GemmArgs::tick: the riders ride once)
     if (r.gat_last && (int)blockIdx.x >= (int)gridDim.x - r.ngat) {
         if constexpr (MEAS_EMPTY_GATHER_RIDERS) return;
         gather_rows_block<bf16_t, 16>((int)blockIdx.x - ((int)gridDim.x - r.ngat), 64 * NW, r.gat);
@@ -696,12 +753,12 @@ template <int BM, int BN, int LAYOUT, int EPI, int NSTAGE, int NW = 4>
 static int launch(hipStream_t s, const GemmArgs& a, int split, const GemmRiders* riders = nullptr) {
     dim3 grid((a.M / BM) * (a.N / BN), split);
     if constexpr (LAYOUT == DMVAE_GEMM_DX && (EPI == DMVAE_EPI_LATENT || EPI == DMVAE_EPI_RELU_MASK)) {
-        if (riders && split == 1) {      // riders in the first ids of this grid (gemm_bf16_dx_riders_kernel)
+        if (riders && (split == 1 || a.tick)) {      // riders in the first ids of this grid (gemm_bf16_dx_riders_kernel); with K slices (GemmArgs::tick) in slice 0 only
             GemmRiders r = *riders;
             double rbytes = 0.0;
             if (r.ngat) { r.gat.nblocks = r.ngat; rbytes = (double)r.gat.n_valid * r.gat.dim * (4 + 2); }
             ProfScope ps(s, kernel_name<BM, BN, LAYOUT, EPI, NSTAGE, NW>(false), 2.0 * a.M * a.N * (double)a.K, gemm_bytes(a) + rbytes);
-            DMVAE_LAUNCH((gemm_bf16_dx_riders_kernel<BM, BN, EPI, NSTAGE, NW>), dim3(grid.x + r.nfin + r.ngat), dim3(64 * NW), 0, s, a, r);
+            DMVAE_LAUNCH((gemm_bf16_dx_riders_kernel<BM, BN, EPI, NSTAGE, NW>), dim3(grid.x + r.nfin + r.ngat, split), dim3(64 * NW), 0, s, a, r);
             return check_launch("gemm_bf16 (dX + riders)");
         }
     }
@@ -1015,7 +1072,7 @@ void gemm_bf16_set_knob(int which, int v) {
 // weight panel each workgroup re-reads comes from L2.  The dZ launch at 4096 rows (rocprofv3, 302 replays): 11.49 us on 64 tiles of 64 rows,
 // 10.19 on 128 of 32 rows, 8.92 on 256 of 16 rows (two waves per workgroup; the step_finalize blocks then ride in the output layer's dX launch).
 static int gemm_bf16_thin_rows(const GemmArgs& a) {      // 0: the general tiles; 32 / 16: rows of the thin tile -- the thinnest that still fits one round of 256 CUs
-    if (!g_thin || a.conv_c || a.N != 64 || a.K < 1024 || a.k_split != a.K) return 0;
+    if (!g_thin || a.conv_c || a.N != 64 || a.K < 1024 || (a.k_split != a.K && !a.tick)) return 0;      // (K slices joined by tickets keep the thin tile)
     if (g_thin >= 2 && a.M % 16 == 0 && a.M / 16 <= 256) return 16;
     if (a.M % 32 == 0 && a.M / 32 <= 256) return 32;
     return 0;

@@ -41,6 +41,11 @@ struct GemmArgs {
     // DW layout, grouped small-tile launch: a BIAS-ONLY strip -- M = 64 pro forma, A is never read; only epi.out2 (the column sums of B)
     // is produced.  The layer's weight gradient itself runs on the macro tile (K slices into slabs, csrc/api.hip launch_dw_queue).
     int bias_only = 0;
+    // K slices of a FUSED-epilogue problem (small-tile kernel, FWD / DX layouts; round 5): grid.y = K / k_split workgroups per tile, each storing its
+    // f32 partial tile to slab [tile][slice] of `ws` (>= tiles * slices * BM * BN floats); the LAST one to arrive (a ticket per tile in `tick`, which
+    // starts at zero and is reset by that workgroup) adds the slabs in ascending slice order and runs the epilogue: deterministic, no float atomics.
+    // For launches that occupy a fraction of the chip with a long K chain (a 100-row batch: every GEMM < 32 CUs).
+    int* tick = nullptr;
 };
 
 // element offset of K position k (multiple of the tile depth) of a conv-mode A operand

@@ -33,13 +33,20 @@ struct HeadsLatentLaunch {
     const bf16_t* Wlg; int64_t ldlg;     // [Hp][ldlg >= 64]
     const float* bmv; const float* blg;  // f32 biases: 2 Dp / 64 entries
     int nt_lg;                           // 16-column tiles of the logits head that hold real classes: ceil(K / 16)
+    // K slices (small batches: few 16-row blocks, each a long K chain): gridDim.y workgroups per block, each over Hp / gridDim.y of the contraction; the
+    // partial f32 tiles meet in slab [block][slice] of ks_ws, the last slice to arrive (ticket ks_tick[block]) adds them in ascending order, adds the
+    // biases and runs the latent stage (the scheme of GemmArgs::tick, gemm_bf16.hip)
+    float* ks_ws; int* ks_tick;
 };
 
 template <int DP> struct HLGeom {        // DP = Dp / 64
     static constexpr int NMV = 128 * DP;
     static constexpr int A_ELEMS = 32 * BK, MVH_ELEMS = 128 * BK, LG_ELEMS = 64 * BK;
     static constexpr int STAGE = A_ELEMS + DP * MVH_ELEMS + LG_ELEMS;        // bf16 elements per ring slot
-    static constexpr int NSTAGE = DP == 1 ? 4 : 3;
+#ifndef DMVAE_HL_NSTAGE1
+#define DMVAE_HL_NSTAGE1 4      // (a measurement build may set 5: 140 KiB of ring at Dp = 64)
+#endif
+    static constexpr int NSTAGE = DP == 1 ? DMVAE_HL_NSTAGE1 : 3;
     static constexpr int LOADS = 1 + 4 * DP + 2;                             // LDS-DMA instructions per lane per K tile
     static constexpr int TLD = NMV + 64 + 4;                                 // floats per row of the parked f32 tile (+ 4: rows start on different banks)
     static constexpr size_t RING_BYTES = (size_t)NSTAGE * STAGE * 2;
@@ -67,10 +74,12 @@ __global__ __launch_bounds__(256) void heads_latent_kernel(HeadsLatentLaunch H) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, g = lane >> 4;
     const int row0 = (int)blockIdx.x * 16;
-    const int nk = H.Hp / BK;
+    const int nsl = (int)gridDim.y;                       // K slices (1 = none)
+    const int nk = H.Hp / BK / nsl;
+    const int k0 = (int)blockIdx.y * nk;                  // first K tile of this slice
     const bool has_lg = wave < H.nt_lg;
 
-    const bf16_t* Ag = H.hz + (int64_t)row0 * H.lda;
+    const bf16_t* Ag = H.hz + (int64_t)row0 * H.lda + (int64_t)k0 * BK;
     const int64_t stepMV = (int64_t)BK * H.ldmv, stepLG = (int64_t)BK * H.ldlg;
 
     // loop-invariant per-lane addressing.  A: one k-contiguous 32-row tile whose rows 16..31 are rows 0..15 of the c-head's columns.
@@ -102,9 +111,9 @@ __global__ __launch_bounds__(256) void heads_latent_kernel(HeadsLatentLaunch H) 
     auto issue = [&](int t, int slot) {
         const unsigned s = lds_w + 2u * (unsigned)(slot * G::STAGE);
         glds_tile(Ag + (int64_t)t * BK, goA, s, 4096u);
-        glds_tile(H.Wmv + t * stepMV, goMV, s + 2u * G::A_ELEMS, 4096u);
-        if constexpr (DP == 2) glds_tile(H.Wmv + 128 + t * stepMV, goMV, s + 2u * (G::A_ELEMS + G::MVH_ELEMS), 4096u);
-        glds_tile(H.Wlg + t * stepLG, goLG, s + 2u * (G::A_ELEMS + DP * G::MVH_ELEMS), 4096u);
+        glds_tile(H.Wmv + (k0 + t) * stepMV, goMV, s + 2u * G::A_ELEMS, 4096u);
+        if constexpr (DP == 2) glds_tile(H.Wmv + 128 + (k0 + t) * stepMV, goMV, s + 2u * (G::A_ELEMS + G::MVH_ELEMS), 4096u);
+        glds_tile(H.Wlg + (k0 + t) * stepLG, goLG, s + 2u * (G::A_ELEMS + DP * G::MVH_ELEMS), 4096u);
     };
     f32x4 acc[2 * DP], accl = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -135,9 +144,9 @@ __global__ __launch_bounds__(256) void heads_latent_kernel(HeadsLatentLaunch H) 
     for (int j = 0; j < 2 * DP; ++j) loadf4(H.bmv, (wave * 2 * DP + j) * 16 + g * 4, bq[j]);
     if (has_lg) loadf4(H.blg, wave * 16 + g * 4, bl);
 
-    const LatentTile lt{tile, G::TLD, 64 * DP, G::NMV};
+    const LatentTile lt{(const lds_f*)tile, G::TLD, 64 * DP, G::NMV};
     latent_body<MODE, DSL, true>(
-        H.L, lat, lat_rows, (int)blockIdx.x, lt,
+        H.L, (lds_f*)lat, (lds_f*)lat_rows, (int)blockIdx.x, lt,
         [&] {          // top: the first ring tiles, before anything else of the block touches memory
 #pragma unroll
             for (int t = 0; t < G::NSTAGE; ++t)
@@ -167,20 +176,68 @@ __global__ __launch_bounds__(256) void heads_latent_kernel(HeadsLatentLaunch H) 
             }
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();          // every wave is done with the ring: it becomes the f32 tile
+            const bool sliced = nsl > 1;                   // (then the biases are added behind the sum of the slices)
 #pragma unroll
             for (int j = 0; j < 2 * DP; ++j) {
                 f32x4 v = acc[j];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += bq[j][e];
+                for (int e = 0; e < 4; ++e) v[e] += sliced ? 0.f : bq[j][e];
                 *reinterpret_cast<f32x4*>(tile + li * G::TLD + (wave * 2 * DP + j) * 16 + g * 4) = v;
             }
             {
                 f32x4 v = accl;                    // (a wave without a logits tile: zeros -- the pad columns of the logits buffer)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += bl[e];
+                for (int e = 0; e < 4; ++e) v[e] += sliced ? 0.f : bl[e];
                 *reinterpret_cast<f32x4*>(tile + li * G::TLD + G::NMV + wave * 16 + g * 4) = v;
             }
             __syncthreads();
+            if (sliced) {
+                // the partial tile to its slab, a ticket, and the last slice to arrive adds them up (agent-scope 16-byte accesses, no cache-wide fence:
+                // see gemm_bf16_body); the biases after the sum
+                constexpr int TQ = 16 * G::TLD / 4;
+                f32x4* slab0 = reinterpret_cast<f32x4*>(H.ks_ws) + (int64_t)blockIdx.x * nsl * TQ;
+                for (int q = tid; q < TQ; q += 256) {
+                    const f32x4 v = reinterpret_cast<const f32x4*>(tile)[q];
+                    f32x4* dst = slab0 + (int64_t)blockIdx.y * TQ + q;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                int* flag = reinterpret_cast<int*>(lat_rows);          // (the row arrays are not in use yet)
+                if (tid == 0) *flag = __hip_atomic_fetch_add(H.ks_tick + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                const bool last = *flag == nsl - 1;
+                __syncthreads();                                       // (everyone has read the flag before the row arrays are written)
+                if (!last) return false;
+                for (int q = tid; q < TQ; q += 256) {
+                    const f32x4 *p0, *p1, *p2, *p3, *p4, *p5, *p6, *p7;
+                    auto at = [&](int sl) { return slab0 + (int64_t)(sl < nsl ? sl : nsl - 1) * TQ + q; };
+                    p0 = at(0); p1 = at(1); p2 = at(2); p3 = at(3); p4 = at(4); p5 = at(5); p6 = at(6); p7 = at(7);
+                    f32x4 u0, u1, u2, u3, u4, u5, u6, u7;
+                    asm volatile(
+                        "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\tglobal_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
+                        "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\tglobal_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\t"
+                        "s_waitcnt vmcnt(0)"
+                        : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(u4), "=&v"(u5), "=&v"(u6), "=&v"(u7)
+                        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7)
+                        : "memory");
+                    f32x4 v = u0;
+                    if (1 < nsl) v += u1;
+                    if (2 < nsl) v += u2;
+                    if (3 < nsl) v += u3;
+                    if (4 < nsl) v += u4;
+                    if (5 < nsl) v += u5;
+                    if (6 < nsl) v += u6;
+                    if (7 < nsl) v += u7;
+                    const int c = (q * 4) % G::TLD;                    // column of the quad (TLD is a multiple of 4); the 4 pad columns take no bias
+                    f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (c < G::NMV) b = *reinterpret_cast<const f32x4*>(H.bmv + c);
+                    else if (c < G::NMV + 64) b = *reinterpret_cast<const f32x4*>(H.blg + (c - G::NMV));
+                    reinterpret_cast<f32x4*>(tile)[q] = v + b;
+                }
+                if (tid == 0) __hip_atomic_store(H.ks_tick + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+            }
             // mean | log_var | logits to global memory, row-contiguous quads (what DMVAE_EPI_BIAS_F32 stored)
             constexpr int QPR = (G::NMV + 64) / 4;
             const dmvae_latent_args& a = H.L.a;
@@ -191,6 +248,7 @@ __global__ __launch_bounds__(256) void heads_latent_kernel(HeadsLatentLaunch H) 
                                         : const_cast<float*>(a.logits) + (int64_t)(row0 + r) * a.ld_logits + (c - G::NMV);
                 *reinterpret_cast<f32x4*>(dst) = v;
             }
+            return true;
         });
 }
 
@@ -220,11 +278,13 @@ bool heads_latent_ok(int B_pad, int D, int K, int Dp, int Kp, int Hp, int mode, 
 }
 
 template <int MODE, int DSL, int DP>
-static void hl_launch_t(hipStream_t s, const HeadsLatentLaunch& H, int nblk, size_t lds) {
+static void hl_launch_t(hipStream_t s, const HeadsLatentLaunch& H, int nblk, int nsl, size_t lds) {
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute((const void*)heads_latent_kernel<MODE, DSL, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
-    DMVAE_LAUNCH((heads_latent_kernel<MODE, DSL, DP>), dim3(nblk), dim3(256), lds, s, H);
+    DMVAE_LAUNCH((heads_latent_kernel<MODE, DSL, DP>), dim3(nblk, nsl), dim3(256), lds, s, H);
 }
+// floats of slab space K slices need (dmvae_heads_args::kslice_ws): blocks x slices x the parked tile
+int64_t heads_latent_kslice_floats(int B_pad, int Dp, int slices) { return (int64_t)(B_pad / 16) * slices * 16 * (Dp == 64 ? HLGeom<1>::TLD : HLGeom<2>::TLD); }
 
 int heads_latent_launch(hipStream_t s, const dmvae_latent_args* a, const dmvae_heads_args* h) {
     const int Dp = h->Dp, Kp = h->Kp;
@@ -249,16 +309,23 @@ int heads_latent_launch(hipStream_t s, const dmvae_latent_args* a, const dmvae_h
     H.bmv = h->b_mv; H.blg = h->b_lg;
     H.nt_lg = (a->K + 15) / 16;
     const int nblk = a->B_pad / 16;
+    const int nsl = h->kslices > 1 ? h->kslices : 1;
+    H.ks_ws = reinterpret_cast<float*>(h->kslice_ws); H.ks_tick = h->kslice_tick;
+    if (nsl > 1 && (nsl > 8 || h->Hp % (nsl * BK) || !h->kslice_ws || !h->kslice_tick || h->kslice_ws_floats < heads_latent_kslice_floats(a->B_pad, Dp, nsl))) {
+        set_error("dmvae_heads_latent_fwd: %d K slices need Hp %% (slices * 64) == 0, at most 8, a slab space of %lld floats and B_pad / 16 zeroed tickets", nsl,
+                  (long long)heads_latent_kslice_floats(a->B_pad, Dp, nsl));
+        return DMVAE_EINVAL;
+    }
     const size_t lds = Dp == 64 ? hl_lds_bytes<1>(a->K, H.L.DC) : hl_lds_bytes<2>(a->K, H.L.DC);
     const double flops = 2.0 * a->B_pad * (double)h->Hp * (2 * Dp + Kp) + 6.0 * a->B * (double)a->K * a->D;
     const double bytes = 2.0 * (2.0 * a->B_pad * h->Hp + (double)h->Hp * (2 * Dp + Kp)) + 4.0 * ((double)a->B * (8.0 * a->D + 4.0 * a->K) + 2.0 * a->K * a->D * (nblk + 1));
     ProfScope ps(s, a->mode == 0 ? "heads_latent_exact" : "heads_latent_relaxed", flops, bytes);
 #define HL(MODE_) \
     switch (H.L.DC) { \
-        case 16: hl_launch_t<MODE_, 1, 1>(s, H, nblk, lds); break; \
-        case 32: hl_launch_t<MODE_, 2, 1>(s, H, nblk, lds); break; \
-        case 64: hl_launch_t<MODE_, 4, 1>(s, H, nblk, lds); break; \
-        default: hl_launch_t<MODE_, 8, 2>(s, H, nblk, lds); break; \
+        case 16: hl_launch_t<MODE_, 1, 1>(s, H, nblk, nsl, lds); break; \
+        case 32: hl_launch_t<MODE_, 2, 1>(s, H, nblk, nsl, lds); break; \
+        case 64: hl_launch_t<MODE_, 4, 1>(s, H, nblk, nsl, lds); break; \
+        default: hl_launch_t<MODE_, 8, 2>(s, H, nblk, nsl, lds); break; \
     }
     if ((H.L.DC == 128) != (Dp == 128)) { set_error("dmvae_heads_latent_fwd: chunk width %d does not go with Dp = %d", H.L.DC, Dp); return DMVAE_EINVAL; }
     if (a->mode == 0) { HL(0) } else { HL(1) }

@@ -55,6 +55,10 @@ int latent_vade_launch(hipStream_t s, const dmvae_latent_args* a);
 bool heads_latent_ok(int B_pad, int D, int K, int Dp, int Kp, int Hp, int mode, int rows_per_latent_block);
 int heads_latent_launch(hipStream_t s, const dmvae_latent_args* a, const dmvae_heads_args* h);
 void heads_latent_set(int v);
+int64_t heads_latent_kslice_floats(int B_pad, int Dp, int slices);
+// measurement kernel (strip_fwd2.hip): two consecutive 512-wide dense layers as one row-strip kernel
+int strip_fwd2_launch(hipStream_t s, int B_pad, int K0, const void* X, int64_t ldx, const void* W0, int64_t ld0, const float* b0,
+                      const void* W1, int64_t ld1, const float* b1, void* Y1, int64_t ldy1, void* Y2, int64_t ldy2);
 // MFMA form for large prior tables (latent_mfma.hip)
 bool latent_mfma_applies(int D, int K, int mode);
 int64_t latent_mfma_ws_bytes(int B_pad, int D, int K);

@@ -38,7 +38,7 @@ namespace dmvae {
 template <int MODE, int DSL>
 __global__ __launch_bounds__(256) void latent_fwd_kernel(LatentLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    latent_body<MODE, DSL, false>(L, lds, nullptr, (int)blockIdx.x, LatentTile{nullptr, 0, 0, 0}, [] {}, [] {});
+    latent_body<MODE, DSL, false>(L, (lds_f*)lds, nullptr, (int)blockIdx.x, LatentTile{nullptr, 0, 0, 0}, [] {}, [] { return true; });
 }
 
 static int g_latent_blocks = 512;          // tuning knob (dmvae_debug_set_knob 14): blocks the geometry aims at (rows per block = 16 .. 64, a power of two)

@@ -28,31 +28,34 @@ __device__ __forceinline__ float row_max16(float v) {
 
 // The block's mean / log_var / logits rows when they come from LDS instead of global memory (FUSED: heads_latent.hip, where the workgroup has just
 // computed them): p[r * ld + d] = mean, p[r * ld + lv_col + d] = log_var, p[r * ld + lg_col + k] = logits of the block's row r.
-struct LatentTile { const float* p; int ld, lv_col, lg_col; };
+// LDS pointers carry their address space in the TYPE: as plain float* (generic pointers the optimiser resolves to LDS only late) the same code compiled
+// to 20 % more waits -- loads no longer batched across LDS traffic that might, for all the early passes knew, alias global memory -- and ran 7 % slower.
+typedef __attribute__((address_space(3))) float lds_f;
+struct LatentTile { const lds_f* p; int ld, lv_col, lg_col; };
 
 // One block of the latent stage: 256 threads, rows [blk * RB, blk * RB + RB).  lds: the block's latent arrays (latent_lds_bytes; with lds_rows: its
 // first latent_lds_head_bytes there, the remaining latent_lds_rows_bytes at lds_rows).
 // FUSED = false: latent_fwd_kernel below (mean / log_var / logits from global memory; top / mid do nothing).
 // FUSED = true (heads_latent.hip): top() runs first of all (it issues the first operand tiles of the head GEMMs), mid() runs after the
 // prior tables are staged and before the first use of the heads' outputs (it runs the GEMMs' K loop and leaves `tile` complete, behind a
-// barrier).  The arithmetic on the rows is the same code in the same order either way: same bits.
+// barrier; it returns false in a workgroup that has nothing further to do: a K slice that was not the last to arrive).  The arithmetic on the rows is the same code in the same order either way: same bits.
 template <int MODE, int DSL, bool FUSED, class TOP, class MID>   // MODE 0 exact, 1 relaxed; DSL = columns per lane per chunk (DC = 16*DSL)
-__device__ __forceinline__ void latent_body(const LatentLaunch& L, float* lds, float* lds_rows, const int blk, const LatentTile tile, TOP&& top, MID&& mid) {
+__device__ __forceinline__ void latent_body(const LatentLaunch& L, lds_f* lds, lds_f* lds_rows, const int blk, const LatentTile tile, TOP&& top, MID&& mid) {
     const dmvae_latent_args& a = L.a;
     MEAS_LAT_STAMP(0);
     const int K = a.K, D = a.D, RB = L.RB;
     constexpr int DC = 16 * DSL, DCP = DC + 1;   // +1: rows of one column land on distinct banks (phase 1b / 2)
-    float* t1 = lds;                  // [K][DCP] prior means
-    float* t2 = t1 + K * DCP;         // [K][DCP] exp(-prior_log_var) (exact) | prior_log_var (relaxed)
-    float* ck = t2 + K * DCP;         // [K]      sum_d prior_log_var
-    float* ws = ck + K;               // [RB][K]  mixture weights (softmax or zeta); 0 for pad rows
-    float* qs = ws + RB * K;          // [RB][K]  softmax(logits)
-    float* sk = qs + RB * K;          // [RB][K]  exact: sum_d (e+(mu-pm)^2)*ip ; relaxed: dLoss/dzeta
+    lds_f* t1 = lds;                  // [K][DCP] prior means
+    lds_f* t2 = t1 + K * DCP;         // [K][DCP] exp(-prior_log_var) (exact) | prior_log_var (relaxed)
+    lds_f* ck = t2 + K * DCP;         // [K]      sum_d prior_log_var
+    lds_f* ws = ck + K;               // [RB][K]  mixture weights (softmax or zeta); 0 for pad rows
+    lds_f* qs = ws + RB * K;          // [RB][K]  softmax(logits)
+    lds_f* sk = qs + RB * K;          // [RB][K]  exact: sum_d (e+(mu-pm)^2)*ip ; relaxed: dLoss/dzeta
     // (lds_rows != nullptr: the arrays from here on -- first written AFTER mid() -- live there instead of behind sk: the fused kernel overlays them on its idle ring)
-    float* r1 = lds_rows ? lds_rows : sk + RB * K;          // [RB][DCP] exact: mu   | relaxed: dLoss/d(bar mean)
-    float* r2 = r1 + RB * DCP;        // [RB][DCP] exact: e^lv | relaxed: dLoss/d(bar log_var)
-    float* rowlv = r2 + RB * DCP;     // [RB] sum_d log_var (exact) | sum_d relaxed KL integrand
-    float* red = rowlv + RB;          // [32]
+    lds_f* r1 = lds_rows ? lds_rows : sk + RB * K;          // [RB][DCP] exact: mu   | relaxed: dLoss/d(bar mean)
+    lds_f* r2 = r1 + RB * DCP;        // [RB][DCP] exact: e^lv | relaxed: dLoss/d(bar log_var)
+    lds_f* rowlv = r2 + RB * DCP;     // [RB] sum_d log_var (exact) | sum_d relaxed KL integrand
+    lds_f* red = rowlv + RB;          // [32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15;                       // lane within the row group
@@ -137,7 +140,7 @@ __device__ __forceinline__ void latent_body(const LatentLaunch& L, float* lds, f
         t1[k * DCP + d] = a.prior_means[(int64_t)k * D + d];
         t2[k * DCP + d] = (MODE == 0) ? __expf(-plv) : plv;
     }
-    mid();
+    if (!mid()) return;          // (fused kernel, K slices: only the last slice of a block to arrive goes on -- heads_latent.hip)
     float klc_acc = 0.f, klz_acc = 0.f;   // per 16-lane group (all lanes of the group hold the same value)
     for (int r = rsub; r < RB; r += 16) {
         const bool first = !FUSED && r == rsub;
@@ -383,11 +386,11 @@ __device__ __forceinline__ void latent_body(const LatentLaunch& L, float* lds, f
 
         // phase 1b: sixteen lanes per row, cluster k = lr + 16*j; sums over d in private accumulators
         for (int r = rsub; r < RB; r += 16) {
-            const float* x1 = r1 + r * DCP;
-            const float* x2 = r2 + r * DCP;
+            const lds_f* x1 = r1 + r * DCP;
+            const lds_f* x2 = r2 + r * DCP;
             for (int k = lr; k < K; k += 16) {
-                const float* p1 = t1 + k * DCP;
-                const float* p2 = t2 + k * DCP;
+                const lds_f* p1 = t1 + k * DCP;
+                const lds_f* p2 = t2 + k * DCP;
                 float s[4] = {0.f, 0.f, 0.f, 0.f};
                 int d = 0;
                 for (; d + 7 < dc; d += 8) {      // 32 independent LDS reads per trip

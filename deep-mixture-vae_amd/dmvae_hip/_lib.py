@@ -30,14 +30,14 @@ MODEL_DMVAE, MODEL_VADE = 0, 1
 EXPORTS = [
     "dmvae_gemm", "dmvae_gemm_partials", "dmvae_gemm_grouped_dw", "dmvae_gemm_grouped", "dmvae_gemm_grouped_dw_adam", "dmvae_plan_train_step", "dmvae_latent_ws_bytes", "dmvae_latent_nblocks_vade",
     "dmvae_plan_forward_backward_stage", "dmvae_plan_grad_buckets", "dmvae_plan_set_stage_groups", "dmvae_plan_update_range",
-"dmvae_latent_nblocks", "dmvae_latent_fwd", "dmvae_heads_latent_fwd", "dmvae_heads_latent_ok",
+"dmvae_latent_nblocks", "dmvae_latent_fwd", "dmvae_heads_latent_fwd", "dmvae_heads_latent_ok", "dmvae_heads_latent_kslice_floats",
     "dmvae_recon_fwd_bwd", "dmvae_recon_nblocks", "dmvae_colsum", "dmvae_loss_finalize",
     "dmvae_adam_tf", "dmvae_adam_finish", "dmvae_gather_rows", "dmvae_philox_normal",
     "dmvae_philox_gumbel", "dmvae_cast_f32_to_bf16", "dmvae_cast_bf16_to_f32",
     "dmvae_plan_create", "dmvae_plan_destroy", "dmvae_plan_sizes", "dmvae_plan_tensor",
     "dmvae_plan_bind", "dmvae_plan_load_batch", "dmvae_plan_load_batch_step", "dmvae_plan_prefetch_batch", "dmvae_plan_swap_batch", "dmvae_plan_forward_backward",
     "dmvae_plan_update", "dmvae_plan_encode", "dmvae_plan_decode", "dmvae_plan_view",
-    "dmvae_prof_enable", "dmvae_prof_collect", "dmvae_debug_spin", "dmvae_debug_stamps", "dmvae_debug_anatomy", "dmvae_debug_anatomy256", "dmvae_debug_set_tile", "dmvae_debug_set_knob", "dmvae_abi_version", "dmvae_last_error",
+    "dmvae_prof_enable", "dmvae_prof_collect", "dmvae_debug_spin", "dmvae_debug_strip_fwd2", "dmvae_debug_stamps", "dmvae_debug_anatomy", "dmvae_debug_anatomy256", "dmvae_debug_set_tile", "dmvae_debug_set_knob", "dmvae_abi_version", "dmvae_last_error",
 ]
 
 
@@ -95,7 +95,8 @@ class HeadsArgs(C.Structure):          # dmvae_heads_args
     _fields_ = [("hz", C.c_void_p), ("lda", C.c_int64),
                 ("Hp", C.c_int32), ("Dp", C.c_int32), ("Kp", C.c_int32), ("reserved", C.c_int32),
                 ("W_mv", C.c_void_p), ("ld_mv", C.c_int64), ("W_lg", C.c_void_p), ("ld_lg", C.c_int64),
-                ("b_mv", C.c_void_p), ("b_lg", C.c_void_p)]
+                ("b_mv", C.c_void_p), ("b_lg", C.c_void_p),
+                ("kslices", C.c_int32), ("reserved2", C.c_int32), ("kslice_ws", C.c_void_p), ("kslice_ws_floats", C.c_int64), ("kslice_tick", C.c_void_p)]
 
 
 class State(C.Structure):
@@ -166,6 +167,7 @@ def _load():
         "dmvae_latent_fwd": [vp, P(LatentArgs)],
         "dmvae_heads_latent_fwd": [vp, P(HeadsArgs), P(LatentArgs)],
         "dmvae_heads_latent_ok": [i32, i32, i32, i32, i32, i32, i32],
+        "dmvae_heads_latent_kslice_floats": [i32, i32, i32],
         "dmvae_recon_fwd_bwd": [vp, i32, i32, i32, i32, i32, i32, vp, i64, vp, i64, f32, vp, i64, vp],
         "dmvae_recon_nblocks": [i32, i32],
         "dmvae_colsum": [vp, i32, vp, i64, i32, i32, vp],
@@ -193,6 +195,7 @@ def _load():
         "dmvae_plan_view": [vp, C.c_char_p, P(vp), P(i64), P(C.c_int32)],
         "dmvae_prof_enable": [i32],
         "dmvae_debug_spin": [vp, i32],
+        "dmvae_debug_strip_fwd2": [vp, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, vp, i64, vp, i64],
         "dmvae_debug_stamps": [P(vp)],
         "dmvae_debug_anatomy": [P(vp)],
         "dmvae_debug_anatomy256": [P(vp)],
@@ -208,6 +211,7 @@ def _load():
         fn.restype = C.c_int
     lib.dmvae_last_error.restype = C.c_char_p
     lib.dmvae_latent_ws_bytes.restype = C.c_int64
+    lib.dmvae_heads_latent_kslice_floats.restype = C.c_int64
     lib.dmvae_plan_destroy.restype = None
     got = lib.dmvae_abi_version()
     if got != ABI_VERSION:       # the public structs grew between versions: a mismatched pair would read past them

@@ -204,7 +204,15 @@ typedef struct dmvae_heads_args {
     const void* W_lg; int64_t ld_lg; /* bf16 [Hp][ld_lg]: the logits kernel                                                           */
     const float* b_mv;               /* f32 [2 Dp] */
     const float* b_lg;               /* f32 [Kp]   */
+    /* K slices (optional; small batches: few 16-row blocks, each a long K chain): kslices (2 .. 8, Hp % (kslices * 64) == 0) workgroups per block,
+     * whose partial tiles the last one to arrive adds in ascending order before the latent stage -- deterministic; the results then differ from the
+     * unsliced call by the f32 summation order.  kslice_ws: >= dmvae_heads_latent_kslice_floats() floats; kslice_tick: B_pad / 16 ints, zero on
+     * entry (left zero).  kslices <= 1: none. */
+    int32_t kslices, reserved2;
+    float* kslice_ws; int64_t kslice_ws_floats;
+    int32_t* kslice_tick;
 } dmvae_heads_args;
+int64_t dmvae_heads_latent_kslice_floats(int B_pad, int Dp, int kslices);
 int dmvae_heads_latent_ok(int B_pad, int D, int K, int Dp, int Kp, int Hp, int mode);
 int dmvae_heads_latent_fwd(void* stream, const dmvae_heads_args* heads, const dmvae_latent_args* a);
 

@@ -34,6 +34,11 @@ int dmvae_prof_enable(int on);
  * event brackets of the following launches contain no host launch latency */
 int dmvae_debug_spin(void* stream, int microseconds);
 int dmvae_prof_collect(dmvae_prof_row* rows, int max_rows);   /* returns number of rows */
+/* measurement kernel (csrc/strip_fwd2.hip; tools/strip2_probe.py): Y1 = relu(X . W0 + b0), Y2 = relu(Y1 . W1 + b1), two 512-wide dense layers
+ * (base_models.py:220-226) as ONE row-strip launch -- 32 rows per workgroup, Y1 kept in LDS (and written), both weight matrices streamed from L2;
+ * bf16 operands, B_pad % 32 == 0, K0 % 64 == 0; same bits as two dmvae_gemm calls with DMVAE_EPI_BIAS_RELU.  Not on the step path. */
+int dmvae_debug_strip_fwd2(void* stream, int B_pad, int K0, const void* X, int64_t ldx, const void* W0, int64_t ld0, const float* b0,
+                           const void* W1, int64_t ld1, const float* b1, void* Y1, int64_t ldy1, void* Y2, int64_t ldy2);
 /* measurement builds only (tools/ablate.sh 6): device pointer of the per-workgroup stamp table of the
  * grouped GEMM kernel, 2048 x {start, end (100 MHz ticks), HW_ID<<32 | XCC_ID, layout<<32 | tile kind};
  * the product library never writes it */
@@ -83,7 +88,10 @@ int dmvae_debug_set_tile(int bm, int bn);
  *             knob 19 = heads forward + latent stage as ONE launch (csrc/heads_latent.hip) where it applies -- bf16, at most 4096 rows, Dp <= 128, K * D < 4096 -- (1,
  *                       default) or as the grouped heads GEMM + latent_fwd_kernel (0): that pair 26.3 us, the fused launch 25.3 us at 4096 rows; step -0.3 .. -0.8 %,
  *             knob 20 = XCD partition of the grouped weight-gradient launch: runs per tile-shape class by count (0, default) or cut over the whole sequence by streamed
- *                       bytes (1: fetches 13 % less at 8192 rows and is 2 .. 6 % slower on the step at every size: profiles/r05_dw_refetch.txt) */
+ *                       bytes (1: fetches 13 % less at 8192 rows and is 2 .. 6 % slower on the step at every size: profiles/r05_dw_refetch.txt),
+ *             knob 21 = K slices of the thin launches of a small batch (<= 256 rows: the dense layers with K >= 2048 and the dZ GEMM; up to 2048 rows: the fused
+ *                       heads + latent launch while blocks x slices <= 256), joined by the last workgroup to arrive (GemmArgs::tick): 1 (default) slices of
+ *                       512, 2 slices of 256 (0.1397 vs 0.1402 ms at 100 rows: the same), 0 none */
 int dmvae_debug_set_knob(int which, int value);
 
 #ifdef __cplusplus

@@ -27,7 +27,7 @@ def dev(a, dtype=torch.float32):
     return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).cuda().contiguous()
 
 
-def run_heads_latent(L, hzc, Wmv, Wlg, bmv, blg, eps, gumbel, pm, plv, mode, tau, r, B, D, K, fused, seed=1234, step=7):
+def run_heads_latent(L, hzc, Wmv, Wlg, bmv, blg, eps, gumbel, pm, plv, mode, tau, r, B, D, K, fused, seed=1234, step=7, kslices=1):
     """hzc: torch bf16 [B_pad][2 Hp]; Wmv bf16 [Hp][2 Dp]; Wlg bf16 [Hp][Kp]; returns every output of the stage as torch tensors"""
     B_pad, Hp = hzc.shape[0], hzc.shape[1] // 2
     Dp, Kp = Wmv.shape[1] // 2, Wlg.shape[1]
@@ -67,6 +67,11 @@ def run_heads_latent(L, hzc, Wmv, Wlg, bmv, blg, eps, gumbel, pm, plv, mode, tau
         h.hz, h.lda, h.Hp, h.Dp, h.Kp = hzc.data_ptr(), 2 * Hp, Hp, Dp, Kp
         h.W_mv, h.ld_mv, h.W_lg, h.ld_lg = Wmv.data_ptr(), 2 * Dp, Wlg.data_ptr(), Kp
         h.b_mv, h.b_lg = bmv.data_ptr(), blg.data_ptr()
+        if kslices > 1:
+            nfl = L.lib.dmvae_heads_latent_kslice_floats(B_pad, Dp, kslices)
+            ksws = torch.full((nfl,), float("nan"), device="cuda")                      # stale slabs must not matter
+            ticks = torch.zeros(B_pad // 16, dtype=torch.int32, device="cuda")
+            h.kslices, h.kslice_ws, h.kslice_ws_floats, h.kslice_tick = kslices, ksws.data_ptr(), nfl, ticks.data_ptr()
         L.check(L.lib.dmvae_heads_latent_fwd(stream(), C.byref(h), C.byref(a)), "dmvae_heads_latent_fwd")
     else:
         pr = (L.GemmProblem * 2)()
@@ -79,6 +84,8 @@ def run_heads_latent(L, hzc, Wmv, Wlg, bmv, blg, eps, gumbel, pm, plv, mode, tau
         L.check(L.lib.dmvae_gemm_grouped(stream(), 1, 0, pr, 2), "dmvae_gemm_grouped")
         L.check(L.lib.dmvae_latent_fwd(stream(), C.byref(a)), "dmvae_latent_fwd")
     torch.cuda.synchronize()
+    if fused and kslices > 1:
+        assert not ticks.any().item(), "the tickets must be back at zero"
     return dict(mv=mv, logits=lg, Z=Z, Zf=Zf, w=w, gmu=gmu, glv=glv, clv=clv, dlogits=dlg, dpri=dpri, lp=lp)
 
 
@@ -128,6 +135,36 @@ def test_heads_latent_fused_equals_the_two_launches(hip, B, D, K, Hp, mode, nois
         assert torch.equal(again[k], one[k]), "%s: not reproducible" % k
 
 
+@pytest.mark.parametrize("B,D,K,Hp,mode,S", [(100, 10, 10, 2048, 0, 8), (256, 64, 10, 2048, 1, 4), (1000, 128, 10, 1024, 0, 2), (16, 3, 5, 128, 0, 2)])
+def test_heads_latent_in_k_slices(hip, B, D, K, Hp, mode, S):
+    """K slices of the fused launch (dmvae_heads_args::kslices; small batches: few 16-row blocks, each a long K chain): S workgroups per block, the last to
+    arrive adds the partial tiles in ascending order, then biases and the latent stage.  Against the unsliced launch: the heads' outputs agree to f32
+    summation order (1e-5), everything downstream to the tolerances below; two sliced runs are bit-identical; the tickets end at zero."""
+    L = hip
+    rng = np.random.RandomState(3 * B + D + K + S)
+    B_pad = (B + 63) // 64 * 64
+    Dp, Kp = (D + 63) // 64 * 64, 64
+    hzc = np.maximum(rng.randn(B_pad, 2 * Hp), 0.0) * 0.5
+    hzc[B:] = 0.0
+    Wmv = np.zeros((Hp, 2 * Dp)); Wmv[:, :D] = rng.randn(Hp, D) * 0.05; Wmv[:, Dp:Dp + D] = rng.randn(Hp, D) * 0.03
+    Wlg = np.zeros((Hp, Kp)); Wlg[:, :K] = rng.randn(Hp, K) * 0.06
+    bmv = np.zeros(2 * Dp); bmv[:D] = rng.randn(D) * 0.1; bmv[Dp:Dp + D] = rng.randn(D) * 0.1 - 0.3
+    blg = np.zeros(Kp); blg[:K] = rng.randn(K) * 0.2
+    pm, plv = rng.randn(K, D), rng.randn(K, D) * 0.4
+    t = [dev(hzc, torch.bfloat16), dev(Wmv, torch.bfloat16), dev(Wlg, torch.bfloat16), dev(bmv), dev(blg)]
+    one = run_heads_latent(L, *t, None, None, pm, plv, mode, 0.7, 0.8, B, D, K, fused=True)
+    sl = run_heads_latent(L, *t, None, None, pm, plv, mode, 0.7, 0.8, B, D, K, fused=True, kslices=S)
+    sl2 = run_heads_latent(L, *t, None, None, pm, plv, mode, 0.7, 0.8, B, D, K, fused=True, kslices=S)
+    for k in sl:
+        assert torch.equal(sl[k], sl2[k]), "%s: two sliced runs differ" % k
+    np.testing.assert_allclose(sl["mv"].cpu().numpy(), one["mv"].cpu().numpy(), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(sl["logits"].cpu().numpy(), one["logits"].cpu().numpy(), rtol=1e-5, atol=2e-5)
+    for k, tol in (("Zf", 1e-4), ("w", 1e-4), ("gmu", 1e-3), ("glv", 1e-3), ("clv", 1e-4)):
+        a, b = one[k].cpu().numpy(), sl[k].cpu().numpy()
+        assert np.abs(a - b).max() <= tol * max(1e-6, np.abs(a).max()), k
+    assert sl["lp"].double().sum(0).cpu().numpy() == pytest.approx(one["lp"].double().sum(0).cpu().numpy(), rel=1e-5)
+
+
 def _three_bf16_pieces(x):
     """x (float32) = p0 + p1 + p2 exactly, each piece representable in bf16 (8 significant bits each, truncation)"""
     x = np.asarray(x, np.float32)
@@ -157,7 +194,7 @@ def test_heads_latent_against_reference_golden_vectors(hip, golden):
         gv = lambda k: golden[pre + k]
         B, D, K = (int(x) for x in gv("shape"))
         B_pad, Dp, Kp = (B + 15) // 16 * 16, 64, 64
-        Hp = (3 * B + 63) // 64 * 64
+        Hp = (3 * B + 127) // 128 * 128
         hzc = np.zeros((B_pad, 2 * Hp), np.float32)
         Wmv, Wlg = np.zeros((Hp, 2 * Dp), np.float32), np.zeros((Hp, Kp), np.float32)
         for i, (pmean, plvar, plog) in enumerate(zip(_three_bf16_pieces(gv("mean")), _three_bf16_pieces(gv("log_var")), _three_bf16_pieces(gv("logits")))):
@@ -166,8 +203,10 @@ def test_heads_latent_against_reference_golden_vectors(hip, golden):
                 Wmv[3 * b + i, :D] = pmean[b]; Wmv[3 * b + i, Dp:Dp + D] = plvar[b]
                 Wlg[3 * b + i, :K] = plog[b]
         t = [dev(hzc, torch.bfloat16), dev(Wmv, torch.bfloat16), dev(Wlg, torch.bfloat16), dev(np.zeros(2 * Dp)), dev(np.zeros(Kp))]
-        for mode, tau, ti in ((0, 1.0, None), (1, 1.0, 0), (1, 0.5, 1)):
-            o = run_heads_latent(L, *t, gv("eps"), gv("gumbel").reshape(B, K), gv("prior_means"), gv("prior_log_vars"), mode, tau, 1.0, B, D, K, fused=True)
+        for mode, tau, ti, S in ((0, 1.0, None, 1), (1, 1.0, 0, 1), (1, 0.5, 1, 1), (0, 1.0, None, 2), (1, 0.5, 1, 4 if Hp % 256 == 0 else 2)):
+            # (S > 1: in K slices -- the three pieces of a value may meet in different slices; their f32 sum is the value in any order, so the heads' outputs
+            #  are still the golden inputs bit for bit)
+            o = run_heads_latent(L, *t, gv("eps"), gv("gumbel").reshape(B, K), gv("prior_means"), gv("prior_log_vars"), mode, tau, 1.0, B, D, K, fused=True, kslices=S)
             mv, lg = o["mv"].cpu().numpy(), o["logits"].cpu().numpy()
             np.testing.assert_array_equal(mv[:B, :D], gv("mean").astype(np.float32))
             np.testing.assert_array_equal(mv[:B, Dp:Dp + D], gv("log_var").astype(np.float32))
@@ -194,7 +233,8 @@ def test_heads_latent_refuses_what_it_cannot_take(hip):
 
 
 def test_step_with_and_without_the_fused_heads_latent_launch(hip):
-    """the whole bf16 training step with knob 19 = 1 (fused, default) and 0 (two launches): same loss, parameters, moments after three steps"""
+    """the whole bf16 training step with knob 19 = 1 (fused, default) and 0 (two launches): same loss, parameters, moments after three steps
+    (K slices off -- knob 21 = 0: at 512 rows the fused launch would run in slices, whose f32 summation order is another one)"""
     L = hip
     import dmvae_oracle as O
     from dmvae_hip import StepEngine
@@ -204,6 +244,7 @@ def test_step_with_and_without_the_fused_heads_latent_launch(hip):
     perm = torch.randperm(2 * B, device="cuda").to(torch.int32)
     out = []
     try:
+        L.check(L.lib.dmvae_debug_set_knob(21, 0))
         for knob in (1, 0):
             L.check(L.lib.dmvae_debug_set_knob(19, knob))
             e = StepEngine(dtype="bf16", max_batch=B, seed=3, **kw)
@@ -215,6 +256,7 @@ def test_step_with_and_without_the_fused_heads_latent_launch(hip):
             out.append((st.last_loss, st.epoch_loss, e.param.clone(), e.m.clone(), e.v.clone(), e.view("mean").clone(), e.view("logits").clone()))
     finally:
         L.check(L.lib.dmvae_debug_set_knob(19, 1))
+        L.check(L.lib.dmvae_debug_set_knob(21, 1))
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
     for a, b in zip(out[0][2:], out[1][2:]):
         assert torch.equal(a, b)

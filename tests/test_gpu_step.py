@@ -398,6 +398,48 @@ def test_a_batch_loaded_by_explicit_first_takes_repeat_passes(hip):
         e.forward_backward(B, eps)
 
 
+def test_k_slices_of_the_thin_launches_at_small_batches(hip):
+    """at <= 256 rows the dense launches with K >= 1024 (here: the 2000 -> 500 decoder layer, 4 slices; the dX of the 500 -> 2 x 2000 head
+    hidden layer, K = 4096, 8 slices) are cut into K slices whose partial tiles the last workgroup to arrive adds in a fixed order before the fused
+    epilogue (GemmArgs::tick, csrc/gemm_bf16.hip).  Against the unsliced launches (knob 21 = 0): same step up to the f32 summation order -- loss to
+    1e-5 relative, gradients to 2e-3 of each tensor's max; two sliced runs bit-identical (no atomics in the sum); HIP-graph replay == eager; the tickets
+    are back at zero after every launch (three steps in a row work)."""
+    kw, B = dict(input_dim=784, latent_dim=10, n_classes=10), 100
+    X = torch.as_tensor(O.synthetic_images(B, 784, seed=2)).cuda()
+    eps = torch.as_tensor(np.random.RandomState(3).randn(B, 10).astype(np.float32)).cuda()
+    res = {}
+    try:
+        for name, knob in (("off", 0), ("on", 1), ("on2", 1)):
+            hip.check(hip.lib.dmvae_debug_set_knob(21, knob))
+            e = make(kw, "bf16", B, seed=9)
+            for _ in range(3):
+                e.load_batch(X, None, 0, B)
+                e.forward_backward(B, eps)
+            torch.cuda.synchronize()
+            res[name] = (e.read_state().last_loss, e.grad.clone(), {k: v.float().clone() for k, v in e.hidden_activations(B).items()}, e)
+        assert res["on"][0] == res["on2"][0] and torch.equal(res["on"][1], res["on2"][1])            # deterministic
+        assert abs(res["on"][0] - res["off"][0]) <= 1e-5 * abs(res["off"][0])
+        for k in res["off"][2]:
+            a, b = res["off"][2][k], res["on"][2][k]
+            assert (a - b).abs().max().item() <= 2e-2 * max(1e-6, a.abs().max().item()), k        # bf16 activations: a unit in the last place
+        e_off, e_on = res["off"][3], res["on"][3]
+        for k in e_off.tensors:
+            a, b = e_off.grad_view(k), e_on.grad_view(k)
+            assert (a - b).abs().max().item() <= 2e-3 * max(1e-12, a.abs().max().item()), k
+        # the captured step replays the same sliced launches (tickets reset inside the graph)
+        data = torch.as_tensor(O.synthetic_images(4 * B, 784, seed=5)).cuda()
+        perm = torch.randperm(4 * B, device="cuda").to(torch.int32)
+        g, h = make(kw, "bf16", B, seed=4), make(kw, "bf16", B, seed=4)
+        g.reset_epoch(4); h.reset_epoch(4)
+        rp = g.capture_step(data, perm, pipelined=False)
+        for _ in range(4):
+            rp(); h.train_step(data, perm, use_state_cursor=True)
+        torch.cuda.synchronize()
+        assert g.read_state().epoch_loss == h.read_state().epoch_loss and torch.equal(g.param, h.param)
+    finally:
+        hip.check(hip.lib.dmvae_debug_set_knob(21, 1))
+
+
 def test_pipelined_capture_is_the_default_for_small_batches_only(monkeypatch):
     """capture_step's default: pipelined up to PIPELINE_MAX_BATCH rows (measured: -2.7 % at 100 rows, -1.7 % at 2048, nothing at 4096), DMVAE_PREFETCH=0 / 1 forces"""
     from dmvae_hip import runtime
