@@ -455,10 +455,25 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
         }
     }
     if constexpr (EPI == DMVAE_EPI_ADAM && !CONV) {
-        // the update in batches of NB quads whose parameter / m / v loads are in flight together (adam_quads, gemm_tile.h)
+        // the update in batches of NB quads whose parameter / m / v loads are in flight together, SOFTWARE-PIPELINED over the batches (adam_pipelined,
+        // gemm_tile.h: the loads of batch i + 1 are issued before the stores of batch i -- vmcnt counts both in issue order, so a load behind stores is
+        // seen only once they are acknowledged; batch after batch, as until round 5, every batch paid a full round trip with nothing in flight)
         constexpr int NQE = BM * CH / NT;
         constexpr int NB = NQE % 4 == 0 ? 4 : (NQE % 2 == 0 ? 2 : 1);
         const unsigned base = (unsigned)((reinterpret_cast<const float*>(a.epi.out) - ac->grad) + (int64_t)m0 * a.epi.ldo + n0);
+#ifndef DMVAE_ADAM_EPI_BATCHWISE
+        adam_pipelined<NB, NQE / NB>(*ac,
+            [&](int i, int b) {
+                const int idx = (i * NB + b) * NT + tid;
+                return base + (unsigned)(idx / CH) * (unsigned)a.epi.ldo + (unsigned)(idx % CH) * 4u;
+            },
+            [&](int i, int b, float (&gv)[4]) {
+                const int idx = (i * NB + b) * NT + tid;
+                const int ml = idx / CH, c = idx % CH;
+                const f32x4 t = *reinterpret_cast<const f32x4*>(ct + ml * BN + ((c ^ (ml & 7)) << 2));
+                gv[0] = t[0]; gv[1] = t[1]; gv[2] = t[2]; gv[3] = t[3];
+            });
+#else
 #pragma unroll
         for (int q0 = 0; q0 < NQE; q0 += NB) {
             unsigned off[NB];
@@ -474,6 +489,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
                 gv[0] = t[0]; gv[1] = t[1]; gv[2] = t[2]; gv[3] = t[3];
             });
         }
+#endif
     } else
 #pragma unroll
     for (int q = 0; q < BM * CH / NT; ++q) {
