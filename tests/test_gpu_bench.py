@@ -39,4 +39,5 @@ def test_bench_two_ranks_over_gloo_prints_one_json_line(form):
     assert len(d["rank_ms_per_step_min_max"]) == 3 and all(a <= b for a, b in d["rank_ms_per_step_min_max"])
     ex = d["exchange"]
     assert ex["exposed_us"] > 0 and ex["step_us"] >= ex["exposed_us"] and ex["exposed_us_min_over_ranks"] <= ex["exposed_us_max_over_ranks"]
+    assert ex["self_check"] == "ok"              # the replicas' checksums after the first sharded step agreed (parallel.ShardedExchange.self_check)
     assert d["roofline"]["frac"] <= 1.0 and d["kernels_per_step"] >= 10            # the profiling leg ran (behind sync_master)
