@@ -42,6 +42,45 @@ def test_ctypes_structs_match_header_layout():
     assert C.sizeof(_lib.Config) == 4 * 3 + 4 + 32 + 4 + 4 + 32 + 4 * 4 + 4 * 4 + 8 + 4 + 4 + 4 + 4
 
 
+def test_ctypes_structs_match_the_header_as_a_c_compiler_lays_it_out(tmp_path):
+    """The boundary is a C header: compile it with gcc (plain C, no HIP) and compare sizeof and the offset of EVERY field of every public struct with the
+    ctypes mirror the Python side binds (dmvae_hip/_lib.py) -- a field added on one side only, or in another order, fails here, not on the GPU."""
+    import ctypes as C
+    import subprocess
+    from dmvae_hip import _lib
+    pairs = [("dmvae_epilogue", _lib.Epilogue), ("dmvae_gemm_problem", _lib.GemmProblem), ("dmvae_adam_ctx", _lib.AdamCtx), ("dmvae_latent_args", _lib.LatentArgs),
+             ("dmvae_heads_args", _lib.HeadsArgs), ("dmvae_state", _lib.State), ("dmvae_config", _lib.Config), ("dmvae_tensor_info", _lib.TensorInfo),
+             ("dmvae_sizes", _lib.Sizes), ("dmvae_buffers", _lib.Buffers), ("dmvae_prof_row", _lib.ProfRow)]
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dmvae_hip.h")).read() + open(os.path.join(ROOT, "include", "dmvae_hip_debug.h")).read(), flags=re.S)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dmvae_hip_debug.h"', 'int main(void) {']
+    want = {}
+    for cname, cls in pairs:
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, flags=re.S).group(1)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):                     # "float* gmu; float* glv" and "int32_t B, B_pad" forms
+                m = re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*(\[[^\]]*\])?\s*$", part.strip())
+                fields.append(m.group(1))
+        py = [f[0] for f in cls._fields_]
+        assert fields == py, (cname, [a for a in fields if a not in py], [b for b in py if b not in fields], fields, py)
+        lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for f in fields:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (cname, f))
+        lines.append('printf("\\n");')
+        want[cname] = [C.sizeof(cls)] + [getattr(cls, f).offset for f in py]
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    got = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in out.splitlines()}
+    assert got == want, {k: (got.get(k), want[k]) for k in want if got.get(k) != want[k]}
+
+
 def test_plan_layout_without_gpu():
     """plan creation is host-only: arena layout, padding and the tensor table."""
     import ctypes as C
