@@ -440,6 +440,51 @@ def test_k_slices_of_the_thin_launches_at_small_batches(hip):
         hip.check(hip.lib.dmvae_debug_set_knob(21, 1))
 
 
+def test_k_slices_repeated_passes_stay_identical(hip):
+    """The K slices hand partial tiles from one XCD to another inside a kernel (agent-scope stores, a ticket, agent-scope loads: csrc/gemm_bf16.hip,
+    csrc/heads_latent.hip).  A visibility fault there -- a slab read before it is complete, a stale line -- would show as a RARE difference: 400 passes over
+    the same batch (each running the sliced dense launches, the sliced dZ GEMM and the fused heads + latent launch in eight slices) must give the bits
+    of the first one, and so must 200 replays of a captured pass at 256 rows."""
+    kw = dict(input_dim=784, latent_dim=10, n_classes=10)
+    for B, reps in ((100, 400), (256, 200)):
+        X = torch.as_tensor(O.synthetic_images(B, 784, seed=7)).cuda()
+        eps = torch.as_tensor(np.random.RandomState(8).randn(B, 10).astype(np.float32)).cuda()
+        e = make(kw, "bf16", B, seed=5)
+        e.load_batch(X, None, 0, B)
+        e.forward_backward(B, eps)
+        torch.cuda.synchronize()
+        g0, l0, m0 = e.grad.clone(), e.read_state().last_loss, e.view("mean").clone()
+        bad = 0
+        for i in range(reps):
+            e.forward_backward(B, eps)
+            if i % 20 == 19 or i == reps - 1:
+                torch.cuda.synchronize()
+                bad += int(not torch.equal(e.grad, g0)) + int(e.read_state().last_loss != l0) + int(not torch.equal(e.view("mean"), m0))
+        assert bad == 0, (B, bad)
+    # ... and with the inputs CHANGING from pass to pass (identical passes cannot tell a stale slab from a fresh one): 60 different batches through a
+    # sliced and an unsliced engine in turn; a slab line left over from the pass before would be off by far more than a summation order
+    B = 100
+    try:
+        hip.check(hip.lib.dmvae_debug_set_knob(21, 1)); on = make(kw, "bf16", B, seed=5)
+        hip.check(hip.lib.dmvae_debug_set_knob(21, 0)); off = make(kw, "bf16", B, seed=5)
+        rng = np.random.RandomState(12)
+        for i in range(60):
+            X = torch.as_tensor((rng.rand(B, 784) * (rng.rand(B, 784) < 0.1 + 0.4 * rng.rand())).astype(np.float32)).cuda()
+            eps = torch.as_tensor(rng.randn(B, 10).astype(np.float32)).cuda()
+            out = []
+            for knob, e in ((1, on), (0, off)):
+                hip.check(hip.lib.dmvae_debug_set_knob(21, knob))
+                e.load_batch(X, None, 0, B)
+                e.forward_backward(B, eps)
+                torch.cuda.synchronize()
+                out.append((e.read_state().last_loss, e.view("mean").clone(), e.grad_view("W_enc0").clone(), e.grad_view("W_dec1").clone()))
+            assert abs(out[0][0] - out[1][0]) <= 1e-5 * abs(out[1][0]), (i, out[0][0], out[1][0])
+            for a, b in zip(out[0][1:], out[1][1:]):      # (bf16 activations downstream of another f32 summation order differ by a unit in the last place here and there:
+                assert (a - b).abs().max().item() <= 1e-2 * max(1e-9, b.abs().max().item()), i      #  2.5e-3 of a tensor's max seen; a stale slab is off by O(1))
+    finally:
+        hip.check(hip.lib.dmvae_debug_set_knob(21, 1))
+
+
 def test_pipelined_capture_is_the_default_for_small_batches_only(monkeypatch):
     """capture_step's default: pipelined up to PIPELINE_MAX_BATCH rows (measured: -2.7 % at 100 rows, -1.7 % at 2048, nothing at 4096), DMVAE_PREFETCH=0 / 1 forces"""
     from dmvae_hip import runtime
