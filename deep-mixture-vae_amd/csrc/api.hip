@@ -578,7 +578,7 @@ static int ksplit_for(const dmvae_plan* p, int N, int K, int epi) {
     const int tiles = (epi == DMVAE_EPI_LATENT ? (p->Bp + 15) / 16 : p->Bp / 64) * (N / 64);      // (the dZ GEMM runs on 16-row tiles; a slab is sized for a 64 x 64 tile either way)
     int S = std::min(KSPLIT_MAX_SLICES, K / (g_ksplit == 2 ? 256 : 512));      // (knob 21 = 2: slices of 256 instead of 512)
     while (S > 1 && (K % (S * 64) || tiles * S > 256 || (int64_t)tiles * S * 4096 > p->ksws_elems)) --S;
-    return (tiles <= 64 && tiles <= 256) ? std::max(S, 1) : 1;
+    return tiles <= 64 ? std::max(S, 1) : 1;      // (a launch that already covers a quarter of the chip keeps its K chain)
 }
 // a dense problem of the plan with its K slices, if the rule gives it any
 static int gemm_plan(dmvae_plan* p, hipStream_t s, int layout, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, const dmvae_epilogue* e,

@@ -94,6 +94,9 @@ __global__ __launch_bounds__(256) void heads_latent_kernel(HeadsLatentLaunch H) 
     }
     stage_offsets<128, false, 4, BK>(H.ldmv, wave, lane, goMV);
     stage_offsets<64, false, 4, BK>(H.ldlg, wave, lane, goLG);
+    // (MEASURED, round 5: requesting only the 16 columns of W_lg that K <= 16 classes multiply -- a [64][16] K tile by global_load_lds_dword, a fifth of the
+    //  ring's bytes less -- is bit-identical and changes nothing: 26.7 us for the launch, 0.2820 vs 0.2807 ms per step.  With the 5-slot ring (nothing
+    //  either) that rules out both the bytes and the depth of the ring as what this K loop waits for.  Not kept.)
     unsigned short foAz[2], foAc[2], foMV[2][2 * DP][2], foLG[2][2], unused;
     constexpr int MVHALF = DP == 1 ? 0 : 1;
     const int mv_half = MVHALF ? (wave >> 1) : 0;                              // Dp = 128: waves 0, 1 hold mean's columns, 2, 3 log_var's
