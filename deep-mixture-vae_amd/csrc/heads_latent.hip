@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void heads_latent_kernel(HeadsLatentLaunch H) 
             }
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();          // every wave is done with the ring: it becomes the f32 tile
+            { const LatentLaunch& L = H.L; (void)L; MEAS_LAT_STAMP(13); }      // (measurement build 7: the K loop has ended)
             const bool sliced = nsl > 1;                   // (then the biases are added behind the sum of the slices)
 #pragma unroll
             for (int j = 0; j < 2 * DP; ++j) {

@@ -43,6 +43,7 @@ template <int MODE, int DSL, bool FUSED, class TOP, class MID>   // MODE 0 exact
 __device__ __forceinline__ void latent_body(const LatentLaunch& L, lds_f* lds, lds_f* lds_rows, const int blk, const LatentTile tile, TOP&& top, MID&& mid) {
     const dmvae_latent_args& a = L.a;
     MEAS_LAT_STAMP(0);
+    top();          // (first of all: the reads of the step state below are a memory round trip the compiler waits for before anything that follows them)
     const int K = a.K, D = a.D, RB = L.RB;
     constexpr int DC = 16 * DSL, DCP = DC + 1;   // +1: rows of one column land on distinct banks (phase 1b / 2)
     lds_f* t1 = lds;                  // [K][DCP] prior means
@@ -68,7 +69,6 @@ __device__ __forceinline__ void latent_body(const LatentLaunch& L, lds_f* lds, l
     const float rB2 = 0.5f * rB;             // r / (2B)
     const float logK = __logf((float)K);
     const int dc0 = min(DC, D);
-    top();
 
     // ---- early global loads: tables of chunk 0, and this group's first row (logits, mean, log_var, eps)
     constexpr int TPF = 4, KF = 4;
@@ -140,7 +140,9 @@ __device__ __forceinline__ void latent_body(const LatentLaunch& L, lds_f* lds, l
         t1[k * DCP + d] = a.prior_means[(int64_t)k * D + d];
         t2[k * DCP + d] = (MODE == 0) ? __expf(-plv) : plv;
     }
+    MEAS_LAT_STAMP(11);
     if (!mid()) return;          // (fused kernel, K slices: only the last slice of a block to arrive goes on -- heads_latent.hip)
+    MEAS_LAT_STAMP(12);
     float klc_acc = 0.f, klz_acc = 0.f;   // per 16-lane group (all lanes of the group hold the same value)
     for (int r = rsub; r < RB; r += 16) {
         const bool first = !FUSED && r == rsub;
