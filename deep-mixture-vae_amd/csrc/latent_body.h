@@ -105,7 +105,25 @@ __device__ __forceinline__ void latent_body(const LatentLaunch& L, lds_f* lds, l
         }
     }
 
+    // FUSED: the K loop of the head GEMMs runs NOW -- behind the requests above and those of c_k's summands (when one pass covers them: K <= 16, D <= 64), in
+    // front of everything that consumes them: the tables reach LDS after the K loop, from registers, instead of holding its start back by their round
+    // trips (3.4 us into the kernel, profiles/r05_heads_latent_phases.txt); a K slice that is not the last to arrive never stages them at all
+    const bool ck_hoist = FUSED && K <= 16 && D <= 64;
+    float ck_pre[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ck_hoist) {
+        const int k = tid >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = lr + 16 * i;
+            ck_pre[i] = a.prior_log_vars[(int64_t)(k < K ? k : 0) * D + (d < D ? d : 0)];
+        }
+    }
     MEAS_LAT_STAMP(1);
+    if constexpr (FUSED) {
+        MEAS_LAT_STAMP(11);
+        if (!mid()) return;
+        MEAS_LAT_STAMP(12);
+    }
     // ---- prologue: c_k, tables of chunk 0 into LDS, per-row softmax / zeta, KL_C ----
     for (int k = tid >> 4; k < K; k += 16) {
         // four loads in flight per lane (index clamped, value selected): one load per trip of `for d: s += table[d]` was a memory round trip
@@ -116,7 +134,7 @@ __device__ __forceinline__ void latent_body(const LatentLaunch& L, lds_f* lds, l
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int d = d0 + 16 * i;
-                t[i] = a.prior_log_vars[(int64_t)k * D + (d < D ? d : 0)];
+                t[i] = ck_hoist ? ck_pre[i] : a.prior_log_vars[(int64_t)k * D + (d < D ? d : 0)];
                 t[i] = d < D ? t[i] : 0.f;
             }
 #pragma unroll
@@ -140,9 +158,7 @@ __device__ __forceinline__ void latent_body(const LatentLaunch& L, lds_f* lds, l
         t1[k * DCP + d] = a.prior_means[(int64_t)k * D + d];
         t2[k * DCP + d] = (MODE == 0) ? __expf(-plv) : plv;
     }
-    MEAS_LAT_STAMP(11);
-    if (!mid()) return;          // (fused kernel, K slices: only the last slice of a block to arrive goes on -- heads_latent.hip)
-    MEAS_LAT_STAMP(12);
+    if constexpr (!FUSED) { if (!mid()) return; }      // (nothing, unfused; FUSED: mid() ran above -- K slices: only the last slice of a block to arrive goes on, heads_latent.hip)
     float klc_acc = 0.f, klz_acc = 0.f;   // per 16-lane group (all lanes of the group hold the same value)
     for (int r = rsub; r < RB; r += 16) {
         const bool first = !FUSED && r == rsub;

@@ -1,6 +1,6 @@
 """Phase stamps of block 0 of the fused heads + latent launch (csrc/heads_latent.hip) at the metric's shape -- needs the abl7 measurement build
 (tools/ablate.sh 7; DMVAE_HIP_LIB=deep-mixture-vae_amd/build/libdmvae_hip_abl7.so).  Stamps (100 MHz): 0 entry, 1 first-row / table loads requested,
-11 prior tables staged (before the K loop), 13 K loop done, 12 f32 tile parked + written (mid() returned), 2 per-row prologue (softmax, KL_C) done,
+13 K loop done, 12 f32 tile parked + written (mid() returned), 2 prior tables staged + per-row prologue (softmax, KL_C) done,
 3 phase 1a, 4 phase 1b, 5 phase 2, 6 end.      python tools/hl_phases.py [rows]"""
 import ctypes as C, os, sys
 import numpy as np, torch
@@ -37,7 +37,7 @@ for it in range(30):
     st = lp[2 * nblk:].view(torch.int64).cpu().numpy()[:16].astype(np.int64)
     if it >= 10: rows.append(st.copy())
 st = np.median(np.array(rows), axis=0)
-order = [(0, "entry"), (1, "first loads requested"), (11, "tables staged"), (13, "K loop done"), (12, "tile parked + written"), (2, "row prologue (softmax, KL_C)"),
+order = [(0, "entry"), (1, "ring slots + stage's loads requested"), (13, "K loop done"), (12, "tile parked + written"), (2, "tables staged, row prologue (softmax, KL_C)"),
          (3, "phase 1a"), (4, "phase 1b"), (5, "phase 2"), (6, "end")]
 prev = st[0]
 for i, name in order:
