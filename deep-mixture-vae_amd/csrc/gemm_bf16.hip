@@ -462,13 +462,18 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& a, const int bid_
         constexpr int NB = NQE % 4 == 0 ? 4 : (NQE % 2 == 0 ? 2 : 1);
         const unsigned base = (unsigned)((reinterpret_cast<const float*>(a.epi.out) - ac->grad) + (int64_t)m0 * a.epi.ldo + n0);
 #ifndef DMVAE_ADAM_EPI_BATCHWISE
-        adam_pipelined<NB, NQE / NB>(*ac,
+#ifdef DMVAE_ADAM_EPI_NB
+        constexpr int PNB = NQE % DMVAE_ADAM_EPI_NB == 0 ? DMVAE_ADAM_EPI_NB : NB, PDEPTH = DMVAE_ADAM_EPI_DEPTH;
+#else
+        constexpr int PNB = NB, PDEPTH = 2;
+#endif
+        adam_pipelined<PNB, NQE / PNB, PDEPTH>(*ac,
             [&](int i, int b) {
-                const int idx = (i * NB + b) * NT + tid;
+                const int idx = (i * PNB + b) * NT + tid;
                 return base + (unsigned)(idx / CH) * (unsigned)a.epi.ldo + (unsigned)(idx % CH) * 4u;
             },
             [&](int i, int b, float (&gv)[4]) {
-                const int idx = (i * NB + b) * NT + tid;
+                const int idx = (i * PNB + b) * NT + tid;
                 const int ml = idx / CH, c = idx % CH;
                 const f32x4 t = *reinterpret_cast<const f32x4*>(ct + ml * BN + ((c ^ (ml & 7)) << 2));
                 gv[0] = t[0]; gv[1] = t[1]; gv[2] = t[2]; gv[3] = t[3];

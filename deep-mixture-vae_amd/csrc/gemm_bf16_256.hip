@@ -51,7 +51,11 @@ namespace dmvae {
 MEAS_TABLES_256
 constexpr int HALF_ELEMS = 128 * BK;     // one half-tile: 128 rows (or columns) x 64 k of bf16 = 16 KiB
 constexpr int LOOKAHEAD = 6;             // half-tiles issued ahead of the phase that consumes them
-constexpr int ADAM_NB = 4;               // quads per batch of the dW + Adam epilogue; two batches of parameter / m / v loads in flight (adam_pipelined)
+#ifndef DMVAE_ADAM256_NB
+#define DMVAE_ADAM256_NB 4
+#define DMVAE_ADAM256_DEPTH 2
+#endif
+constexpr int ADAM_NB = DMVAE_ADAM256_NB, ADAM_DEPTH = DMVAE_ADAM256_DEPTH;               // quads per batch of the dW + Adam epilogue; two batches of parameter / m / v loads in flight (adam_pipelined)
 template <int V> using IC = std::integral_constant<int, V>;
 
 // Bias gradient of a dW problem: db[n] = sum_k dY[k][n].  The smaller tiles get it from a ones-operand MFMA in the
@@ -282,7 +286,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& a, const dmvae_adam
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave, in-order LDS: the block is written
         if constexpr (EPI == DMVAE_EPI_ADAM) {                  // batches of ADAM_NB quads: loads of a batch in flight together (adam_quads)
             const unsigned base = (unsigned)((reinterpret_cast<const float*>(a.epi.out) - ac.grad) + (int64_t)(m0 + h * 128 + wr * 64) * a.epi.ldo + n0 + wc * 64 + li * 4);
-            adam_pipelined<ADAM_NB, 16 / ADAM_NB>(ac,
+            adam_pipelined<ADAM_NB, 16 / ADAM_NB, ADAM_DEPTH>(ac,
                 [&](int i, int b) { return base + (unsigned)((i * ADAM_NB + b) * 4 + g) * (unsigned)a.epi.ldo; },
                 [&](int i, int b, float (&gv)[4]) {
                     const int r = (i * ADAM_NB + b) * 4 + g;

@@ -197,14 +197,18 @@ __device__ __forceinline__ void adam_quads(const dmvae_adam_ctx& c, const unsign
     }
 }
 
-// The same over NBATCH batches, software-pipelined: the loads of batch i + 1 are issued BEFORE the stores of batch i.  vmcnt counts
-// loads and stores in issue order, so a load that follows stores is only seen once those stores are acknowledged; issued ahead of
-// them, the next batch's parameters arrive while this batch is computed and written.
-template <int NB, int NBATCH, class OFF, class G>
+// The same over NBATCH batches, software-pipelined: the loads of batches i + 1 .. i + DEPTH - 1 are issued BEFORE the stores of batch i.  vmcnt
+// counts loads and stores in issue order, so a load that follows stores is only seen once those stores are acknowledged; issued ahead of
+// them, the next batches' parameters arrive while this batch is computed and written.  DEPTH buffers of NB quads cost 12 DEPTH NB registers
+// and keep (DEPTH - 1) NB quads of loads in flight while a batch is waited for: for one register budget, small batches on a deep ring hold
+// more in flight than two large ones (2 x 4: 4 of 8 quads; 4 x 2: 6 of 8; 8 x 1: 7 of 8).  Same arithmetic per element in the same order
+// per address: bit-identical for every (NB, DEPTH).
+template <int NB, int NBATCH, int DEPTH = 2, class OFF, class G>
 __device__ __forceinline__ void adam_pipelined(const dmvae_adam_ctx& c, OFF&& off_of, G&& grad_of) {      // off_of(i, b) -> element offset; grad_of(i, b, g[4])
+    static_assert(DEPTH >= 2, "at least the batch in hand and the next one");
     const dmvae_state* st = reinterpret_cast<const dmvae_state*>(c.state);
     const float lr_t = st->lr_t;
-    float4 p[2][NB], m[2][NB], v[2][NB];
+    float4 p[DEPTH][NB], m[DEPTH][NB], v[DEPTH][NB];
     auto load = [&](int i, int buf) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -214,11 +218,13 @@ __device__ __forceinline__ void adam_pipelined(const dmvae_adam_ctx& c, OFF&& of
             v[buf][b] = *reinterpret_cast<const float4*>(c.v + o);
         }
     };
-    load(0, 0);
+#pragma unroll
+    for (int i = 0; i < DEPTH - 1; ++i)
+        if (i < NBATCH) load(i, i);
 #pragma unroll
     for (int i = 0; i < NBATCH; ++i) {
-        const int buf = i & 1;
-        if (i + 1 < NBATCH) load(i + 1, buf ^ 1);
+        const int buf = i % DEPTH;
+        if (i + DEPTH - 1 < NBATCH) load(i + DEPTH - 1, (i + DEPTH - 1) % DEPTH);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const unsigned o = off_of(i, b);
