@@ -962,6 +962,9 @@ static int grouped_launch(hipStream_t s, const GemmArgs* probs, int nprob, const
     }();
     ProfScope ps(s, pname.c_str(), flops, bytes);
     // (8-wave workgroups in the grouped grids were measured too: 0.3071 vs 0.3014 ms/step, not kept)
+    // (ONE workgroup per CU at a time -- the launch padding its LDS request -- with half of the CUs dealt a long tile first and the others a short one, so
+    //  that the long tiles' Adam epilogues fall into two bunches under the other half's K loops, was measured in round 5 for the weight-gradient group:
+    //  bit-identical, cfg2 0.2700 -> 0.2943 ms, cfg4 0.6099 -> 0.7127.  Two resident workgroups overlapping their K loops are worth more than un-bunched epilogues.)
     if constexpr (LAYOUT != DMVAE_GEMM_DW) {
         if (shortk) {
             DMVAE_LAUNCH((gemm_bf16_grouped_kernel<64, 64, LAYOUT, EPI, 2, 4, true>), dim3(total + extra), dim3(256), 0, s, g);
